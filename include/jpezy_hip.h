@@ -1,0 +1,140 @@
+/*
+ * jpezy_hip.h -- C-ABI of the MI355X (gfx950) baseline-JPEG hot path of falgon/jpezy.
+ *
+ * The reference has no FFI seam: its hot path is a set of private member functions of two class
+ * templates.  This header is the seam a maintainer binds instead; every entry
+ * point cites the reference code it replaces (paths relative to /root/reference/src/).
+ *
+ * Conventions: plain C, no exceptions cross the boundary.  Functions returning int give 0 on success
+ * and a negative jpezy_status otherwise; jpezy_hip_last_error() (thread-local) says why.  The caller
+ * owns every buffer it passes; the library owns streams and scratch inside the opaque context.  A
+ * context is used by one thread at a time; distinct contexts (one per GPU) may run concurrently.
+ * There is NO CPU fallback: without a HIP device every compute entry point fails with JPEZY_E_NODEVICE.
+ *
+ * Coefficient buffer layout (both directions), per frame:
+ *     int16_t coeffs[mcu_rows][mcu_cols][B][64]
+ * MCUs row-major with mcu_cols = ceil(W/16), mcu_rows = ceil(H/16) (encoder/jpezy_encoder.hpp:55-56);
+ * B = 6 blocks in the order Y0(top-left) Y1(top-right) Y2(bottom-left) Y3(bottom-right) Cb Cr
+ * (jpezy_encoder.hpp:227-242), or B = 4 (Y0..Y3) when gray != 0 -- in GRAY_MODE the reference zeroes
+ * the chroma blocks (jpezy_encoder.hpp:61-64) so they are not materialised; inside a block the 64
+ * quantised coefficients are in ZIG-ZAG order: coeffs[n] = q[ZZ[n]] (jpezy.hpp:36-45).
+ * Pixel planes are planar 8-bit r, g, b with row stride W, W*H bytes each (jpezy_encoder.hpp:105,266).
+ */
+#ifndef JPEZY_HIP_H
+#define JPEZY_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct jpezy_ctx jpezy_ctx;
+
+enum jpezy_status {
+    JPEZY_OK = 0,
+    JPEZY_E_BADARG = -1,      /* null pointer, non-positive or > 65535 dimension, ...                */
+    JPEZY_E_NODEVICE = -2,    /* no HIP device / device index out of range                           */
+    JPEZY_E_HIP = -3,         /* a HIP runtime call failed (message in jpezy_hip_last_error)         */
+    JPEZY_E_UNSUPPORTED = -4, /* decode layout other than jpezy's own 2x2,1x1,1x1 3-component files  */
+    JPEZY_E_FORMAT = -5,      /* malformed JPEG / Huffman stream (the reference throws runtime_error) */
+    JPEZY_E_NOSPACE = -6      /* output buffer too small                                             */
+};
+
+const char* jpezy_hip_last_error(void);
+int jpezy_hip_device_count(void);
+
+/* ---- context: one per GPU.  Owns a HIP stream, staging buffers and the device constant tables ---- */
+jpezy_ctx* jpezy_ctx_create(int device);
+void jpezy_ctx_destroy(jpezy_ctx* ctx);
+int jpezy_ctx_sync(jpezy_ctx* ctx);
+int jpezy_ctx_device(const jpezy_ctx* ctx);
+
+/* ---- geometry helpers (jpezy_encoder.hpp:55-56) ---- */
+int jpezy_mcu_cols(int W);
+int jpezy_mcu_rows(int H);
+size_t jpezy_coeff_count(int W, int H, int gray);   /* int16 elements per frame */
+
+/*
+ * ENCODE compute stage.  Replaces, for every MCU of every frame, the reference's
+ *   encoder::make_YCC      (encoder/jpezy_encoder.hpp:90-144)   RGB->YCbCr, edge clamp, 2x2 decimation
+ *   RGB::Y/Cb/Cr           (:244-256)                            truncating FP64 colour conversion
+ *   encoder::DCT           (:146-166)                            8x8 FDCT, int(sum*cu*cv/4)
+ *   encoder::quantization  (:168-172)                            Annex-K, C++ int division
+ *   the ZZ read order of encode_huffman (:195,212)               zig-zag
+ * i.e. everything in the MCU loop (:58-67) except encode_huffman.  Results are bit-identical to the
+ * reference arithmetic evaluated in IEEE binary64 without contraction ("exactness").
+ *
+ * jpezy_fdct_quant: host buffers (what encoder::encode calls).  r,g,b: n_frames consecutive W*H planes.
+ */
+int jpezy_fdct_quant(jpezy_ctx* ctx, const uint8_t* r, const uint8_t* g, const uint8_t* b, int W, int H,
+                     int gray, int n_frames, int16_t* coeffs);
+/*
+ * jpezy_fdct_quant_dev: same, all pointers are DEVICE pointers; plane_stride = bytes between
+ * consecutive frames of one plane (>= W*H); asynchronous on `stream` (a hipStream_t; NULL = the
+ * context's own stream).  Used by batch drivers / the benchmark with inputs resident in HBM.
+ */
+int jpezy_fdct_quant_dev(jpezy_ctx* ctx, const uint8_t* d_r, const uint8_t* d_g, const uint8_t* d_b,
+                         size_t plane_stride, int W, int H, int gray, int n_frames, int16_t* d_coeffs,
+                         void* stream);
+
+/*
+ * DECODE compute stage.  Replaces, for every MCU, the reference's
+ *   decoder::inverse_quantization (decoder/jpezy_decoder.hpp:645-650)
+ *   decoder::inverse_dct          (:652-670)      int(sum/4 + 128), no clamp
+ *   decode_mcu's replication      (:519-524)      nearest-neighbour chroma upsample
+ *   decoder::make_rgb / to_r,g,b / revise_value (:531-578, 672-676)
+ * for files with jpezy's own layout (3 components, sampling 2x2,1x1,1x1, 8-bit).  qt: four 64-entry
+ * tables in NATURAL order (as analyze_dqt leaves them, :258-277); comp_tq[c] selects the table of
+ * component c (Frame_component::Tq).  gray != 0 is GRAY_MODE: r = g = b = clamp(Y) (:561); coeffs keep
+ * the 6-block layout (a decoded file always carries chroma blocks).
+ */
+int jpezy_dequant_idct(jpezy_ctx* ctx, const int16_t* coeffs, const uint16_t qt[4][64],
+                       const uint8_t comp_tq[3], int W, int H, int gray, int n_frames, uint8_t* r,
+                       uint8_t* g, uint8_t* b);
+int jpezy_dequant_idct_dev(jpezy_ctx* ctx, const int16_t* d_coeffs, const uint16_t qt[4][64],
+                           const uint8_t comp_tq[3], size_t plane_stride, int W, int H, int gray,
+                           int n_frames, uint8_t* d_r, uint8_t* d_g, uint8_t* d_b, void* stream);
+
+/* Test hook: route EVERY coefficient / sample through the kernels' exact-order fallback (the path a
+ * guard-band hit takes).  0 = normal.  Exists so that the rare branch has its own parity test. */
+void jpezy_ctx_set_force_exact(jpezy_ctx* ctx, int on);
+/* Synchronises the device and returns how many coefficients/samples were resolved through the
+ * exact-order fallback on this context since the previous call (the counter is then reset); -1 on error */
+long jpezy_ctx_last_fallback_count(jpezy_ctx* ctx);
+
+/*
+ * HOST serial tail / head (stay on the CPU per BASELINE.json north_star).
+ *
+ * jpezy_write_jpeg replaces jpezy_writer::write_header/write_eoi (encoder/jpezy_writer.hpp:20-105) and
+ * encoder::encode_huffman (encoder/jpezy_encoder.hpp:174-225) with the Annex-K tables of
+ * encoder/huffman_table.hpp.  comment may be NULL/"" (no COM segment).  Returns bytes written (the
+ * value encoder::encode returns, :76) or a negative status.
+ */
+long jpezy_write_jpeg(const int16_t* coeffs, int W, int H, int gray, const char* comment, uint8_t* out,
+                      size_t cap);
+size_t jpezy_jpeg_bound(int W, int H);   /* a cap that always suffices */
+
+typedef struct jpezy_frame_info {
+    int width, height, ncomp, precision;
+    int H[3], V[3], Tq[3];
+    int hmax, vmax, mcu_cols, mcu_rows, blocks_per_mcu;
+    int restart_interval;
+    int major_rev, minor_rev, units, hdensity, vdensity;
+    int format;               /* 0 undefined, 1 JFIF, 2 JFXX (jpezy.hpp:155-160) */
+    char comment[256];
+    uint16_t qt[4][64];       /* natural order */
+} jpezy_frame_info;
+
+/*
+ * jpezy_read_jpeg replaces decoder::analyze_header and the marker parsers (decoder/jpezy_decoder.hpp:
+ * 171-502) and decoder::decode_huffman (:583-642).  coeffs (may be NULL: headers only) receives
+ * [mcu][block][64] int16 in zig-zag order with DC prediction undone.
+ */
+int jpezy_read_jpeg(const uint8_t* data, size_t len, jpezy_frame_info* info, int16_t* coeffs,
+                    size_t coeff_cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

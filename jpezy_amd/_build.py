@@ -1,0 +1,78 @@
+"""Builds the in-tree native artefacts with hipcc (gfx950 only; cross-compiles without a GPU).
+
+    libjpezy_hip.so   the C-ABI library (include/jpezy_hip.h): HIP kernels + context + host Huffman/JFIF
+    bin/jpezy_encode, bin/jpezy_decode   the CLIs (C++ host code linked against the library)
+"""
+import os
+import shutil
+import subprocess
+from pathlib import Path
+
+PKG = Path(__file__).resolve().parent
+CSRC = PKG / "csrc"
+ROOT = PKG.parent
+LIB = PKG / "libjpezy_hip.so"
+BIN = PKG / "bin"
+
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+# -ffp-contract=off: the reference arithmetic is plain IEEE mul/add; every FMA in the kernels is explicit.
+COMMON = ["-std=c++17", "-O3", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
+DEVICE = ["--offload-arch=gfx950"]
+
+LIB_SOURCES = [CSRC / "jpezy_kernels.hip", CSRC / "jpezy_capi.hip", CSRC / "jpezy_host_codec.cpp"]
+LIB_DEPS = LIB_SOURCES + [CSRC / "jpezy_device.h", CSRC / "jpezy_host_codec.h",
+                          ROOT / "include" / "jpezy_hip.h", ROOT / "include" / "jpezy_constants.h"]
+CLI = {"jpezy_encode": CSRC / "host" / "encode_main.cpp", "jpezy_decode": CSRC / "host" / "decode_main.cpp"}
+
+
+def _stale(target, deps):
+    if not target.exists():
+        return True
+    t = target.stat().st_mtime
+    return any(d.exists() and d.stat().st_mtime > t for d in deps)
+
+
+def _run(cmd):
+    proc = subprocess.run([str(c) for c in cmd], capture_output=True, text=True)
+    if proc.returncode != 0:
+        raise RuntimeError("build failed:\n" + " ".join(map(str, cmd)) + "\n" + proc.stdout + proc.stderr)
+    return proc.stdout + proc.stderr
+
+
+def build_lib(force=False, verbose=False):
+    if force or _stale(LIB, LIB_DEPS):
+        objs = []
+        for src in LIB_SOURCES:
+            obj = src.with_suffix(".o")
+            flags = COMMON + (DEVICE if src.suffix == ".hip" else ["-x", "c++"])
+            out = _run([HIPCC, *flags, "-c", src, "-o", obj])
+            if verbose and out.strip():
+                print(out)
+            objs.append(obj)
+        _run([HIPCC, "-shared", "-fPIC", *DEVICE, "-o", LIB, *objs])
+    return LIB
+
+
+def build_cli(force=False):
+    BIN.mkdir(exist_ok=True)
+    host_hdrs = list((CSRC / "host").glob("*.hpp"))
+    for name, src in CLI.items():
+        if not src.exists():
+            continue
+        exe = BIN / name
+        if force or _stale(exe, [src, LIB, *host_hdrs]):
+            _run([HIPCC, *COMMON, "-x", "c++", src, "-I", ROOT / "include", "-o", exe,
+                  "-L", PKG, "-ljpezy_hip", f"-Wl,-rpath,{PKG}", "-Wl,-rpath,$ORIGIN/..", "-lpthread"])
+    return BIN
+
+
+def build_all(force=False, verbose=False):
+    build_lib(force, verbose)
+    build_cli(force)
+    return LIB
+
+
+if __name__ == "__main__":
+    import sys
+    build_all(force="--force" in sys.argv, verbose=True)
+    print("built", LIB)

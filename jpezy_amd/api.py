@@ -1,0 +1,273 @@
+"""ctypes binding of include/jpezy_hip.h plus a Python mirror of the reference's encoder/decoder surface.
+
+Naming follows the reference: `Encoder(property, r, g, b).encode(output_file, gray=...)` mirrors
+`jpezy::encoder<T>::encode<MODE_TAG>(const char*)` (ref encoder/jpezy_encoder.hpp:22-77) and
+`Decoder(filename).decode(gray=...)` mirrors `jpezy::decoder<>::decode<MODE_TAG>()`
+(ref decoder/jpezy_decoder.hpp:39-134).  All compute goes through the C-ABI; nothing here touches oracle/.
+"""
+import ctypes as C
+from pathlib import Path
+
+import numpy as np
+
+_PKG = Path(__file__).resolve().parent
+_LIBPATH = _PKG / "libjpezy_hip.so"
+_LIB = None
+
+
+class JpezyError(RuntimeError):
+    pass
+
+
+class FrameInfo(C.Structure):
+    _fields_ = [
+        ("width", C.c_int), ("height", C.c_int), ("ncomp", C.c_int), ("precision", C.c_int),
+        ("H", C.c_int * 3), ("V", C.c_int * 3), ("Tq", C.c_int * 3),
+        ("hmax", C.c_int), ("vmax", C.c_int), ("mcu_cols", C.c_int), ("mcu_rows", C.c_int),
+        ("blocks_per_mcu", C.c_int), ("restart_interval", C.c_int),
+        ("major_rev", C.c_int), ("minor_rev", C.c_int), ("units", C.c_int),
+        ("hdensity", C.c_int), ("vdensity", C.c_int), ("format", C.c_int),
+        ("comment", C.c_char * 256),
+        ("qt", (C.c_uint16 * 64) * 4),
+    ]
+
+
+# every symbol include/jpezy_hip.h declares: (name, restype, argtypes)
+_u8p, _i16p, _vp = C.POINTER(C.c_uint8), C.POINTER(C.c_int16), C.c_void_p
+_QT = C.POINTER((C.c_uint16 * 64) * 4)
+_TQ = C.POINTER(C.c_uint8 * 3)
+ABI = [
+    ("jpezy_hip_last_error", C.c_char_p, []),
+    ("jpezy_hip_device_count", C.c_int, []),
+    ("jpezy_ctx_create", _vp, [C.c_int]),
+    ("jpezy_ctx_destroy", None, [_vp]),
+    ("jpezy_ctx_sync", C.c_int, [_vp]),
+    ("jpezy_ctx_device", C.c_int, [_vp]),
+    ("jpezy_mcu_cols", C.c_int, [C.c_int]),
+    ("jpezy_mcu_rows", C.c_int, [C.c_int]),
+    ("jpezy_coeff_count", C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    ("jpezy_fdct_quant", C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
+    ("jpezy_fdct_quant_dev", C.c_int, [_vp, _vp, _vp, _vp, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp]),
+    ("jpezy_dequant_idct", C.c_int, [_vp, _vp, _QT, _TQ, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp]),
+    ("jpezy_dequant_idct_dev", C.c_int, [_vp, _vp, _QT, _TQ, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp]),
+    ("jpezy_ctx_set_force_exact", None, [_vp, C.c_int]),
+    ("jpezy_ctx_last_fallback_count", C.c_long, [_vp]),
+    ("jpezy_write_jpeg", C.c_long, [_vp, C.c_int, C.c_int, C.c_int, C.c_char_p, _vp, C.c_size_t]),
+    ("jpezy_jpeg_bound", C.c_size_t, [C.c_int, C.c_int]),
+    ("jpezy_read_jpeg", C.c_int, [_vp, C.c_size_t, C.POINTER(FrameInfo), _vp, C.c_size_t]),
+]
+
+
+def library_path():
+    return _LIBPATH
+
+
+def load_library():
+    """Load libjpezy_hip.so (built by `python -m jpezy_amd._build` / __graft_entry__.build()).  Fails loudly."""
+    global _LIB
+    if _LIB is None:
+        if not _LIBPATH.exists():
+            raise JpezyError(f"{_LIBPATH} is missing: build it with `python -m jpezy_amd._build` "
+                             "(there is no CPU fallback for the jpezy hot path)")
+        lib = C.CDLL(str(_LIBPATH))
+        for name, res, args in ABI:
+            fn = getattr(lib, name)          # AttributeError if the library does not export the symbol
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = lib
+    return _LIB
+
+
+def _check(rc):
+    if rc < 0:
+        raise JpezyError(f"jpezy status {rc}: {load_library().jpezy_hip_last_error().decode()}")
+    return rc
+
+
+def mcu_grid(W, H):
+    lib = load_library()
+    return lib.jpezy_mcu_cols(W), lib.jpezy_mcu_rows(H)
+
+
+def coeff_count(W, H, gray=False):
+    return load_library().jpezy_coeff_count(W, H, int(gray))
+
+
+def _np_ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+ANNEX_K_INFO = None
+
+
+def annex_k_tables():
+    """(qt[4][64] ctypes array, comp_tq) of a file written by jpezy_encode, parsed from a header-only file."""
+    global ANNEX_K_INFO
+    if ANNEX_K_INFO is None:
+        z = np.zeros(6 * 64, dtype=np.int16)
+        info, _ = read_jpeg(write_jpeg(z, 16, 16))
+        ANNEX_K_INFO = info
+    return ANNEX_K_INFO
+
+
+class Context:
+    """One per GPU: wraps jpezy_ctx (stream + device tables + staging)."""
+
+    def __init__(self, device=0):
+        lib = load_library()
+        self._h = lib.jpezy_ctx_create(device)
+        if not self._h:
+            raise JpezyError("jpezy_ctx_create failed: " + lib.jpezy_hip_last_error().decode())
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_h", None):
+            load_library().jpezy_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        _check(load_library().jpezy_ctx_sync(self._h))
+
+    def set_force_exact(self, on):
+        load_library().jpezy_ctx_set_force_exact(self._h, int(bool(on)))
+
+    def fallback_count(self):
+        return load_library().jpezy_ctx_last_fallback_count(self._h)
+
+    # ---- host-buffer entry points (numpy) ----
+    def fdct_quant(self, r, g, b, W, H, gray=False, n_frames=1):
+        planes = [np.ascontiguousarray(p, dtype=np.uint8).reshape(-1) for p in (r, g, b)]
+        for p in planes:
+            if p.size != W * H * n_frames:
+                raise JpezyError("plane size does not match W*H*n_frames")
+        mc, mr = mcu_grid(W, H)
+        out = np.empty((n_frames, mr, mc, 4 if gray else 6, 64), dtype=np.int16)
+        _check(load_library().jpezy_fdct_quant(self._h, _np_ptr(planes[0]), _np_ptr(planes[1]), _np_ptr(planes[2]),
+                                               W, H, int(gray), n_frames, _np_ptr(out)))
+        return out[0] if n_frames == 1 else out
+
+    def dequant_idct(self, coeffs, W, H, qt=None, comp_tq=(0, 1, 1), gray=False, n_frames=1):
+        coeffs = np.ascontiguousarray(coeffs, dtype=np.int16)
+        if coeffs.size != coeff_count(W, H, False) * n_frames:
+            raise JpezyError("coefficient buffer size does not match the 6-block layout")
+        qtab = qt if qt is not None else annex_k_tables().qt
+        tq = (C.c_uint8 * 3)(*comp_tq)
+        planes = [np.empty(W * H * n_frames, dtype=np.uint8) for _ in range(3)]
+        _check(load_library().jpezy_dequant_idct(self._h, _np_ptr(coeffs), C.byref(qtab), C.byref(tq), W, H, int(gray),
+                                                 n_frames, _np_ptr(planes[0]), _np_ptr(planes[1]), _np_ptr(planes[2])))
+        return planes
+
+    # ---- device-pointer entry points (torch tensors on this context's device) ----
+    def fdct_quant_dev(self, d_r, d_g, d_b, W, H, d_coeffs, gray=False, n_frames=1, plane_stride=None, stream=None):
+        import torch
+        if stream is None:
+            stream = torch.cuda.current_stream(d_r.device).cuda_stream
+        stride = plane_stride if plane_stride is not None else W * H
+        _check(load_library().jpezy_fdct_quant_dev(self._h, d_r.data_ptr(), d_g.data_ptr(), d_b.data_ptr(), stride, W, H,
+                                                   int(gray), n_frames, d_coeffs.data_ptr(), stream))
+
+    def dequant_idct_dev(self, d_coeffs, W, H, d_r, d_g, d_b, qt=None, comp_tq=(0, 1, 1), gray=False, n_frames=1,
+                         plane_stride=None, stream=None):
+        import torch
+        if stream is None:
+            stream = torch.cuda.current_stream(d_coeffs.device).cuda_stream
+        qtab = qt if qt is not None else annex_k_tables().qt
+        tq = (C.c_uint8 * 3)(*comp_tq)
+        stride = plane_stride if plane_stride is not None else W * H
+        _check(load_library().jpezy_dequant_idct_dev(self._h, d_coeffs.data_ptr(), C.byref(qtab), C.byref(tq), stride, W, H,
+                                                     int(gray), n_frames, d_r.data_ptr(), d_g.data_ptr(), d_b.data_ptr(),
+                                                     stream))
+
+
+# ---- host serial tail / head ----
+def write_jpeg(coeffs, W, H, gray=False, comment=None):
+    """zig-zag int16 coefficients -> the .jpg bytes jpezy_encode writes (header + Huffman + EOI)."""
+    lib = load_library()
+    coeffs = np.ascontiguousarray(coeffs, dtype=np.int16)
+    if coeffs.size != lib.jpezy_coeff_count(W, H, int(gray)):
+        raise JpezyError("coefficient buffer size does not match W, H, gray")
+    if comment is None:
+        comment = b"Encoded by JPEZY" if gray else b"Encoded by jpezy"   # ref encode_io.hpp:149,181
+    cap = lib.jpezy_jpeg_bound(W, H)
+    buf = np.empty(cap, dtype=np.uint8)
+    n = _check(lib.jpezy_write_jpeg(_np_ptr(coeffs), W, H, int(gray), comment, _np_ptr(buf), cap))
+    return buf[:n].tobytes()
+
+
+def read_jpeg(data):
+    """.jpg bytes -> (FrameInfo, int16 coeffs [mcu_rows, mcu_cols, blocks_per_mcu, 64] in zig-zag order)."""
+    lib = load_library()
+    arr = np.frombuffer(bytes(data), dtype=np.uint8)
+    info = FrameInfo()
+    _check(lib.jpezy_read_jpeg(_np_ptr(arr), arr.size, C.byref(info), None, 0))
+    co = np.zeros((info.mcu_rows, info.mcu_cols, info.blocks_per_mcu, 64), dtype=np.int16)
+    _check(lib.jpezy_read_jpeg(_np_ptr(arr), arr.size, C.byref(info), _np_ptr(co), co.size))
+    return info, co
+
+
+_DEFAULT_CTX = {}
+
+
+def default_context(device=0):
+    if device not in _DEFAULT_CTX:
+        _DEFAULT_CTX[device] = Context(device)
+    return _DEFAULT_CTX[device]
+
+
+class Encoder:
+    """Mirror of jpezy::encoder<T> (ref encoder/jpezy_encoder.hpp:22-77): holds copies of the planes;
+    encode() runs the compute stage on the GPU and the Huffman/JFIF tail on the host, writes the file and
+    returns the number of bytes written."""
+
+    block_size = 8
+
+    def __init__(self, width, height, r, g, b, ctx=None):
+        self.width, self.height = int(width), int(height)
+        self.r, self.g, self.b = (np.array(p, dtype=np.uint8, copy=True).reshape(-1) for p in (r, g, b))
+        self.ctx = ctx
+
+    def coefficients(self, gray=False):
+        ctx = self.ctx or default_context()
+        return ctx.fdct_quant(self.r, self.g, self.b, self.width, self.height, gray=gray)
+
+    def encode_bytes(self, gray=False):
+        return write_jpeg(self.coefficients(gray), self.width, self.height, gray)
+
+    def encode(self, output_file, gray=False):
+        data = self.encode_bytes(gray)
+        with open(output_file, "wb") as f:
+            f.write(data)
+        return len(data)
+
+
+class Decoder:
+    """Mirror of jpezy::decoder<> (ref decoder/jpezy_decoder.hpp:39-134): decode() returns (r, g, b) planes
+    of W*H bytes each, or None where the reference returns an empty optional."""
+
+    rgb_size, block_size, blocks_size, mcu_size = 3, 8, 64, 4
+
+    def __init__(self, filename, ctx=None):
+        self.filename = filename
+        self.ctx = ctx
+        self.pr = None
+
+    def decode(self, gray=False):
+        try:
+            with open(self.filename, "rb") as f:
+                data = f.read()
+            info, coeffs = read_jpeg(data)
+        except (OSError, JpezyError):
+            return None
+        self.pr = info
+        layout = [(info.H[i], info.V[i]) for i in range(info.ncomp)]
+        if info.ncomp != 3 or layout != [(2, 2), (1, 1), (1, 1)] or info.precision != 8:
+            raise JpezyError("decode layout other than 2x2,1x1,1x1 is not on the GPU path yet (JPEZY_E_UNSUPPORTED)")
+        ctx = self.ctx or default_context()
+        tq = tuple(info.Tq[i] for i in range(3))
+        return ctx.dequant_idct(coeffs, info.width, info.height, qt=info.qt, comp_tq=tq, gray=gray)

@@ -1,0 +1,332 @@
+// jpezy_capi.hip -- implementation of the C-ABI declared in include/jpezy_hip.h.
+// Owns: per-GPU context (device id, stream, device constant tables, staging buffers, fallback counter).
+// No CPU fallback: every compute entry point needs a HIP device.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "../../include/jpezy_constants.h"
+#include "../../include/jpezy_hip.h"
+#include "jpezy_device.h"
+#include "jpezy_host_codec.h"
+
+using namespace jpezy_dev;
+
+namespace {
+
+thread_local std::string g_err;
+
+int set_err(int code, const std::string& msg)
+{
+    g_err = msg;
+    return code;
+}
+int hip_err(hipError_t e, const char* what)
+{
+    return set_err(JPEZY_E_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+#define HIP_TRY(expr)                                     \
+    do {                                                  \
+        hipError_t e__ = (expr);                          \
+        if (e__ != hipSuccess) return hip_err(e__, #expr); \
+    } while (0)
+
+const int kQt[2][64] = { JPEZY_QT_LUMA_INIT, JPEZY_QT_CHROMA_INIT };
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t n)
+    {
+        if (n <= cap) return 0;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        hipError_t e = hipMalloc(&p, n);
+        if (e != hipSuccess) return hip_err(e, "hipMalloc");
+        cap = n;
+        return 0;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+}  // namespace
+
+struct jpezy_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    DeviceTables* d_tab = nullptr;
+    unsigned long long* d_counter = nullptr;
+    double* d_dqscale = nullptr;   // [3][8][8]
+    int* d_dqt = nullptr;          // [3][64]
+    uint16_t dq_cache[3][64];
+    bool dq_valid = false;
+    bool force_exact = false;
+    DevBuf in[3], out;             // staging for the host-buffer entry points
+};
+
+extern "C" {
+
+const char* jpezy_hip_last_error(void) { return g_err.c_str(); }
+
+int jpezy_hip_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int jpezy_mcu_cols(int W) { return (W / 16) + ((W % 16) ? 1 : 0); }
+int jpezy_mcu_rows(int H) { return (H / 16) + ((H % 16) ? 1 : 0); }
+size_t jpezy_coeff_count(int W, int H, int gray)
+{
+    if (W <= 0 || H <= 0) return 0;
+    return (size_t)jpezy_mcu_cols(W) * (size_t)jpezy_mcu_rows(H) * (gray ? 4 : 6) * 64;
+}
+
+jpezy_ctx* jpezy_ctx_create(int device)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        set_err(JPEZY_E_NODEVICE, "no HIP device (the jpezy hot path has no CPU fallback)");
+        return nullptr;
+    }
+    if (device < 0 || device >= n) {
+        set_err(JPEZY_E_NODEVICE, "device index out of range");
+        return nullptr;
+    }
+    jpezy_ctx* c = new jpezy_ctx;
+    c->device = device;
+    DeviceTables h;
+    const double S = JPEZY_INV_SQRT2;
+    for (int t = 0; t < 2; ++t) {
+        for (int j = 0; j < 8; ++j)
+            for (int i = 0; i < 8; ++i) {
+                const double cu = j ? 1.0 : S, cv = i ? 1.0 : S;
+                h.qscale[t][j][i] = cu * cv / (4.0 * kQt[t][i * 8 + j]) * (double)(1 << QFRAC_BITS);
+            }
+        h.rq_dc[t] = 1.0 / kQt[t][0];
+        for (int k = 0; k < 64; ++k) h.qt[t][k] = kQt[t][k];
+    }
+    bool ok = hipSetDevice(device) == hipSuccess;
+    ok = ok && hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
+    ok = ok && hipMalloc((void**)&c->d_tab, sizeof(DeviceTables)) == hipSuccess;
+    ok = ok && hipMalloc((void**)&c->d_counter, sizeof(unsigned long long)) == hipSuccess;
+    ok = ok && hipMalloc((void**)&c->d_dqscale, sizeof(double) * 3 * 64) == hipSuccess;
+    ok = ok && hipMalloc((void**)&c->d_dqt, sizeof(int) * 3 * 64) == hipSuccess;
+    ok = ok && hipMemcpy(c->d_tab, &h, sizeof h, hipMemcpyHostToDevice) == hipSuccess;
+    ok = ok && hipMemset(c->d_counter, 0, sizeof(unsigned long long)) == hipSuccess;
+    if (!ok) {
+        set_err(JPEZY_E_HIP, std::string("context creation failed: ") + hipGetErrorString(hipGetLastError()));
+        jpezy_ctx_destroy(c);
+        return nullptr;
+    }
+    return c;
+}
+
+void jpezy_ctx_destroy(jpezy_ctx* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
+    if (c->d_tab) (void)hipFree(c->d_tab);
+    if (c->d_counter) (void)hipFree(c->d_counter);
+    if (c->d_dqscale) (void)hipFree(c->d_dqscale);
+    if (c->d_dqt) (void)hipFree(c->d_dqt);
+    for (auto& b : c->in) b.release();
+    c->out.release();
+    delete c;
+}
+
+int jpezy_ctx_sync(jpezy_ctx* c)
+{
+    if (!c) return set_err(JPEZY_E_BADARG, "null context");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return JPEZY_OK;
+}
+
+int jpezy_ctx_device(const jpezy_ctx* c) { return c ? c->device : -1; }
+
+void jpezy_ctx_set_force_exact(jpezy_ctx* c, int on)
+{
+    if (c) c->force_exact = on != 0;
+}
+
+long jpezy_ctx_last_fallback_count(jpezy_ctx* c)
+{
+    if (!c) return -1;
+    unsigned long long v = 0;
+    if (hipSetDevice(c->device) != hipSuccess) return -1;
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpy(&v, c->d_counter, sizeof v, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    if (hipMemset(c->d_counter, 0, sizeof v) != hipSuccess) return -1;
+    return (long)v;
+}
+
+static int check_dims(const jpezy_ctx* c, int W, int H, int n_frames)
+{
+    if (!c) return set_err(JPEZY_E_BADARG, "null context");
+    if (W <= 0 || H <= 0 || W > 65535 || H > 65535) return set_err(JPEZY_E_BADARG, "width/height must be in 1..65535 (16-bit SOF0 fields)");
+    if (n_frames <= 0) return set_err(JPEZY_E_BADARG, "n_frames must be positive");
+    return JPEZY_OK;
+}
+
+int jpezy_fdct_quant_dev(jpezy_ctx* c, const uint8_t* d_r, const uint8_t* d_g, const uint8_t* d_b,
+                         size_t plane_stride, int W, int H, int gray, int n_frames, int16_t* d_coeffs, void* stream)
+{
+    if (int rc = check_dims(c, W, H, n_frames)) return rc;
+    if (!d_r || !d_g || !d_b || !d_coeffs) return set_err(JPEZY_E_BADARG, "null device pointer");
+    if (plane_stride < (size_t)W * H) return set_err(JPEZY_E_BADARG, "plane_stride smaller than W*H");
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    EncParams p;
+    p.r = d_r; p.g = d_g; p.b = d_b;
+    p.plane_stride = plane_stride;
+    p.coeffs = d_coeffs;
+    p.coeffs_per_frame = jpezy_coeff_count(W, H, gray);
+    p.tab = c->d_tab;
+    p.fallback_count = c->d_counter;
+    p.W = W; p.H = H;
+    p.mcu_cols = jpezy_mcu_cols(W);
+    p.mcu_rows = jpezy_mcu_rows(H);
+    p.quads_per_row = (p.mcu_cols + 3) / 4;
+    p.n_frames = n_frames;
+    HIP_TRY(launch_fdct_quant(p, gray != 0, c->force_exact, s));
+    return JPEZY_OK;
+}
+
+int jpezy_fdct_quant(jpezy_ctx* c, const uint8_t* r, const uint8_t* g, const uint8_t* b, int W, int H, int gray,
+                     int n_frames, int16_t* coeffs)
+{
+    if (int rc = check_dims(c, W, H, n_frames)) return rc;
+    if (!r || !g || !b || !coeffs) return set_err(JPEZY_E_BADARG, "null host pointer");
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t plane = (size_t)W * H;
+    const size_t stride = (plane + 15) & ~(size_t)15;          // keep every frame 16-byte aligned
+    const size_t ncoef = jpezy_coeff_count(W, H, gray);
+    const uint8_t* src[3] = { r, g, b };
+    for (int k = 0; k < 3; ++k) {
+        if (int rc = c->in[k].reserve(stride * n_frames)) return rc;
+        if (stride == plane) {
+            HIP_TRY(hipMemcpyAsync(c->in[k].p, src[k], plane * n_frames, hipMemcpyHostToDevice, c->stream));
+        } else {
+            HIP_TRY(hipMemcpy2DAsync(c->in[k].p, stride, src[k], plane, plane, (size_t)n_frames, hipMemcpyHostToDevice, c->stream));
+        }
+    }
+    if (int rc = c->out.reserve(ncoef * n_frames * sizeof(int16_t))) return rc;
+    if (int rc = jpezy_fdct_quant_dev(c, (const uint8_t*)c->in[0].p, (const uint8_t*)c->in[1].p, (const uint8_t*)c->in[2].p,
+                                      stride, W, H, gray, n_frames, (int16_t*)c->out.p, c->stream))
+        return rc;
+    HIP_TRY(hipMemcpyAsync(coeffs, c->out.p, ncoef * n_frames * sizeof(int16_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return JPEZY_OK;
+}
+
+static int upload_dequant(jpezy_ctx* c, const uint16_t qt[4][64], const uint8_t comp_tq[3], hipStream_t s)
+{
+    uint16_t sel[3][64];
+    for (int k = 0; k < 3; ++k) std::memcpy(sel[k], qt[comp_tq[k] & 3], sizeof sel[k]);
+    if (c->dq_valid && !std::memcmp(sel, c->dq_cache, sizeof sel)) return JPEZY_OK;
+    // A previous launch may still be reading the tables: drain the stream before rewriting them.
+    HIP_TRY(hipStreamSynchronize(s));
+    static thread_local double h_scale[3][8][8];
+    static thread_local int h_qt[3][64];
+    const double S = JPEZY_INV_SQRT2;
+    for (int k = 0; k < 3; ++k)
+        for (int u = 0; u < 8; ++u)
+            for (int v = 0; v < 8; ++v) {
+                const double cu = u ? 1.0 : S, cv = v ? 1.0 : S;
+                h_scale[k][u][v] = cu * cv * (double)sel[k][v * 8 + u];
+                h_qt[k][v * 8 + u] = sel[k][v * 8 + u];
+            }
+    HIP_TRY(hipMemcpy(c->d_dqscale, h_scale, sizeof h_scale, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->d_dqt, h_qt, sizeof h_qt, hipMemcpyHostToDevice));
+    std::memcpy(c->dq_cache, sel, sizeof sel);
+    c->dq_valid = true;
+    return JPEZY_OK;
+}
+
+int jpezy_dequant_idct_dev(jpezy_ctx* c, const int16_t* d_coeffs, const uint16_t qt[4][64], const uint8_t comp_tq[3],
+                           size_t plane_stride, int W, int H, int gray, int n_frames, uint8_t* d_r, uint8_t* d_g,
+                           uint8_t* d_b, void* stream)
+{
+    if (int rc = check_dims(c, W, H, n_frames)) return rc;
+    if (!d_coeffs || !qt || !comp_tq || !d_r || !d_g || !d_b) return set_err(JPEZY_E_BADARG, "null pointer");
+    if (plane_stride < (size_t)W * H) return set_err(JPEZY_E_BADARG, "plane_stride smaller than W*H");
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    if (int rc = upload_dequant(c, qt, comp_tq, s)) return rc;
+    DecParams p;
+    p.coeffs = d_coeffs;
+    p.coeffs_per_frame = jpezy_coeff_count(W, H, 0);
+    p.r = d_r; p.g = d_g; p.b = d_b;
+    p.plane_stride = plane_stride;
+    p.dqscale = c->d_dqscale;
+    p.dqt = c->d_dqt;
+    p.fallback_count = c->d_counter;
+    p.W = W; p.H = H;
+    p.mcu_cols = jpezy_mcu_cols(W);
+    p.mcu_rows = jpezy_mcu_rows(H);
+    p.quads_per_row = (p.mcu_cols + 3) / 4;
+    p.n_frames = n_frames;
+    HIP_TRY(launch_dequant_idct(p, gray != 0, c->force_exact, s));
+    return JPEZY_OK;
+}
+
+int jpezy_dequant_idct(jpezy_ctx* c, const int16_t* coeffs, const uint16_t qt[4][64], const uint8_t comp_tq[3], int W,
+                       int H, int gray, int n_frames, uint8_t* r, uint8_t* g, uint8_t* b)
+{
+    if (int rc = check_dims(c, W, H, n_frames)) return rc;
+    if (!coeffs || !qt || !comp_tq || !r || !g || !b) return set_err(JPEZY_E_BADARG, "null pointer");
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t plane = (size_t)W * H;
+    const size_t stride = (plane + 15) & ~(size_t)15;
+    const size_t ncoef = jpezy_coeff_count(W, H, 0);
+    if (int rc = c->out.reserve(ncoef * n_frames * sizeof(int16_t))) return rc;
+    HIP_TRY(hipMemcpyAsync(c->out.p, coeffs, ncoef * n_frames * sizeof(int16_t), hipMemcpyHostToDevice, c->stream));
+    for (int k = 0; k < 3; ++k)
+        if (int rc = c->in[k].reserve(stride * n_frames)) return rc;
+    if (int rc = jpezy_dequant_idct_dev(c, (const int16_t*)c->out.p, qt, comp_tq, stride, W, H, gray, n_frames,
+                                        (uint8_t*)c->in[0].p, (uint8_t*)c->in[1].p, (uint8_t*)c->in[2].p, c->stream))
+        return rc;
+    uint8_t* dst[3] = { r, g, b };
+    for (int k = 0; k < 3; ++k) {
+        if (stride == plane) {
+            HIP_TRY(hipMemcpyAsync(dst[k], c->in[k].p, plane * n_frames, hipMemcpyDeviceToHost, c->stream));
+        } else {
+            HIP_TRY(hipMemcpy2DAsync(dst[k], plane, c->in[k].p, stride, plane, (size_t)n_frames, hipMemcpyDeviceToHost, c->stream));
+        }
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return JPEZY_OK;
+}
+
+long jpezy_write_jpeg(const int16_t* coeffs, int W, int H, int gray, const char* comment, uint8_t* out, size_t cap)
+{
+    std::string err;
+    const long n = jpezy_host::write_jpeg(coeffs, W, H, gray != 0, comment, out, cap, &err);
+    if (n < 0) g_err = err;
+    return n;
+}
+
+size_t jpezy_jpeg_bound(int W, int H) { return jpezy_host::jpeg_bound(W, H); }
+
+int jpezy_read_jpeg(const uint8_t* data, size_t len, jpezy_frame_info* info, int16_t* coeffs, size_t coeff_cap)
+{
+    std::string err;
+    const int rc = jpezy_host::read_jpeg(data, len, info, coeffs, coeff_cap, &err);
+    if (rc < 0) g_err = err;
+    return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,23 @@
+// jpezy_host_codec.h -- host-side serial tail/head of the codec (internal C++ API behind the C-ABI):
+// JFIF writer + Annex-K Huffman encoder, marker parser + Huffman decoder.  Product code: independent of
+// oracle/ (which restates the same reference functions for checking).
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/jpezy_hip.h"
+
+namespace jpezy_host {
+
+// ref encoder/jpezy_writer.hpp:20-105 + encoder/jpezy_encoder.hpp:174-242
+long write_jpeg(const int16_t* coeffs, int W, int H, bool gray, const char* comment, uint8_t* out, size_t cap,
+                std::string* err);
+size_t jpeg_bound(int W, int H);
+
+// ref decoder/jpezy_decoder.hpp:171-502, 583-642
+int read_jpeg(const uint8_t* data, size_t len, jpezy_frame_info* info, int16_t* coeffs, size_t coeff_cap,
+              std::string* err);
+
+}  // namespace jpezy_host

@@ -1,0 +1,657 @@
+// jpezy_kernels.hip -- hand-written gfx950 (MI355X / CDNA4) kernels for the jpezy hot path.
+//
+//   fdct_quant_kernel   : RGB->YCbCr + 4:2:0 decimation + 8x8 FDCT + Annex-K quantise + zig-zag
+//                         (ref encoder/jpezy_encoder.hpp:90-172, 244-256; jpezy.hpp:36-45,131-152)
+//   dequant_idct_kernel : de-zig-zag + dequantise + 8x8 IDCT + nearest upsample + YCbCr->RGB + clamp
+//                         (ref decoder/jpezy_decoder.hpp:504-578, 645-676)
+//
+// Work decomposition (both kernels): one 64-lane wavefront owns a "quad" = 4 horizontally adjacent
+// 16x16 MCUs (64x16 pixels, 24 blocks); a 256-thread workgroup is 4 independent waves (no s_barrier --
+// each wave has a private LDS slice and synchronises with itself only).  Lane = (row, m): row = lane>>2
+// is a pixel row of the MCU, m = lane&3 the MCU of the quad, so one lane streams a 16-pixel row segment
+// of each plane as a single 16-byte access (4 lanes = 64 contiguous bytes) and the 3 KB of coefficients
+// of a quad move as 3 coalesced 1 KB wave accesses.  The two separable 1-D passes run in registers (one
+// 8-point transform per lane-row/column, 2 independent transforms per lane for ILP) with a padded,
+// bank-conflict-free LDS transpose between them.  No MFMA: FP64 8x8 is VALU work.
+//
+// Exactness (DESIGN.md "exactness"): the reference truncates FP64 results, so the output depends on the
+// exact rounding sequence only where the true value sits on a quantiser / integer boundary.  The fast
+// separable transform (FMA allowed, error < 1e-9) is accepted when the fixed-point value is >= 2 units
+// of 2^-24 (2^-18 for samples) away from every boundary; otherwise the coefficient is re-evaluated by
+// exact_*() in the reference's exact operation order (plain IEEE mul/add, no contraction).  DC terms are
+// sums of integers and are always evaluated exactly.  Colour conversion is evaluated in the reference's
+// exact FP64 order everywhere.  This file must be compiled with -ffp-contract=off; every fused
+// multiply-add below is an explicit __builtin_fma in a fast-path estimate.
+#include "jpezy_device.h"
+#include "../../include/jpezy_constants.h"
+
+namespace jpezy_dev {
+
+__constant__ double c_cos[64] = JPEZY_COS_INIT;            // [u*8+x] = cos((2x+1)u*pi/16)
+__constant__ unsigned char c_zzinv[64] = JPEZY_ZZ_INV_INIT;  // natural index -> zig-zag position
+
+#define JPEZY_S JPEZY_INV_SQRT2
+
+// cos(k*pi/16) -- the same correctly rounded doubles as the cos table rows (fast path only)
+#define C1 0x1.f6297cff75cb0p-1
+#define C2 0x1.d906bcf328d46p-1
+#define C3 0x1.a9b66290ea1a3p-1
+#define C4 0x1.6a09e667f3bcdp-1
+#define C5 0x1.1c73b39ae68c8p-1
+#define C6 0x1.87de2a6aea963p-2
+#define C7 0x1.8f8b83c69a60bp-3
+
+#define FMA(a, b, c) __builtin_fma((a), (b), (c))
+
+// LDS geometry (dwords), chosen so that the column reads (ds_read_b64, 32-lane groups, 64 banks) are
+// conflict free: per-MCU stride == 16 (mod 64) dwords.  Row pitch 36 dwords keeps 16-byte alignment and
+// limits the ds_write_b128 conflicts to 2-way.
+constexpr int Y_PITCH = 36;                 // 16 doubles + 2 pad
+constexpr int Y_MCU = 16 * Y_PITCH + 16;    // 592
+constexpr int C_PITCH = 20;                 // 8 doubles + 2 pad
+constexpr int C_COMP = 8 * C_PITCH;         // 160
+constexpr int C_MCU = 2 * C_COMP + 16;      // 336
+constexpr int WAVE_LDS_DWORDS = 4 * Y_MCU;  // 2368 dwords = 9472 B per wave
+
+__device__ __forceinline__ void wave_sync()
+{
+    // LDS traffic of one wave is executed in order; this only stops the compiler from moving LDS
+    // accesses of different lanes across the phase boundary.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// X[u] = sum_x x[x] * cos((2x+1)u*pi/16), u = 0..7 ; X[0] is the plain (exact, for integers) sum.
+__device__ __forceinline__ void fdct8(const double* x, double* X)
+{
+    const double s0 = x[0] + x[7], s1 = x[1] + x[6], s2 = x[2] + x[5], s3 = x[3] + x[4];
+    const double d0 = x[0] - x[7], d1 = x[1] - x[6], d2 = x[2] - x[5], d3 = x[3] - x[4];
+    const double e0 = s0 + s3, e1 = s1 + s2, e2 = s0 - s3, e3 = s1 - s2;
+    X[0] = e0 + e1;
+    X[4] = (e0 - e1) * C4;
+    X[2] = FMA(e3, C6, e2 * C2);
+    X[6] = FMA(-e3, C2, e2 * C6);
+    X[1] = FMA(d3, C7, FMA(d2, C5, FMA(d1, C3, d0 * C1)));
+    X[3] = FMA(-d3, C5, FMA(-d2, C1, FMA(-d1, C7, d0 * C3)));
+    X[5] = FMA(d3, C3, FMA(d2, C7, FMA(-d1, C1, d0 * C5)));
+    X[7] = FMA(-d3, C1, FMA(d2, C3, FMA(-d1, C5, d0 * C7)));
+}
+
+// x[y] = sum_v X[v] * cos((2y+1)v*pi/16)   (X[0] already carries its 1/sqrt2)
+__device__ __forceinline__ void idct8(const double* X, double* x)
+{
+    const double t0 = FMA(X[4], C4, X[0]), t1 = FMA(-X[4], C4, X[0]);
+    const double t2 = FMA(X[6], C6, X[2] * C2), t3 = FMA(-X[6], C2, X[2] * C6);
+    const double E0 = t0 + t2, E3 = t0 - t2, E1 = t1 + t3, E2 = t1 - t3;
+    const double O0 = FMA(X[7], C7, FMA(X[5], C5, FMA(X[3], C3, X[1] * C1)));
+    const double O1 = FMA(-X[7], C5, FMA(-X[5], C1, FMA(-X[3], C7, X[1] * C3)));
+    const double O2 = FMA(X[7], C3, FMA(X[5], C7, FMA(-X[3], C1, X[1] * C5)));
+    const double O3 = FMA(-X[7], C1, FMA(X[5], C3, FMA(-X[3], C5, X[1] * C7)));
+    x[0] = E0 + O0; x[7] = E0 - O0;
+    x[1] = E1 + O1; x[6] = E1 - O1;
+    x[2] = E2 + O2; x[5] = E2 - O2;
+    x[3] = E3 + O3; x[4] = E3 - O3;
+}
+
+// ---- colour conversion in the reference's exact order (ref jpezy_encoder.hpp:244-256) ----
+__device__ __forceinline__ double ref_y(double r, double g, double b)
+{
+    return __builtin_trunc((0.2990 * r) + (0.5870 * g) + (0.1140 * b) - 128.0);
+}
+__device__ __forceinline__ double ref_cb(double r, double g, double b)
+{
+    return __builtin_trunc(-(0.1687 * r) - (0.3313 * g) + (0.5000 * b));
+}
+__device__ __forceinline__ double ref_cr(double r, double g, double b)
+{
+    return __builtin_trunc((0.5000 * r) - (0.4187 * g) - (0.0813 * b));
+}
+
+// ---- exact-order FDCT + quantise of ONE coefficient (ref jpezy_encoder.hpp:146-172) ----
+// comp 0: luma block with top-left pixel (px0,py0), step 1.  comp 1/2: Cb/Cr of the MCU at (px0,py0),
+// step 2 (top-left sample of each 2x2, ref :134-142).  Coordinates clamp to the image (ref :101,104).
+__device__ __noinline__ int exact_fdct_coef(const uint8_t* __restrict__ r, const uint8_t* __restrict__ g,
+                                            const uint8_t* __restrict__ b, int W, int H, int px0, int py0,
+                                            int comp, int i, int j, int Q)
+{
+    const int step = comp ? 2 : 1;
+    double sum = 0;
+    for (int y = 0; y < 8; ++y) {
+        const int yy = min(py0 + y * step, H - 1);
+        const double cy = c_cos[i * 8 + y];
+        for (int x = 0; x < 8; ++x) {
+            const int xx = min(px0 + x * step, W - 1);
+            const size_t idx = (size_t)yy * W + xx;
+            const double rf = (double)r[idx], gf = (double)g[idx], bf = (double)b[idx];
+            const double pic = comp == 0 ? ref_y(rf, gf, bf) : comp == 1 ? ref_cb(rf, gf, bf) : ref_cr(rf, gf, bf);
+            sum += pic * c_cos[j * 8 + x] * cy;
+        }
+    }
+    const double cu = j ? 1.0 : JPEZY_S, cv = i ? 1.0 : JPEZY_S;
+    const int dct = (int)(sum * cu * cv / 4);
+    return dct / Q;
+}
+
+// Quantise the 8 coefficients F[i] (vertical frequency i, this lane's horizontal frequency j).
+// ks[i] = cu*cv/(4Q) * 2^24.  Returns a bit mask of coefficients that need the exact path.
+template <bool FORCE_EXACT>
+__device__ __forceinline__ unsigned quant8(const double* F, const double* ks, bool dc_lane, double rq_dc, int* q)
+{
+    constexpr int MASK = (1 << QFRAC_BITS) - 1;
+    unsigned flags = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int n = (int)(F[i] * ks[i]);               // v_cvt_i32_f64 truncates toward zero
+        // within 1 unit of a multiple of 2^24 -- except around 0, which is not a truncation boundary
+        flags |= (((unsigned)((n + 1) & MASK) <= 2u && (unsigned)(n + 1) > 2u) ? 1u : 0u) << i;
+        q[i] = (n + ((n >> 31) & MASK)) >> QFRAC_BITS;    // trunc-toward-zero division by 2^24
+    }
+    // DC: F[0] of the j == 0 lane is the exact integer sum of the block, so the reference value
+    // int(sum*S*S/4) is reproduced bit for bit; (|iv|+0.5)/Q is never within 0.5/Q of an integer.
+    {
+        const double iv = __builtin_trunc(F[0] * JPEZY_S * JPEZY_S / 4);
+        int nq = (int)((__builtin_fabs(iv) + 0.5) * rq_dc);
+        nq = iv < 0 ? -nq : nq;
+        if (dc_lane) {
+            q[0] = nq;
+            flags &= ~1u;
+        }
+    }
+    if (FORCE_EXACT) flags = 0xFFu;
+    return flags;
+}
+
+struct BlockRef {   // what exact_fdct_coef needs to find a block again
+    const uint8_t* r;
+    const uint8_t* g;
+    const uint8_t* b;
+    int W, H;
+};
+
+template <bool FORCE_EXACT>
+__device__ __forceinline__ void quant_block_column(const double* F, const double* ks, int j, double rq_dc,
+                                                   const int* qt, const BlockRef& img, int px0, int py0, int comp,
+                                                   bool live, int16_t* stage_blk, unsigned& nfallback)
+{
+    int q[8];
+    unsigned flags = quant8<FORCE_EXACT>(F, ks, j == 0, rq_dc, q);
+    if (!live) flags = 0;
+    if (flags) {
+#pragma unroll 1
+        for (int i = 0; i < 8; ++i) {
+            if ((flags >> i) & 1u) {
+                q[i] = exact_fdct_coef(img.r, img.g, img.b, img.W, img.H, px0, py0, comp, i, j, qt[i * 8 + j]);
+                ++nfallback;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) stage_blk[c_zzinv[i * 8 + j]] = (int16_t)q[i];
+}
+
+__device__ __forceinline__ double byte_of(const uint32_t* w, int k)
+{
+    return (double)((w[k >> 2] >> ((k & 3) * 8)) & 0xFFu);
+}
+
+// ======================================================================================================
+// ENCODE
+// ======================================================================================================
+template <bool GRAY, bool ALIGNED, bool FORCE_EXACT>
+__global__ __launch_bounds__(256) void fdct_quant_kernel(EncParams p)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t lds_all[4][WAVE_LDS_DWORDS];
+    constexpr int BPM = GRAY ? 4 : 6;
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long quad = (long)blockIdx.x * 4 + wave;
+    const long quads_per_frame = (long)p.mcu_rows * p.quads_per_row;
+    if (quad >= quads_per_frame * p.n_frames) return;   // wave-uniform
+    const int frame = (int)(quad / quads_per_frame);
+    const int qrem = (int)(quad - (long)frame * quads_per_frame);
+    const int mcu_y = qrem / p.quads_per_row;
+    const int quad_x = qrem - mcu_y * p.quads_per_row;
+
+    uint32_t* lds = lds_all[wave];
+    const int row = lane >> 2, m = lane & 3;
+    const int mcu_x_raw = quad_x * 4 + m;
+    const bool live = mcu_x_raw < p.mcu_cols;
+    const int mcu_x = live ? mcu_x_raw : p.mcu_cols - 1;
+    const int W = p.W, H = p.H;
+    const uint8_t* pr = p.r + (size_t)frame * p.plane_stride;
+    const uint8_t* pg = p.g + (size_t)frame * p.plane_stride;
+    const uint8_t* pb = p.b + (size_t)frame * p.plane_stride;
+    const BlockRef img = { pr, pg, pb, W, H };
+
+    // ---- 1. stream this lane's 16-pixel row segment of the three planes ----
+    uint32_t R[4], G[4], B[4];
+    {
+        const int y = min(mcu_y * 16 + row, H - 1);             // edge replication, ref :101
+        const size_t rowoff = (size_t)y * W;
+        if (ALIGNED) {
+            const size_t off = rowoff + (size_t)mcu_x * 16;
+            const uint4 vr = *reinterpret_cast<const uint4*>(pr + off);
+            const uint4 vg = *reinterpret_cast<const uint4*>(pg + off);
+            const uint4 vb = *reinterpret_cast<const uint4*>(pb + off);
+            R[0] = vr.x; R[1] = vr.y; R[2] = vr.z; R[3] = vr.w;
+            G[0] = vg.x; G[1] = vg.y; G[2] = vg.z; G[3] = vg.w;
+            B[0] = vb.x; B[1] = vb.y; B[2] = vb.z; B[3] = vb.w;
+        } else {
+#pragma unroll
+            for (int w4 = 0; w4 < 4; ++w4) {
+                uint32_t ar = 0, ag = 0, ab = 0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int x = min(mcu_x * 16 + w4 * 4 + k, W - 1);   // ref :104
+                    ar |= (uint32_t)pr[rowoff + x] << (8 * k);
+                    ag |= (uint32_t)pg[rowoff + x] << (8 * k);
+                    ab |= (uint32_t)pb[rowoff + x] << (8 * k);
+                }
+                R[w4] = ar; G[w4] = ag; B[w4] = ab;
+            }
+        }
+    }
+
+    // ---- 2. luma of the 16 pixels, row pass of the left / right block, into the transpose tile ----
+    {
+        double yv[16], X[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) yv[k] = ref_y(byte_of(R, k), byte_of(G, k), byte_of(B, k));
+        fdct8(yv, X);
+        fdct8(yv + 8, X + 8);
+        double2* dst = reinterpret_cast<double2*>(lds + m * Y_MCU + row * Y_PITCH);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) dst[k] = make_double2(X[2 * k], X[2 * k + 1]);
+    }
+
+    // ---- 3. chroma rows: even pixel rows, even pixel columns (top-left of each 2x2, ref :134-142) ----
+    double cbX[8], crX[8];
+    if (!GRAY) {
+        if ((row & 1) == 0) {
+            double cbv[8], crv[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const double rf = byte_of(R, 2 * k), gf = byte_of(G, 2 * k), bf = byte_of(B, 2 * k);
+                cbv[k] = ref_cb(rf, gf, bf);
+                crv[k] = ref_cr(rf, gf, bf);
+            }
+            fdct8(cbv, cbX);
+            fdct8(crv, crX);
+        }
+    }
+    wave_sync();
+
+    // ---- 4. luma column pass: lane (cq, m) owns column cq of the 16x16 tile = column j of two blocks ----
+    const int cq = row;                 // 0..15
+    const int j = cq & 7;
+    const DeviceTables* tab = p.tab;
+    unsigned nfallback = 0;
+    double Ftop[8], Fbot[8];
+    {
+        double col[16];
+        const uint32_t* src = lds + m * Y_MCU + cq * 2;
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) col[rr] = *reinterpret_cast<const double*>(src + rr * Y_PITCH);
+        fdct8(col, Ftop);
+        fdct8(col + 8, Fbot);
+    }
+    wave_sync();   // everybody has read the luma tile; the slice is reused below
+
+    // chroma tile write (even rows only)
+    if (!GRAY) {
+        if ((row & 1) == 0) {
+            double2* dcb = reinterpret_cast<double2*>(lds + m * C_MCU + (row >> 1) * C_PITCH);
+            double2* dcr = reinterpret_cast<double2*>(lds + m * C_MCU + C_COMP + (row >> 1) * C_PITCH);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                dcb[k] = make_double2(cbX[2 * k], cbX[2 * k + 1]);
+                dcr[k] = make_double2(crX[2 * k], crX[2 * k + 1]);
+            }
+        }
+        wave_sync();
+    }
+    double Fc[8];
+    if (!GRAY) {
+        double col[8];
+        const uint32_t* src = lds + m * C_MCU + (cq >> 3) * C_COMP + j * 2;
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) col[rr] = *reinterpret_cast<const double*>(src + rr * C_PITCH);
+        fdct8(col, Fc);
+        wave_sync();   // chroma tile consumed; slice becomes the output staging area
+    }
+
+    // ---- 5. quantise + zig-zag into the staging area [m][blk][64] int16 (same layout as global) ----
+    int16_t* stage = reinterpret_cast<int16_t*>(lds);
+    {
+        double ks[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ks[i] = tab->qscale[0][j][i];
+        const double rq = tab->rq_dc[0];
+        const int bx = cq >> 3;   // 0: left blocks (Y0,Y2), 1: right blocks (Y1,Y3)
+        const int px0 = mcu_x * 16 + bx * 8, py0 = mcu_y * 16;
+        quant_block_column<FORCE_EXACT>(Ftop, ks, j, rq, tab->qt[0], img, px0, py0, 0, live,
+                                        stage + (m * BPM + bx) * 64, nfallback);
+        quant_block_column<FORCE_EXACT>(Fbot, ks, j, rq, tab->qt[0], img, px0, py0 + 8, 0, live,
+                                        stage + (m * BPM + 2 + bx) * 64, nfallback);
+    }
+    if (!GRAY) {
+        double ks[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ks[i] = tab->qscale[1][j][i];
+        const int comp = 1 + (cq >> 3);
+        quant_block_column<FORCE_EXACT>(Fc, ks, j, tab->rq_dc[1], tab->qt[1], img, mcu_x * 16, mcu_y * 16, comp, live,
+                                        stage + (m * BPM + 3 + comp) * 64, nfallback);
+    }
+    wave_sync();
+
+    // ---- 6. coalesced store of the quad's coefficients (BPM*128 bytes per MCU, contiguous) ----
+    {
+        const int valid_mcus = min(4, p.mcu_cols - quad_x * 4);
+        const int valid_bytes = valid_mcus * BPM * 128;
+        int16_t* gbase = p.coeffs + (size_t)frame * p.coeffs_per_frame +
+                         ((size_t)mcu_y * p.mcu_cols + (size_t)quad_x * 4) * (BPM * 64);
+        const uint4* s4 = reinterpret_cast<const uint4*>(lds);
+        uint4* g4 = reinterpret_cast<uint4*>(gbase);
+#pragma unroll
+        for (int k = 0; k < BPM * 128 * 4 / 1024; ++k) {
+            const int c = k * 64 + lane;
+            if (c * 16 < valid_bytes) g4[c] = s4[c];
+        }
+    }
+    if (nfallback) atomicAdd(p.fallback_count, (unsigned long long)nfallback);
+}
+
+// ======================================================================================================
+// DECODE
+// ======================================================================================================
+
+// exact-order IDCT of ONE sample (ref jpezy_decoder.hpp:645-670); blk = 64 zig-zag int16 coefficients
+__device__ __noinline__ int exact_idct_sample(const int16_t* __restrict__ blk, const int* __restrict__ qt, int x, int y)
+{
+    double sum = 0;
+    for (int v = 0; v < 8; ++v) {
+        const double cv = (!v) ? JPEZY_S : 1.0;
+        for (int u = 0; u < 8; ++u) {
+            const double cu = (!u) ? JPEZY_S : 1.0;
+            const int dct = (int)blk[c_zzinv[v * 8 + u]] * qt[v * 8 + u];
+            sum += cu * cv * dct * c_cos[u * 8 + x] * c_cos[v * 8 + y];
+        }
+    }
+    return (int)(sum / 4 + 128);
+}
+
+// fixed-point sample + guard flag from the fast row sum
+__device__ __forceinline__ int sample_fx(double sum, bool& flag)
+{
+    constexpr int MASK = (1 << SFRAC_BITS) - 1;
+    const double t = FMA(sum, (double)(1 << (SFRAC_BITS - 2)), (double)(128 << SFRAC_BITS));   // (sum/4+128)*2^18
+    const bool wild = !(__builtin_fabs(t) < (double)(1 << 30));
+    const int n = (int)t;
+    flag = wild || ((unsigned)((n + 1) & MASK) <= 2u);
+    return (n + ((n >> 31) & MASK)) >> SFRAC_BITS;
+}
+
+__device__ __forceinline__ uint32_t clamp_byte(double v)   // revise_value, ref :672-676
+{
+    const int iv = (int)v;                 // truncates; (-1,0) -> 0 like the reference's v < 0 -> 0
+    return (uint32_t)min(max(iv, 0), 255);
+}
+
+template <bool GRAY, bool ALIGNED, bool FORCE_EXACT>
+__global__ __launch_bounds__(256) void dequant_idct_kernel(DecParams p)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t lds_all[4][WAVE_LDS_DWORDS];
+    constexpr int BPM = 6;
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long quad = (long)blockIdx.x * 4 + wave;
+    const long quads_per_frame = (long)p.mcu_rows * p.quads_per_row;
+    if (quad >= quads_per_frame * p.n_frames) return;
+    const int frame = (int)(quad / quads_per_frame);
+    const int qrem = (int)(quad - (long)frame * quads_per_frame);
+    const int mcu_y = qrem / p.quads_per_row;
+    const int quad_x = qrem - mcu_y * p.quads_per_row;
+
+    uint32_t* lds = lds_all[wave];
+    const int row = lane >> 2, m = lane & 3;
+    const int mcu_x = quad_x * 4 + m;
+    const bool live = mcu_x < p.mcu_cols;
+    const int W = p.W, H = p.H;
+
+    // ---- 1. coalesced load of the quad's 3 KB of coefficients into the staging area ----
+    const int16_t* gbase = p.coeffs + (size_t)frame * p.coeffs_per_frame +
+                           ((size_t)mcu_y * p.mcu_cols + (size_t)quad_x * 4) * (BPM * 64);
+    {
+        const int valid_mcus = min(4, p.mcu_cols - quad_x * 4);
+        const int valid_bytes = valid_mcus * BPM * 128;
+        const uint4* g4 = reinterpret_cast<const uint4*>(gbase);
+        uint4* s4 = reinterpret_cast<uint4*>(lds);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int c = k * 64 + lane;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (c * 16 < valid_bytes) v = g4[c];
+            s4[c] = v;
+        }
+    }
+    wave_sync();
+
+    // ---- 2. column pass (over v) for column u = cq&7 of two luma blocks and one chroma block ----
+    const int cq = row, u = cq & 7;
+    const int16_t* stage = reinterpret_cast<const int16_t*>(lds);
+    double gtop[8], gbot[8], gc[8];
+    float amax = 0.f;
+    {
+        double dq[8], in[8];
+        unsigned char zp[8];
+#pragma unroll
+        for (int v = 0; v < 8; ++v) {
+            dq[v] = p.dqscale[(0 * 8 + u) * 8 + v];
+            zp[v] = c_zzinv[v * 8 + u];
+        }
+        const int bx = cq >> 3;
+        const int16_t* bt = stage + (m * BPM + bx) * 64;
+        const int16_t* bb = stage + (m * BPM + 2 + bx) * 64;
+#pragma unroll
+        for (int v = 0; v < 8; ++v) { in[v] = (double)bt[zp[v]] * dq[v]; amax = fmaxf(amax, fabsf((float)in[v])); }
+        idct8(in, gtop);
+#pragma unroll
+        for (int v = 0; v < 8; ++v) { in[v] = (double)bb[zp[v]] * dq[v]; amax = fmaxf(amax, fabsf((float)in[v])); }
+        idct8(in, gbot);
+        if (!GRAY) {
+            const int comp = 1 + (cq >> 3);
+            const int16_t* bc = stage + (m * BPM + 3 + comp) * 64;
+#pragma unroll
+            for (int v = 0; v < 8; ++v) {
+                in[v] = (double)bc[zp[v]] * p.dqscale[(comp * 8 + u) * 8 + v];
+                amax = fmaxf(amax, fabsf((float)in[v]));
+            }
+            idct8(in, gc);
+        }
+    }
+    // fast path is only trusted for sane magnitudes (error bound); wave-uniform decision
+    const bool force = FORCE_EXACT || __any(amax > 32768.f);
+    wave_sync();   // staging consumed (the exact path re-reads coefficients from global memory)
+
+    // ---- 3. transpose: luma tile [y 0..15][x-col 0..15]; chroma tiles after it is consumed ----
+    {
+        uint32_t* dst = lds + m * Y_MCU + cq * 2;
+#pragma unroll
+        for (int y = 0; y < 8; ++y) {
+            *reinterpret_cast<double*>(dst + y * Y_PITCH) = gtop[y];
+            *reinterpret_cast<double*>(dst + (8 + y) * Y_PITCH) = gbot[y];
+        }
+    }
+    wave_sync();
+    int Y[16];
+    unsigned yflags = 0;
+    {
+        double in[16], out[16];
+        const double2* src = reinterpret_cast<const double2*>(lds + m * Y_MCU + row * Y_PITCH);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { const double2 t = src[k]; in[2 * k] = t.x; in[2 * k + 1] = t.y; }
+        idct8(in, out);
+        idct8(in + 8, out + 8);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            bool f;
+            Y[k] = sample_fx(out[k], f);
+            yflags |= (f ? 1u : 0u) << k;
+        }
+    }
+    if (force) yflags = 0xFFFFu;
+    int Cb[8], Cr[8];
+    unsigned cflags = 0;
+    if (!GRAY) {
+        wave_sync();
+        {
+            uint32_t* dst = lds + m * C_MCU + (cq >> 3) * C_COMP + u * 2;
+#pragma unroll
+            for (int y = 0; y < 8; ++y) *reinterpret_cast<double*>(dst + y * C_PITCH) = gc[y];
+        }
+        wave_sync();
+        double in[16], out[16];
+        const double2* scb = reinterpret_cast<const double2*>(lds + m * C_MCU + (row >> 1) * C_PITCH);
+        const double2* scr = reinterpret_cast<const double2*>(lds + m * C_MCU + C_COMP + (row >> 1) * C_PITCH);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const double2 a = scb[k], b = scr[k];
+            in[2 * k] = a.x; in[2 * k + 1] = a.y;
+            in[8 + 2 * k] = b.x; in[8 + 2 * k + 1] = b.y;
+        }
+        idct8(in, out);
+        idct8(in + 8, out + 8);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            bool f;
+            Cb[k] = sample_fx(out[k], f);
+            cflags |= (f ? 1u : 0u) << k;
+            Cr[k] = sample_fx(out[8 + k], f);
+            cflags |= (f ? 1u : 0u) << (8 + k);
+        }
+        if (force) cflags = 0xFFFFu;
+    }
+    if (!live) { yflags = 0; cflags = 0; }
+
+    // ---- 4. exact path for flagged samples ----
+    unsigned nfallback = 0;
+    if (yflags | cflags) {
+        const int16_t* mcu = gbase + (size_t)m * BPM * 64;
+        const int by = row >> 3, yy = row & 7;
+#pragma unroll 1
+        for (int k = 0; k < 16; ++k) {
+            if ((yflags >> k) & 1u) {
+                Y[k] = exact_idct_sample(mcu + (by * 2 + (k >> 3)) * 64, p.dqt, k & 7, yy);
+                ++nfallback;
+            }
+        }
+        if (!GRAY) {
+#pragma unroll 1
+            for (int k = 0; k < 16; ++k) {
+                if ((cflags >> k) & 1u) {
+                    const int s = exact_idct_sample(mcu + (4 + (k >> 3)) * 64, p.dqt + 64 * (1 + (k >> 3)), k & 7, row >> 1);
+                    if (k < 8) Cb[k] = s; else Cr[k - 8] = s;
+                    ++nfallback;
+                }
+            }
+        }
+    }
+
+    // ---- 5. YCbCr -> RGB in the reference's exact order (ref :567-578), clamp, pack, store ----
+    uint32_t Rw[4] = { 0, 0, 0, 0 }, Gw[4] = { 0, 0, 0, 0 }, Bw[4] = { 0, 0, 0, 0 };
+    if (!GRAY) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const double up = (double)Cb[c] - 128.0, vp = (double)Cr[c] - 128.0;
+            const double pr_ = vp * 1.4020, pg1 = up * 0.3441, pg2 = vp * 0.7139, pb_ = up * 1.7718;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int k = 2 * c + h;
+                const double yp = (double)Y[k];
+                Rw[k >> 2] |= clamp_byte(yp + pr_) << ((k & 3) * 8);
+                Gw[k >> 2] |= clamp_byte(yp - pg1 - pg2) << ((k & 3) * 8);
+                Bw[k >> 2] |= clamp_byte(yp + pb_) << ((k & 3) * 8);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) Rw[k >> 2] |= (uint32_t)min(max(Y[k], 0), 255) << ((k & 3) * 8);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) Gw[k] = Bw[k] = Rw[k];
+    }
+    const int py = mcu_y * 16 + row;
+    if (live && py < H) {
+        uint8_t* orp = p.r + (size_t)frame * p.plane_stride + (size_t)py * W;
+        uint8_t* ogp = p.g + (size_t)frame * p.plane_stride + (size_t)py * W;
+        uint8_t* obp = p.b + (size_t)frame * p.plane_stride + (size_t)py * W;
+        if (ALIGNED) {
+            const size_t off = (size_t)mcu_x * 16;
+            *reinterpret_cast<uint4*>(orp + off) = make_uint4(Rw[0], Rw[1], Rw[2], Rw[3]);
+            *reinterpret_cast<uint4*>(ogp + off) = make_uint4(Gw[0], Gw[1], Gw[2], Gw[3]);
+            *reinterpret_cast<uint4*>(obp + off) = make_uint4(Bw[0], Bw[1], Bw[2], Bw[3]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int x = mcu_x * 16 + k;
+                if (x < W) {                                   // ref :546-551
+                    orp[x] = (uint8_t)(Rw[k >> 2] >> ((k & 3) * 8));
+                    ogp[x] = (uint8_t)(Gw[k >> 2] >> ((k & 3) * 8));
+                    obp[x] = (uint8_t)(Bw[k >> 2] >> ((k & 3) * 8));
+                }
+            }
+        }
+    }
+    if (nfallback) atomicAdd(p.fallback_count, (unsigned long long)nfallback);
+}
+
+// ======================================================================================================
+// launchers
+// ======================================================================================================
+template <typename P>
+static bool is_aligned16(const P& p, const void* a, const void* b, const void* c)
+{
+    return (p.W % 16 == 0) && (p.plane_stride % 16 == 0) && (((uintptr_t)a | (uintptr_t)b | (uintptr_t)c) % 16 == 0);
+}
+
+template <bool GRAY, bool ALIGNED>
+static void enc_launch2(const EncParams& p, bool force, dim3 grid, hipStream_t s)
+{
+    if (force)
+        hipLaunchKernelGGL((fdct_quant_kernel<GRAY, ALIGNED, true>), grid, dim3(256), 0, s, p);
+    else
+        hipLaunchKernelGGL((fdct_quant_kernel<GRAY, ALIGNED, false>), grid, dim3(256), 0, s, p);
+}
+
+hipError_t launch_fdct_quant(const EncParams& p, bool gray, bool force_exact, hipStream_t stream)
+{
+    const long quads = (long)p.n_frames * p.mcu_rows * p.quads_per_row;
+    if (quads <= 0) return hipSuccess;
+    const dim3 grid((unsigned)((quads + 3) / 4));
+    const bool al = is_aligned16(p, p.r, p.g, p.b);
+    if (gray) { if (al) enc_launch2<true, true>(p, force_exact, grid, stream); else enc_launch2<true, false>(p, force_exact, grid, stream); }
+    else      { if (al) enc_launch2<false, true>(p, force_exact, grid, stream); else enc_launch2<false, false>(p, force_exact, grid, stream); }
+    return hipGetLastError();
+}
+
+template <bool GRAY, bool ALIGNED>
+static void dec_launch2(const DecParams& p, bool force, dim3 grid, hipStream_t s)
+{
+    if (force)
+        hipLaunchKernelGGL((dequant_idct_kernel<GRAY, ALIGNED, true>), grid, dim3(256), 0, s, p);
+    else
+        hipLaunchKernelGGL((dequant_idct_kernel<GRAY, ALIGNED, false>), grid, dim3(256), 0, s, p);
+}
+
+hipError_t launch_dequant_idct(const DecParams& p, bool gray, bool force_exact, hipStream_t stream)
+{
+    const long quads = (long)p.n_frames * p.mcu_rows * p.quads_per_row;
+    if (quads <= 0) return hipSuccess;
+    const dim3 grid((unsigned)((quads + 3) / 4));
+    const bool al = is_aligned16(p, p.r, p.g, p.b);
+    if (gray) { if (al) dec_launch2<true, true>(p, force_exact, grid, stream); else dec_launch2<true, false>(p, force_exact, grid, stream); }
+    else      { if (al) dec_launch2<false, true>(p, force_exact, grid, stream); else dec_launch2<false, false>(p, force_exact, grid, stream); }
+    return hipGetLastError();
+}
+
+}  // namespace jpezy_dev

@@ -49,6 +49,7 @@ jpezy_ctx* jpezy_ctx_create(int device);
 void jpezy_ctx_destroy(jpezy_ctx* ctx);
 int jpezy_ctx_sync(jpezy_ctx* ctx);
 int jpezy_ctx_device(const jpezy_ctx* ctx);
+void* jpezy_ctx_stream(const jpezy_ctx* ctx);   /* the context's own hipStream_t (non-blocking) */
 
 /* ---- geometry helpers (jpezy_encoder.hpp:55-56) ---- */
 int jpezy_mcu_cols(int W);
@@ -71,8 +72,9 @@ int jpezy_fdct_quant(jpezy_ctx* ctx, const uint8_t* r, const uint8_t* g, const u
                      int gray, int n_frames, int16_t* coeffs);
 /*
  * jpezy_fdct_quant_dev: same, all pointers are DEVICE pointers; plane_stride = bytes between
- * consecutive frames of one plane (>= W*H); asynchronous on `stream` (a hipStream_t; NULL = the
- * context's own stream).  Used by batch drivers / the benchmark with inputs resident in HBM.
+ * consecutive frames of one plane (>= W*H); asynchronous on `stream`, a hipStream_t with HIP's own
+ * meaning (NULL = the default stream; jpezy_ctx_stream() = the context's private stream).  Used by
+ * batch drivers / the benchmark with inputs resident in HBM.
  */
 int jpezy_fdct_quant_dev(jpezy_ctx* ctx, const uint8_t* d_r, const uint8_t* d_g, const uint8_t* d_b,
                          size_t plane_stride, int W, int H, int gray, int n_frames, int16_t* d_coeffs,

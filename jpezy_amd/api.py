@@ -43,6 +43,7 @@ ABI = [
     ("jpezy_ctx_destroy", None, [_vp]),
     ("jpezy_ctx_sync", C.c_int, [_vp]),
     ("jpezy_ctx_device", C.c_int, [_vp]),
+    ("jpezy_ctx_stream", _vp, [_vp]),
     ("jpezy_mcu_cols", C.c_int, [C.c_int]),
     ("jpezy_mcu_rows", C.c_int, [C.c_int]),
     ("jpezy_coeff_count", C.c_size_t, [C.c_int, C.c_int, C.c_int]),
@@ -69,6 +70,13 @@ def load_library():
         if not _LIBPATH.exists():
             raise JpezyError(f"{_LIBPATH} is missing: build it with `python -m jpezy_amd._build` "
                              "(there is no CPU fallback for the jpezy hot path)")
+        # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so.7.  Import torch first so
+        # that our DT_NEEDED(libamdhip64.so.7) binds to the copy torch already loaded; a second runtime in
+        # the same process cannot see the GPU.  Without torch the system ROCm runtime is used.
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
         lib = C.CDLL(str(_LIBPATH))
         for name, res, args in ABI:
             fn = getattr(lib, name)          # AttributeError if the library does not export the symbol

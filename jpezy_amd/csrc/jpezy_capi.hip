@@ -156,6 +156,7 @@ int jpezy_ctx_sync(jpezy_ctx* c)
 }
 
 int jpezy_ctx_device(const jpezy_ctx* c) { return c ? c->device : -1; }
+void* jpezy_ctx_stream(const jpezy_ctx* c) { return c ? (void*)c->stream : nullptr; }
 
 void jpezy_ctx_set_force_exact(jpezy_ctx* c, int on)
 {
@@ -188,7 +189,7 @@ int jpezy_fdct_quant_dev(jpezy_ctx* c, const uint8_t* d_r, const uint8_t* d_g, c
     if (!d_r || !d_g || !d_b || !d_coeffs) return set_err(JPEZY_E_BADARG, "null device pointer");
     if (plane_stride < (size_t)W * H) return set_err(JPEZY_E_BADARG, "plane_stride smaller than W*H");
     HIP_TRY(hipSetDevice(c->device));
-    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    hipStream_t s = (hipStream_t)stream;
     EncParams p;
     p.r = d_r; p.g = d_g; p.b = d_b;
     p.plane_stride = plane_stride;
@@ -264,7 +265,7 @@ int jpezy_dequant_idct_dev(jpezy_ctx* c, const int16_t* d_coeffs, const uint16_t
     if (!d_coeffs || !qt || !comp_tq || !d_r || !d_g || !d_b) return set_err(JPEZY_E_BADARG, "null pointer");
     if (plane_stride < (size_t)W * H) return set_err(JPEZY_E_BADARG, "plane_stride smaller than W*H");
     HIP_TRY(hipSetDevice(c->device));
-    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    hipStream_t s = (hipStream_t)stream;
     if (int rc = upload_dequant(c, qt, comp_tq, s)) return rc;
     DecParams p;
     p.coeffs = d_coeffs;

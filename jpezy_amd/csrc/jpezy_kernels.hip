@@ -51,7 +51,10 @@ constexpr int Y_MCU = 16 * Y_PITCH + 16;    // 592
 constexpr int C_PITCH = 20;                 // 8 doubles + 2 pad
 constexpr int C_COMP = 8 * C_PITCH;         // 160
 constexpr int C_MCU = 2 * C_COMP + 16;      // 336
-constexpr int WAVE_LDS_DWORDS = 4 * Y_MCU;  // 2368 dwords = 9472 B per wave
+constexpr int TILE_DWORDS = 4 * Y_MCU;      // 2368 dwords = 9472 B: transpose tiles / staging
+// Behind the tiles: the wave's queue of guard-band hits (count + entries), never overlapped by a tile.
+constexpr int QUEUE_CAP = 126;
+constexpr int WAVE_LDS_DWORDS = TILE_DWORDS + 64;   // 9728 B per wave, 38912 B per workgroup (4 per CU)
 
 __device__ __forceinline__ void wave_sync()
 {
@@ -108,44 +111,62 @@ __device__ __forceinline__ double ref_cr(double r, double g, double b)
     return __builtin_trunc((0.5000 * r) - (0.4187 * g) - (0.0813 * b));
 }
 
-// ---- exact-order FDCT + quantise of ONE coefficient (ref jpezy_encoder.hpp:146-172) ----
-// comp 0: luma block with top-left pixel (px0,py0), step 1.  comp 1/2: Cb/Cr of the MCU at (px0,py0),
-// step 2 (top-left sample of each 2x2, ref :134-142).  Coordinates clamp to the image (ref :101,104).
-__device__ __noinline__ int exact_fdct_coef(const uint8_t* __restrict__ r, const uint8_t* __restrict__ g,
-                                            const uint8_t* __restrict__ b, int W, int H, int px0, int py0,
-                                            int comp, int i, int j, int Q)
+// In-order sum of one double per lane, lane 0 first: sum = (((0 + t0) + t1) + ...) + t63, every add
+// rounded -- the reference's accumulation order.  Wave-uniform result.
+__device__ __forceinline__ double ordered_wave_sum(double t)
+{
+    const int lo = (int)(unsigned)(__builtin_bit_cast(unsigned long long, t) & 0xFFFFFFFFull);
+    const int hi = (int)(unsigned)(__builtin_bit_cast(unsigned long long, t) >> 32);
+    double sum = 0;
+#pragma unroll
+    for (int k = 0; k < 64; ++k) {
+        const unsigned long long bits = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(hi, k) << 32) |
+                                        (unsigned)__builtin_amdgcn_readlane(lo, k);
+        sum += __builtin_bit_cast(double, bits);
+    }
+    return sum;
+}
+
+struct BlockRef {   // the frame's planes: what the exact path needs to find a block again
+    const uint8_t* r;
+    const uint8_t* g;
+    const uint8_t* b;
+    int W, H;
+};
+
+// ---- exact-order FDCT + quantise of ONE coefficient by the whole wave (ref jpezy_encoder.hpp:146-172) ----
+// All arguments are wave-uniform.  Lane k owns term k = y*8+x of the reference's double loop: it re-reads its
+// pixel, converts it, forms (pic*cos[j][x])*cos[i][y]; the 64 terms are then added in the reference's order.
+// comp 0: luma block with top-left pixel (px0,py0), step 1.  comp 1/2: Cb/Cr of the MCU at (px0,py0), step 2
+// (top-left sample of each 2x2, ref :134-142).  Coordinates clamp to the image (ref :101,104).
+__device__ __forceinline__ int exact_fdct_coef_wave(const BlockRef& img, int px0, int py0, int comp, int i, int j,
+                                                    int Q, int lane)
 {
     const int step = comp ? 2 : 1;
-    double sum = 0;
-    for (int y = 0; y < 8; ++y) {
-        const int yy = min(py0 + y * step, H - 1);
-        const double cy = c_cos[i * 8 + y];
-        for (int x = 0; x < 8; ++x) {
-            const int xx = min(px0 + x * step, W - 1);
-            const size_t idx = (size_t)yy * W + xx;
-            const double rf = (double)r[idx], gf = (double)g[idx], bf = (double)b[idx];
-            const double pic = comp == 0 ? ref_y(rf, gf, bf) : comp == 1 ? ref_cb(rf, gf, bf) : ref_cr(rf, gf, bf);
-            sum += pic * c_cos[j * 8 + x] * cy;
-        }
-    }
+    const int y = lane >> 3, x = lane & 7;
+    const int yy = min(py0 + y * step, img.H - 1);
+    const int xx = min(px0 + x * step, img.W - 1);
+    const size_t idx = (size_t)yy * img.W + xx;
+    const double rf = (double)img.r[idx], gf = (double)img.g[idx], bf = (double)img.b[idx];
+    const double pic = comp == 0 ? ref_y(rf, gf, bf) : comp == 1 ? ref_cb(rf, gf, bf) : ref_cr(rf, gf, bf);
+    const double sum = ordered_wave_sum(pic * c_cos[j * 8 + x] * c_cos[i * 8 + y]);
     const double cu = j ? 1.0 : JPEZY_S, cv = i ? 1.0 : JPEZY_S;
     const int dct = (int)(sum * cu * cv / 4);
     return dct / Q;
 }
 
 // Quantise the 8 coefficients F[i] (vertical frequency i, this lane's horizontal frequency j).
-// ks[i] = cu*cv/(4Q) * 2^24.  Returns a bit mask of coefficients that need the exact path.
-template <bool FORCE_EXACT>
-__device__ __forceinline__ unsigned quant8(const double* F, const double* ks, bool dc_lane, double rq_dc, int* q)
+// ks[i] = cu*cv/(4Q) * 2^24.  n[i] = trunc(v/Q * 2^24); q[i] = trunc-toward-zero(n / 2^24).
+// Returns true when some coefficient lies within 1 unit of a multiple of 2^24 (candidate for the exact path).
+__device__ __forceinline__ bool quant8(const double* F, const double* ks, bool dc_lane, double rq_dc, int* n, int* q)
 {
     constexpr int MASK = (1 << QFRAC_BITS) - 1;
-    unsigned flags = 0;
+    unsigned m[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        const int n = (int)(F[i] * ks[i]);               // v_cvt_i32_f64 truncates toward zero
-        // within 1 unit of a multiple of 2^24 -- except around 0, which is not a truncation boundary
-        flags |= (((unsigned)((n + 1) & MASK) <= 2u && (unsigned)(n + 1) > 2u) ? 1u : 0u) << i;
-        q[i] = (n + ((n >> 31) & MASK)) >> QFRAC_BITS;    // trunc-toward-zero division by 2^24
+        n[i] = (int)(F[i] * ks[i]);                          // v_cvt_i32_f64 truncates toward zero
+        q[i] = (n[i] + ((n[i] >> 31) & MASK)) >> QFRAC_BITS;  // trunc-toward-zero division by 2^24
+        m[i] = (unsigned)(n[i] + 1) & MASK;                  // 0,1,2 <=> within one unit of a boundary
     }
     // DC: F[0] of the j == 0 lane is the exact integer sum of the block, so the reference value
     // int(sum*S*S/4) is reproduced bit for bit; (|iv|+0.5)/Q is never within 0.5/Q of an integer.
@@ -155,39 +176,41 @@ __device__ __forceinline__ unsigned quant8(const double* F, const double* ks, bo
         nq = iv < 0 ? -nq : nq;
         if (dc_lane) {
             q[0] = nq;
-            flags &= ~1u;
+            m[0] = MASK;
         }
     }
-    if (FORCE_EXACT) flags = 0xFFu;
-    return flags;
+    const unsigned a = min(min(m[0], m[1]), m[2]), b = min(min(m[3], m[4]), m[5]), c = min(m[6], m[7]);
+    return min(min(a, b), c) <= 2u;
 }
 
-struct BlockRef {   // what exact_fdct_coef needs to find a block again
-    const uint8_t* r;
-    const uint8_t* g;
-    const uint8_t* b;
-    int W, H;
-};
+// byte offsets of the staging area: blocks padded to 144 B so that the 8 blocks written by one
+// ds_write_b16 wave-instruction fall on different banks
+constexpr int STG_BLK = 144;
 
-template <bool FORCE_EXACT>
+// Quantise one block column, write it (zig-zag) to the staging area and queue the guard-band hits.
+// blk = index of the block inside the quad (m*BPM + b).  Queue entry = blk << 6 | natural index.
 __device__ __forceinline__ void quant_block_column(const double* F, const double* ks, int j, double rq_dc,
-                                                   const int* qt, const BlockRef& img, int px0, int py0, int comp,
-                                                   bool live, int16_t* stage_blk, unsigned& nfallback)
+                                                   bool live, const int* zoff, char* stage_blk, int blk,
+                                                   unsigned* queue)
 {
-    int q[8];
-    unsigned flags = quant8<FORCE_EXACT>(F, ks, j == 0, rq_dc, q);
-    if (!live) flags = 0;
-    if (flags) {
+    constexpr int MASK = (1 << QFRAC_BITS) - 1;
+    int n[8], q[8];
+    const bool cand = quant8(F, ks, j == 0, rq_dc, n, q);
+    if (cand && live) {   // rare
 #pragma unroll 1
         for (int i = 0; i < 8; ++i) {
-            if ((flags >> i) & 1u) {
-                q[i] = exact_fdct_coef(img.r, img.g, img.b, img.W, img.H, px0, py0, comp, i, j, qt[i * 8 + j]);
-                ++nfallback;
+            // within one unit of a multiple of 2^24 -- except around 0, which is not a truncation boundary;
+            // the DC term of the j == 0 lane is already exact
+            const bool f = ((unsigned)(n[i] + 1) & MASK) <= 2u && (unsigned)(n[i] + 1) > 2u && !(i == 0 && j == 0);
+            if (f) {
+                const unsigned slot = atomicAdd(&queue[0], 1u);
+                if (slot < (unsigned)QUEUE_CAP)
+                    reinterpret_cast<unsigned short*>(queue + 1)[slot] = (unsigned short)((blk << 6) | (i * 8 + j));
             }
         }
     }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) stage_blk[c_zzinv[i * 8 + j]] = (int16_t)q[i];
+    for (int i = 0; i < 8; ++i) *reinterpret_cast<int16_t*>(stage_blk + zoff[i]) = (int16_t)q[i];
 }
 
 __device__ __forceinline__ double byte_of(const uint32_t* w, int k)
@@ -199,10 +222,12 @@ __device__ __forceinline__ double byte_of(const uint32_t* w, int k)
 // ENCODE
 // ======================================================================================================
 template <bool GRAY, bool ALIGNED, bool FORCE_EXACT>
-__global__ __launch_bounds__(256) void fdct_quant_kernel(EncParams p)
+__global__ __launch_bounds__(256, 4) void fdct_quant_kernel(EncParams p)
 {
     __shared__ __attribute__((aligned(16))) uint32_t lds_all[4][WAVE_LDS_DWORDS];
     constexpr int BPM = GRAY ? 4 : 6;
+    constexpr int STG_BASE = 4 * C_MCU * 4;                   // bytes: staging sits behind the chroma tile
+    static_assert(STG_BASE + 4 * 6 * STG_BLK <= TILE_DWORDS * 4, "staging does not fit the tile area");
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long quad = (long)blockIdx.x * 4 + wave;
@@ -214,6 +239,8 @@ __global__ __launch_bounds__(256) void fdct_quant_kernel(EncParams p)
     const int quad_x = qrem - mcu_y * p.quads_per_row;
 
     uint32_t* lds = lds_all[wave];
+    unsigned* queue = lds + TILE_DWORDS;                        // [0] = count, then 16-bit entries
+    if (lane == 0) queue[0] = 0;
     const int row = lane >> 2, m = lane & 3;
     const int mcu_x_raw = quad_x * 4 + m;
     const bool live = mcu_x_raw < p.mcu_cols;
@@ -264,119 +291,143 @@ __global__ __launch_bounds__(256) void fdct_quant_kernel(EncParams p)
 #pragma unroll
         for (int k = 0; k < 8; ++k) dst[k] = make_double2(X[2 * k], X[2 * k + 1]);
     }
-
-    // ---- 3. chroma rows: even pixel rows, even pixel columns (top-left of each 2x2, ref :134-142) ----
-    double cbX[8], crX[8];
-    if (!GRAY) {
-        if ((row & 1) == 0) {
-            double cbv[8], crv[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const double rf = byte_of(R, 2 * k), gf = byte_of(G, 2 * k), bf = byte_of(B, 2 * k);
-                cbv[k] = ref_cb(rf, gf, bf);
-                crv[k] = ref_cr(rf, gf, bf);
-            }
-            fdct8(cbv, cbX);
-            fdct8(crv, crX);
-        }
-    }
     wave_sync();
 
-    // ---- 4. luma column pass: lane (cq, m) owns column cq of the 16x16 tile = column j of two blocks ----
+    // ---- 3. luma column pass: lane (cq, m) owns column cq of the 16x16 tile = column j of two blocks ----
     const int cq = row;                 // 0..15
     const int j = cq & 7;
     const DeviceTables* tab = p.tab;
-    unsigned nfallback = 0;
-    double Ftop[8], Fbot[8];
+    char* stage = reinterpret_cast<char*>(lds) + STG_BASE;
+    int zoff[8];                        // byte offset of natural coefficient (i, j) inside a staged block
+#pragma unroll
+    for (int i = 0; i < 8; ++i) zoff[i] = 2 * (int)c_zzinv[i * 8 + j];
     {
-        double col[16];
-        const uint32_t* src = lds + m * Y_MCU + cq * 2;
+        double Ftop[8], Fbot[8];
+        {
+            double col[16];
+            const uint32_t* src = lds + m * Y_MCU + cq * 2;
 #pragma unroll
-        for (int rr = 0; rr < 16; ++rr) col[rr] = *reinterpret_cast<const double*>(src + rr * Y_PITCH);
-        fdct8(col, Ftop);
-        fdct8(col + 8, Fbot);
-    }
-    wave_sync();   // everybody has read the luma tile; the slice is reused below
-
-    // chroma tile write (even rows only)
-    if (!GRAY) {
-        if ((row & 1) == 0) {
-            double2* dcb = reinterpret_cast<double2*>(lds + m * C_MCU + (row >> 1) * C_PITCH);
-            double2* dcr = reinterpret_cast<double2*>(lds + m * C_MCU + C_COMP + (row >> 1) * C_PITCH);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                dcb[k] = make_double2(cbX[2 * k], cbX[2 * k + 1]);
-                dcr[k] = make_double2(crX[2 * k], crX[2 * k + 1]);
-            }
+            for (int rr = 0; rr < 16; ++rr) col[rr] = *reinterpret_cast<const double*>(src + rr * Y_PITCH);
+            fdct8(col, Ftop);
+            fdct8(col + 8, Fbot);
         }
-        wave_sync();
-    }
-    double Fc[8];
-    if (!GRAY) {
-        double col[8];
-        const uint32_t* src = lds + m * C_MCU + (cq >> 3) * C_COMP + j * 2;
-#pragma unroll
-        for (int rr = 0; rr < 8; ++rr) col[rr] = *reinterpret_cast<const double*>(src + rr * C_PITCH);
-        fdct8(col, Fc);
-        wave_sync();   // chroma tile consumed; slice becomes the output staging area
-    }
+        wave_sync();   // every lane has read the luma tile: the slice is reused from here on
 
-    // ---- 5. quantise + zig-zag into the staging area [m][blk][64] int16 (same layout as global) ----
-    int16_t* stage = reinterpret_cast<int16_t*>(lds);
-    {
+        // ---- 4. quantise + zig-zag the two luma block columns into the staging area ----
         double ks[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) ks[i] = tab->qscale[0][j][i];
         const double rq = tab->rq_dc[0];
         const int bx = cq >> 3;   // 0: left blocks (Y0,Y2), 1: right blocks (Y1,Y3)
-        const int px0 = mcu_x * 16 + bx * 8, py0 = mcu_y * 16;
-        quant_block_column<FORCE_EXACT>(Ftop, ks, j, rq, tab->qt[0], img, px0, py0, 0, live,
-                                        stage + (m * BPM + bx) * 64, nfallback);
-        quant_block_column<FORCE_EXACT>(Fbot, ks, j, rq, tab->qt[0], img, px0, py0 + 8, 0, live,
-                                        stage + (m * BPM + 2 + bx) * 64, nfallback);
+        quant_block_column(Ftop, ks, j, rq, live, zoff, stage + (m * BPM + bx) * STG_BLK, m * BPM + bx, queue);
+        quant_block_column(Fbot, ks, j, rq, live, zoff, stage + (m * BPM + 2 + bx) * STG_BLK, m * BPM + 2 + bx, queue);
     }
+
+    // ---- 5. chroma: top-left pixel of every 2x2 (ref :134-142) = even pixel rows, even columns.  The odd-row
+    //         lane fetches its even neighbour's pixels (DPP row_shr:4) and computes Cr while the even-row lane
+    //         computes Cb, so all 64 lanes carry one chroma row each. ----
     if (!GRAY) {
+        const bool odd = (row & 1) != 0;
+        uint32_t R2[4], G2[4], B2[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            // row_shr:4 within each 16-lane DPP row, written only to lanes 4-7 and 12-15 (bank_mask 0b1010)
+            R2[k] = (uint32_t)__builtin_amdgcn_update_dpp((int)R[k], (int)R[k], 0x114, 0xF, 0xA, false);
+            G2[k] = (uint32_t)__builtin_amdgcn_update_dpp((int)G[k], (int)G[k], 0x114, 0xF, 0xA, false);
+            B2[k] = (uint32_t)__builtin_amdgcn_update_dpp((int)B[k], (int)B[k], 0x114, 0xF, 0xA, false);
+        }
+        // Cb = (-(0.1687 r) - 0.3313 g) + 0.5 b ; Cr = (0.5 r - 0.4187 g) - 0.0813 b  (ref :249-256), both as
+        // trunc((k1*r - k2*g) + k3*b): (-a)*r == -(a*r) and x - y == x + (-y) hold bit for bit in IEEE-754.
+        const double k1 = odd ? 0.5000 : -0.1687, k2 = odd ? 0.4187 : 0.3313, k3 = odd ? -0.0813 : 0.5000;
+        double cv[8], cX[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            cv[k] = __builtin_trunc((k1 * byte_of(R2, 2 * k) - k2 * byte_of(G2, 2 * k)) + k3 * byte_of(B2, 2 * k));
+        fdct8(cv, cX);
+        double2* dst = reinterpret_cast<double2*>(lds + m * C_MCU + (odd ? C_COMP : 0) + (row >> 1) * C_PITCH);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dst[k] = make_double2(cX[2 * k], cX[2 * k + 1]);
+        wave_sync();
+
+        double Fc[8];
+        {
+            double col[8];
+            const uint32_t* src = lds + m * C_MCU + (cq >> 3) * C_COMP + j * 2;
+#pragma unroll
+            for (int rr = 0; rr < 8; ++rr) col[rr] = *reinterpret_cast<const double*>(src + rr * C_PITCH);
+            fdct8(col, Fc);
+        }
         double ks[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) ks[i] = tab->qscale[1][j][i];
         const int comp = 1 + (cq >> 3);
-        quant_block_column<FORCE_EXACT>(Fc, ks, j, tab->rq_dc[1], tab->qt[1], img, mcu_x * 16, mcu_y * 16, comp, live,
-                                        stage + (m * BPM + 3 + comp) * 64, nfallback);
+        quant_block_column(Fc, ks, j, tab->rq_dc[1], live, zoff, stage + (m * BPM + 3 + comp) * STG_BLK,
+                           m * BPM + 3 + comp, queue);
     }
     wave_sync();
+
+    // ---- 5b. guard-band hits: re-evaluate in the reference's exact operation order, one coefficient at a
+    //          time, all 64 lanes cooperating (rare: ~0.7 % of blocks on random pixels).  FORCE_EXACT (test
+    //          hook) and a queue overflow send EVERY coefficient of the quad through this path. ----
+    {
+        const unsigned nq = queue[0];
+        const bool all = FORCE_EXACT || nq > (unsigned)QUEUE_CAP;
+        const unsigned total = all ? (unsigned)(4 * BPM * 64) : nq;
+        if (total) {
+            const int valid_mcus = min(4, p.mcu_cols - quad_x * 4);
+            unsigned done = 0;
+#pragma unroll 1
+            for (unsigned e = 0; e < total; ++e) {
+                const unsigned code = all ? e : reinterpret_cast<const unsigned short*>(queue + 1)[e];
+                const int blk = __builtin_amdgcn_readfirstlane((int)(code >> 6)), nat = __builtin_amdgcn_readfirstlane((int)(code & 63));
+                const int em = blk / BPM, eb = blk - em * BPM;
+                if (em >= valid_mcus) continue;
+                const int ei = nat >> 3, ej = nat & 7;
+                const int emx = quad_x * 4 + em;
+                int px0 = emx * 16, py0 = mcu_y * 16, comp = 0;
+                if (eb < 4) { px0 += (eb & 1) * 8; py0 += (eb >> 1) * 8; } else { comp = eb - 3; }
+                const int Q = tab->qt[comp ? 1 : 0][nat];
+                const int qv = exact_fdct_coef_wave(img, px0, py0, comp, ei, ej, Q, lane);
+                if (lane == 0) *reinterpret_cast<int16_t*>(stage + blk * STG_BLK + 2 * (int)c_zzinv[nat]) = (int16_t)qv;
+                ++done;
+            }
+            if (lane == 0 && done) atomicAdd(p.fallback_count, (unsigned long long)done);
+            wave_sync();
+        }
+    }
 
     // ---- 6. coalesced store of the quad's coefficients (BPM*128 bytes per MCU, contiguous) ----
     {
         const int valid_mcus = min(4, p.mcu_cols - quad_x * 4);
-        const int valid_bytes = valid_mcus * BPM * 128;
+        const int valid_chunks = valid_mcus * BPM * 8;         // 16-byte chunks
         int16_t* gbase = p.coeffs + (size_t)frame * p.coeffs_per_frame +
                          ((size_t)mcu_y * p.mcu_cols + (size_t)quad_x * 4) * (BPM * 64);
-        const uint4* s4 = reinterpret_cast<const uint4*>(lds);
         uint4* g4 = reinterpret_cast<uint4*>(gbase);
 #pragma unroll
         for (int k = 0; k < BPM * 128 * 4 / 1024; ++k) {
             const int c = k * 64 + lane;
-            if (c * 16 < valid_bytes) g4[c] = s4[c];
+            if (c < valid_chunks) g4[c] = *reinterpret_cast<const uint4*>(stage + (c >> 3) * STG_BLK + (c & 7) * 16);
         }
     }
-    if (nfallback) atomicAdd(p.fallback_count, (unsigned long long)nfallback);
 }
 
 // ======================================================================================================
 // DECODE
 // ======================================================================================================
 
-// exact-order IDCT of ONE sample (ref jpezy_decoder.hpp:645-670); blk = 64 zig-zag int16 coefficients
-__device__ __noinline__ int exact_idct_sample(const int16_t* __restrict__ blk, const int* __restrict__ qt, int x, int y)
+// exact-order IDCT of ONE sample (ref jpezy_decoder.hpp:645-670) from the block's list of NON-ZERO dequantised
+// coefficients, kept in the reference's summation order (v outer, u inner).  Skipping the zero coefficients
+// leaves the rounded running sum unchanged (x + (+-0) == x), so this is the reference's sum bit for bit.
+// list[t] = {natural index, coefficient * quantiser}; K, list wave-uniform; x, y per lane.
+__device__ __forceinline__ int exact_idct_sample_sparse(const int2* __restrict__ list, int K, int x, int y)
 {
     double sum = 0;
-    for (int v = 0; v < 8; ++v) {
-        const double cv = (!v) ? JPEZY_S : 1.0;
-        for (int u = 0; u < 8; ++u) {
-            const double cu = (!u) ? JPEZY_S : 1.0;
-            const int dct = (int)blk[c_zzinv[v * 8 + u]] * qt[v * 8 + u];
-            sum += cu * cv * dct * c_cos[u * 8 + x] * c_cos[v * 8 + y];
-        }
+#pragma unroll 1
+    for (int t = 0; t < K; ++t) {
+        const int2 e = list[t];
+        const int v = e.x >> 3, u = e.x & 7;
+        const double cv = (!v) ? JPEZY_S : 1.0, cu = (!u) ? JPEZY_S : 1.0;
+        sum += cu * cv * e.y * c_cos[u * 8 + x] * c_cos[v * 8 + y];
     }
     return (int)(sum / 4 + 128);
 }
@@ -414,6 +465,7 @@ __global__ __launch_bounds__(256) void dequant_idct_kernel(DecParams p)
     const int quad_x = qrem - mcu_y * p.quads_per_row;
 
     uint32_t* lds = lds_all[wave];
+    if (lane == 0) lds[TILE_DWORDS] = 0;                        // guard-band queue count
     const int row = lane >> 2, m = lane & 3;
     const int mcu_x = quad_x * 4 + m;
     const bool live = mcu_x < p.mcu_cols;
@@ -534,25 +586,70 @@ __global__ __launch_bounds__(256) void dequant_idct_kernel(DecParams p)
     }
     if (!live) { yflags = 0; cflags = 0; }
 
-    // ---- 4. exact path for flagged samples ----
-    unsigned nfallback = 0;
-    if (yflags | cflags) {
-        const int16_t* mcu = gbase + (size_t)m * BPM * 64;
-        const int by = row >> 3, yy = row & 7;
-#pragma unroll 1
-        for (int k = 0; k < 16; ++k) {
-            if ((yflags >> k) & 1u) {
-                Y[k] = exact_idct_sample(mcu + (by * 2 + (k >> 3)) * 64, p.dqt, k & 7, yy);
-                ++nfallback;
-            }
+    // ---- 4. exact path for flagged samples.  Lanes OR the blocks they need into a mask; for each such block
+    //         the wave builds the list of its non-zero dequantised coefficients (in the reference's summation
+    //         order), then every lane re-evaluates its own flagged samples of that block in exact order and
+    //         leaves them in a patch table [lane][k] (k: 0-15 luma, 16-23 Cb, 24-31 Cr) it reads back.
+    //         Cost grows with the number of non-zero coefficients: DC-only blocks (every sample sits on an
+    //         integer) cost one term per sample. ----
+    {
+        unsigned* need_blocks = lds + TILE_DWORDS;                 // zeroed at kernel start
+        int* patch = reinterpret_cast<int*>(lds);                  // tiles are dead by now: 64 x 32 x 4 B = 8 KB
+        int2* list = reinterpret_cast<int2*>(lds + 2048);          // 64 entries x 8 B behind the patch table
+        static_assert(2048 + 128 <= TILE_DWORDS, "patch table + list do not fit the tile area");
+        const unsigned myflags = force ? (GRAY ? 0xFFFFu : 0xFFFFFFFFu) : (yflags | (cflags << 16));
+        const int by = row >> 3;
+        unsigned myblocks = 0;
+        if (live) {
+            if (myflags & 0x000000FFu) myblocks |= 1u << (m * BPM + by * 2);
+            if (myflags & 0x0000FF00u) myblocks |= 1u << (m * BPM + by * 2 + 1);
+            if (myflags & 0x00FF0000u) myblocks |= 1u << (m * BPM + 4);
+            if (myflags & 0xFF000000u) myblocks |= 1u << (m * BPM + 5);
         }
-        if (!GRAY) {
+        wave_sync();                                               // all tile reads are done
+        if (myblocks) atomicOr(need_blocks, myblocks);
+        wave_sync();
+        unsigned todo = __builtin_amdgcn_readfirstlane((int)need_blocks[0]);
+        if (todo) {
+            unsigned done = 0;
 #pragma unroll 1
-            for (int k = 0; k < 16; ++k) {
-                if ((cflags >> k) & 1u) {
-                    const int s = exact_idct_sample(mcu + (4 + (k >> 3)) * 64, p.dqt + 64 * (1 + (k >> 3)), k & 7, row >> 1);
-                    if (k < 8) Cb[k] = s; else Cr[k - 8] = s;
-                    ++nfallback;
+            while (todo) {
+                const int blk = __builtin_ctz(todo);
+                todo &= todo - 1;
+                const int em = blk / BPM, eb = blk - em * BPM;
+                const int comp = eb < 4 ? 0 : eb - 3;
+                // build the non-zero list: lane k looks at natural index k
+                const int16_t* gblk = gbase + (size_t)blk * 64;
+                const int d = (int)gblk[c_zzinv[lane]] * p.dqt[comp * 64 + lane];      // inverse_quantization :645-650
+                const unsigned long long nzmask = __ballot(d != 0);
+                const int K = __builtin_popcountll(nzmask);
+                if (d != 0) list[__builtin_popcountll(nzmask & ((1ull << lane) - 1ull))] = make_int2(lane, d);
+                wave_sync();
+                if (m == em && ((myblocks >> blk) & 1u)) {
+                    // my flagged samples inside this block: 8 consecutive k
+                    const int k0 = eb < 4 ? (eb & 1) * 8 : 16 + (eb - 4) * 8;
+                    const int yy = eb < 4 ? (row & 7) : (row >> 1);
+#pragma unroll 1
+                    for (int k = k0; k < k0 + 8; ++k) {
+                        if ((myflags >> k) & 1u) {
+                            patch[lane * 32 + k] = exact_idct_sample_sparse(list, K, k & 7, yy);
+                            ++done;
+                        }
+                    }
+                }
+                wave_sync();
+            }
+            if (done) atomicAdd(p.fallback_count, (unsigned long long)done);
+            if (myflags && live) {
+#pragma unroll
+                for (int k = 0; k < 16; ++k)
+                    if ((myflags >> k) & 1u) Y[k] = patch[lane * 32 + k];
+                if (!GRAY) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        if ((myflags >> (16 + k)) & 1u) Cb[k] = patch[lane * 32 + 16 + k];
+                        if ((myflags >> (24 + k)) & 1u) Cr[k] = patch[lane * 32 + 24 + k];
+                    }
                 }
             }
         }
@@ -602,7 +699,6 @@ __global__ __launch_bounds__(256) void dequant_idct_kernel(DecParams p)
             }
         }
     }
-    if (nfallback) atomicAdd(p.fallback_count, (unsigned long long)nfallback);
 }
 
 // ======================================================================================================

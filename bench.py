@@ -160,17 +160,18 @@ def main():
 
     gather = None
     if world > 1 and not args.no_gather:
-        # north_star: gather the coefficient buffers over xGMI.  One all_gather of this rank's step output.
+        # north_star: gather the coefficient buffers over xGMI -- jpezy_amd.sharding.gather_coefficients,
+        # one all_gather of this rank's step output (fps frames per rank).
+        from jpezy_amd import sharding
         src = co[0].reshape(-1)
-        dst = torch.empty((world, src.numel()), dtype=src.dtype, device=dev)
         for _ in range(3):
-            dist.all_gather_into_tensor(dst, src)
+            sharding.gather_coefficients(src, fps * world, ncoef)
         torch.cuda.synchronize(dev)
         dist.barrier()
         g0 = time.perf_counter()
         reps = 10
         for _ in range(reps):
-            dist.all_gather_into_tensor(dst, src)
+            sharding.gather_coefficients(src, fps * world, ncoef)
         torch.cuda.synchronize(dev)
         dist.barrier()
         gdt = (time.perf_counter() - g0) / reps

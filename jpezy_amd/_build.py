@@ -62,7 +62,7 @@ def build_cli(force=False):
         exe = BIN / name
         if force or _stale(exe, [src, LIB, *host_hdrs]):
             _run([HIPCC, *COMMON, "-x", "c++", src, "-I", ROOT / "include", "-o", exe,
-                  "-L", PKG, "-ljpezy_hip", f"-Wl,-rpath,{PKG}", "-Wl,-rpath,$ORIGIN/..", "-lpthread"])
+                  "-L", PKG, "-ljpezy_hip", "-Wl,-rpath,$ORIGIN/..", "-lpthread"])
     return BIN
 
 

@@ -1,0 +1,160 @@
+// encode_io.hpp -- jpezy::encode_io (ASCII PPM P3 reader), to_jpeg, gray_scale and the pipe operators, mirroring
+// src/encoder/encode_io.hpp:35-208.  The reference's parser goes line by line through std::list and boost::split and
+// is 12x slower than its encoder (README.md:49,52); this one is a single pass over the file with the SAME acceptance
+// rules: lines containing '#' are dropped (:53), "P3" must be a line of its own (:63), width/height must be one line
+// of exactly two space-separated tokens (:68-72), max_color is parsed and unused (:77), a last line without a
+// trailing newline is dropped (:80), an empty token inside a pixel line is an error (std::stoi("") throws).
+#ifndef JPEZY_AMD_HOST_ENCODE_IO_HPP
+#define JPEZY_AMD_HOST_ENCODE_IO_HPP
+#include <cctype>
+#include <cstdio>
+#include <fstream>
+#include <iostream>
+#include <string>
+#include <tuple>
+#include <utility>
+#include <vector>
+
+#include "jpezy_encoder.hpp"
+#include "pnm_stream.hpp"
+
+namespace jpezy {
+
+struct to_jpeg {
+    explicit constexpr to_jpeg(const char* file_) : file(file_) {}
+    const char* file;
+};
+
+struct gray_scale_t {};
+inline constexpr gray_scale_t gray_scale{};
+
+struct encode_io : pnm_stream {
+    encode_io(const char* file_name) : pnm_stream(true, 0, 0, 0)
+    {
+        std::string text;
+        if (std::FILE* fp = std::fopen(file_name, "rb")) {
+            std::fseek(fp, 0, SEEK_END);
+            const long n = std::ftell(fp);
+            std::fseek(fp, 0, SEEK_SET);
+            text.resize(n > 0 ? static_cast<std::size_t>(n) : 0);
+            if (n > 0 && std::fread(text.data(), 1, text.size(), fp) != text.size()) text.clear();
+            std::fclose(fp);
+        } else {
+            initializing_succeed = false;
+            return;
+        }
+        std::size_t pos = 0;
+        bool eof = false;
+        // jump_comment (:49-55): next line that holds no '#'; sets eof when the line ended at end of file
+        auto next_line = [&]() -> std::string_view {
+            for (;;) {
+                if (pos >= text.size()) { eof = true; return {}; }
+                const std::size_t nl = text.find('\n', pos);
+                std::string_view line;
+                if (nl == std::string::npos) { line = std::string_view(text).substr(pos); pos = text.size(); eof = true; }
+                else { line = std::string_view(text).substr(pos, nl - pos); pos = nl + 1; }
+                if (eof || line.find('#') == std::string_view::npos) return line;
+            }
+        };
+        auto is_sp = [](char c) { return std::isspace(static_cast<unsigned char>(c)) != 0; };
+
+        if (next_line() != "P3") { initializing_succeed = false; return; }
+        {
+            const std::string_view wh = next_line();
+            std::vector<std::string> tok(1);
+            for (char c : wh) { if (is_sp(c)) tok.emplace_back(); else tok.back().push_back(c); }
+            if (tok.size() != 2) { initializing_succeed = false; return; }
+            width = static_cast<std::size_t>(std::stoi(tok[0]));
+            height = static_cast<std::size_t>(std::stoi(tok[1]));
+        }
+        max_color = static_cast<std::size_t>(std::stoi(std::string(next_line())));
+
+        std::vector<value_type> img;
+        img.reserve(width * height * 3);
+        for (std::string_view line = next_line(); !eof; line = next_line()) {
+            std::size_t i = 0;
+            const std::size_t n = line.size();
+            while (i <= n) {
+                std::size_t j = i;
+                while (j < n && !is_sp(line[j])) ++j;
+                if (j == i) {                          // empty token
+                    if (i == n) break;                 // ... the trailing one is popped (:84-85)
+                    throw std::invalid_argument("stoi");
+                }
+                int v = 0;
+                bool digits = false;
+                std::size_t k = i;
+                const bool neg = line[k] == '-';
+                if (neg || line[k] == '+') ++k;
+                for (; k < j && line[k] >= '0' && line[k] <= '9'; ++k) { v = v * 10 + (line[k] - '0'); digits = true; }
+                if (!digits) throw std::invalid_argument("stoi");
+                img.push_back(static_cast<value_type>(neg ? -v : v));
+                i = j + 1;
+            }
+        }
+        rgb_img.resize(img.size() / 3);
+        for (std::size_t px = 0; px < rgb_img.size(); ++px) rgb_img[px] = { img[3 * px], img[3 * px + 1], img[3 * px + 2] };
+        std::cout << "width: " << width << " height: " << height << std::endl;
+        if (rgb_img.size() < width * height) initializing_succeed = false;   // the reference would read out of bounds
+    }
+
+private:
+    friend std::ostream& operator<<(std::ostream& os, const encode_io& pnm)   // Mode::PPM / --debug (:104-119)
+    {
+        pnm.report_error(__func__);
+        os << "P3\n" << pnm.width << " " << pnm.height << "\n" << pnm.max_color << "\n";
+        for (const auto& px : pnm.rgb_img)
+            os << std::to_integer<unsigned>(px[0]) << " " << std::to_integer<unsigned>(px[1]) << " " << std::to_integer<unsigned>(px[2]) << '\n';
+        return os;
+    }
+
+    std::tuple<std::vector<rgb_type>, std::vector<rgb_type>, std::vector<rgb_type>> split_rgb() const   // :121-133
+    {
+        std::vector<rgb_type> r(rgb_img.size()), g(rgb_img.size()), b(rgb_img.size());
+        for (std::size_t i = 0; i < rgb_img.size(); ++i) { r[i] = rgb_img[i][0]; g[i] = rgb_img[i][1]; b[i] = rgb_img[i][2]; }
+        return { std::move(r), std::move(g), std::move(b) };
+    }
+
+    template <class MODE_TAG>
+    std::size_t run_encoder(const char* file, const char* comment) const
+    {
+        const property pr = make_property({ width, height, 3, 8, comment, property::Format::JFIF, byte(1), byte(2),
+                                            property::Units::dots_inch, 96, 96, 0, 0, property::ExtensionCodes::undefined,
+                                            property::AnalyzedResult::Yet });
+        auto [r, g, b] = split_rgb();
+        encoder enc(pr, r, g, b);
+        return enc.template encode<MODE_TAG>(file);
+    }
+
+    friend std::ofstream& operator<<(std::ofstream& ofs, const std::pair<const to_jpeg, const encode_io&>& pnm)   // :135-169
+    {
+        ofs.close();
+        pnm.second.report_error(__func__);
+        const std::size_t size = pnm.second.run_encoder<COLOR_MODE>(pnm.first.file, "Encoded by jpezy");
+        std::cout << "Output size: " << size << " byte" << std::endl;
+        return ofs;
+    }
+
+    friend std::ofstream& operator<<(std::ofstream& ofs, const std::pair<gray_scale_t, std::pair<const to_jpeg, const encode_io&>>& pnm)   // :171-196
+    {
+        ofs.close();
+        pnm.second.second.report_error(__func__);
+        const std::size_t size = pnm.second.second.run_encoder<GRAY_MODE>(pnm.second.first.file, "Encoded by JPEZY");
+        std::cout << "Output size: " << size << " srook::byte" << std::endl;      // sic (:193)
+        return ofs;
+    }
+
+    friend std::pair<gray_scale_t, std::pair<const to_jpeg, const encode_io&>>
+    operator|(const std::pair<const to_jpeg, const encode_io&>& pnm, const gray_scale_t& gr)
+    {
+        return { gr, pnm };
+    }
+
+    friend std::pair<const to_jpeg, const encode_io&> operator|(const encode_io& pnm, const to_jpeg& jpeg_tag) noexcept
+    {
+        return { jpeg_tag, pnm };
+    }
+};
+
+}  // namespace jpezy
+#endif

@@ -79,6 +79,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="encode4096", choices=sorted(WORKLOADS))
     ap.add_argument("--ring", type=int, default=0, help="distinct batches in the ring (0 = enough to exceed 512 MiB)")
+    ap.add_argument("--variant", type=int, default=None, help="encode kernel variant (0 FP64 butterflies, 1 FP32 first level)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-gather", action="store_true", help="skip the separate RCCL gather measurement (N>1)")
     args = ap.parse_args()
@@ -104,6 +105,8 @@ def main():
 
     W, H, gray, fps, direction, desc = WORKLOADS[args.workload]
     ctx = J.Context(local_rank)
+    if args.variant is not None:
+        ctx.set_variant(args.variant)
     plane = W * H
     ncoef = J.coeff_count(W, H, gray if direction == "encode" else False)
     step_bytes = algorithmic_bytes(W, H, gray, direction) * fps

@@ -99,8 +99,12 @@ int jpezy_dequant_idct_dev(jpezy_ctx* ctx, const int16_t* d_coeffs, const uint16
                            int n_frames, uint8_t* d_r, uint8_t* d_g, uint8_t* d_b, void* stream);
 
 /* Test hook: route EVERY coefficient / sample through the kernels' exact-order fallback (the path a
- * guard-band hit takes).  0 = normal.  Exists so that the rare branch has its own parity test. */
+ * guard-band hit takes).  0 = normal, 1 = reference-order path, 2 = (encode variant 1 only) the FP64 second
+ * level, which may still defer to the reference-order path.  Exists so the rare branches have parity tests. */
 void jpezy_ctx_set_force_exact(jpezy_ctx* ctx, int on);
+/* Encode kernel variant: 0 = FP64 butterflies (round-1 kernel), 1 = FP32 first level + FP64 second level +
+ * reference-order third level.  Both produce identical coefficients; they differ in speed only. */
+int jpezy_ctx_set_variant(jpezy_ctx* ctx, int variant);
 /* Synchronises the device and returns how many coefficients/samples were resolved through the
  * exact-order fallback on this context since the previous call (the counter is then reset); -1 on error */
 long jpezy_ctx_last_fallback_count(jpezy_ctx* ctx);

@@ -52,6 +52,7 @@ ABI = [
     ("jpezy_dequant_idct", C.c_int, [_vp, _vp, _QT, _TQ, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp]),
     ("jpezy_dequant_idct_dev", C.c_int, [_vp, _vp, _QT, _TQ, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp]),
     ("jpezy_ctx_set_force_exact", None, [_vp, C.c_int]),
+    ("jpezy_ctx_set_variant", C.c_int, [_vp, C.c_int]),
     ("jpezy_ctx_last_fallback_count", C.c_long, [_vp]),
     ("jpezy_write_jpeg", C.c_long, [_vp, C.c_int, C.c_int, C.c_int, C.c_char_p, _vp, C.c_size_t]),
     ("jpezy_jpeg_bound", C.c_size_t, [C.c_int, C.c_int]),
@@ -143,7 +144,10 @@ class Context:
         _check(load_library().jpezy_ctx_sync(self._h))
 
     def set_force_exact(self, on):
-        load_library().jpezy_ctx_set_force_exact(self._h, int(bool(on)))
+        load_library().jpezy_ctx_set_force_exact(self._h, int(on))
+
+    def set_variant(self, variant):
+        _check(load_library().jpezy_ctx_set_variant(self._h, int(variant)))
 
     def fallback_count(self):
         return load_library().jpezy_ctx_last_fallback_count(self._h)

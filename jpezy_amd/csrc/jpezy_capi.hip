@@ -69,7 +69,8 @@ struct jpezy_ctx {
     int* d_dqt = nullptr;          // [3][64]
     uint16_t dq_cache[3][64];
     bool dq_valid = false;
-    bool force_exact = false;
+    int force_exact = 0;           // 0 normal, 1 everything through the reference-order path, 2 (f32 variant) through level 2
+    int variant = 1;               // encode kernel: 0 = FP64 butterflies, 1 = FP32 first level (default: faster)
     DevBuf in[3], out;             // staging for the host-buffer entry points
 };
 
@@ -115,16 +116,24 @@ jpezy_ctx* jpezy_ctx_create(int device)
                 h.qscale[t][j][i] = cu * cv / (4.0 * kQt[t][i * 8 + j]) * (double)(1 << QFRAC_BITS);
             }
         h.rq_dc[t] = 1.0 / kQt[t][0];
-        for (int k = 0; k < 64; ++k) h.qt[t][k] = kQt[t][k];
+        for (int k = 0; k < 64; ++k) {
+            h.qt[t][k] = kQt[t][k];
+            h.qinv[t][k] = 1.0 / kQt[t][k];
+        }
+        for (int j = 0; j < 8; ++j)
+            for (int i = 0; i < 8; ++i) {
+                const double cu = j ? 1.0 : S, cv = i ? 1.0 : S;
+                h.qscale_f[t][j][i] = (float)(cu * cv / (4.0 * kQt[t][i * 8 + j]));
+            }
     }
     bool ok = hipSetDevice(device) == hipSuccess;
     ok = ok && hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
     ok = ok && hipMalloc((void**)&c->d_tab, sizeof(DeviceTables)) == hipSuccess;
-    ok = ok && hipMalloc((void**)&c->d_counter, sizeof(unsigned long long)) == hipSuccess;
+    ok = ok && hipMalloc((void**)&c->d_counter, sizeof(unsigned long long) * COUNTER_SHARDS) == hipSuccess;
     ok = ok && hipMalloc((void**)&c->d_dqscale, sizeof(double) * 3 * 64) == hipSuccess;
     ok = ok && hipMalloc((void**)&c->d_dqt, sizeof(int) * 3 * 64) == hipSuccess;
     ok = ok && hipMemcpy(c->d_tab, &h, sizeof h, hipMemcpyHostToDevice) == hipSuccess;
-    ok = ok && hipMemset(c->d_counter, 0, sizeof(unsigned long long)) == hipSuccess;
+    ok = ok && hipMemset(c->d_counter, 0, sizeof(unsigned long long) * COUNTER_SHARDS) == hipSuccess;
     if (!ok) {
         set_err(JPEZY_E_HIP, std::string("context creation failed: ") + hipGetErrorString(hipGetLastError()));
         jpezy_ctx_destroy(c);
@@ -160,17 +169,27 @@ void* jpezy_ctx_stream(const jpezy_ctx* c) { return c ? (void*)c->stream : nullp
 
 void jpezy_ctx_set_force_exact(jpezy_ctx* c, int on)
 {
-    if (c) c->force_exact = on != 0;
+    if (c) c->force_exact = on < 0 ? 0 : on > 2 ? 2 : on;
+}
+
+int jpezy_ctx_set_variant(jpezy_ctx* c, int variant)
+{
+    if (!c) return set_err(JPEZY_E_BADARG, "null context");
+    if (variant < 0 || variant > 1) return set_err(JPEZY_E_BADARG, "unknown kernel variant");
+    c->variant = variant;
+    return JPEZY_OK;
 }
 
 long jpezy_ctx_last_fallback_count(jpezy_ctx* c)
 {
     if (!c) return -1;
-    unsigned long long v = 0;
+    static thread_local unsigned long long shards[COUNTER_SHARDS];
     if (hipSetDevice(c->device) != hipSuccess) return -1;
     if (hipDeviceSynchronize() != hipSuccess) return -1;
-    if (hipMemcpy(&v, c->d_counter, sizeof v, hipMemcpyDeviceToHost) != hipSuccess) return -1;
-    if (hipMemset(c->d_counter, 0, sizeof v) != hipSuccess) return -1;
+    if (hipMemcpy(shards, c->d_counter, sizeof shards, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    if (hipMemset(c->d_counter, 0, sizeof shards) != hipSuccess) return -1;
+    unsigned long long v = 0;
+    for (unsigned long long s : shards) v += s;
     return (long)v;
 }
 
@@ -202,7 +221,11 @@ int jpezy_fdct_quant_dev(jpezy_ctx* c, const uint8_t* d_r, const uint8_t* d_g, c
     p.mcu_rows = jpezy_mcu_rows(H);
     p.quads_per_row = (p.mcu_cols + 3) / 4;
     p.n_frames = n_frames;
-    HIP_TRY(launch_fdct_quant(p, gray != 0, c->force_exact, s));
+    fast_div_setup((unsigned)p.quads_per_row, &p.qpr_magic, &p.qpr_shift);
+    if (c->variant == 1)
+        HIP_TRY(launch_fdct_quant_f32(p, gray != 0, c->force_exact, s));
+    else
+        HIP_TRY(launch_fdct_quant(p, gray != 0, c->force_exact != 0, s));
     return JPEZY_OK;
 }
 
@@ -280,7 +303,7 @@ int jpezy_dequant_idct_dev(jpezy_ctx* c, const int16_t* d_coeffs, const uint16_t
     p.mcu_rows = jpezy_mcu_rows(H);
     p.quads_per_row = (p.mcu_cols + 3) / 4;
     p.n_frames = n_frames;
-    HIP_TRY(launch_dequant_idct(p, gray != 0, c->force_exact, s));
+    HIP_TRY(launch_dequant_idct(p, gray != 0, c->force_exact != 0, s));
     return JPEZY_OK;
 }
 

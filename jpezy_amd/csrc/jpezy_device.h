@@ -18,7 +18,19 @@ struct DeviceTables {
     double qscale[2][8][8];
     double rq_dc[2];          // 1 / Q_t[0]
     int qt[2][64];            // natural order
+    // f32 first-level kernel: qscale_f[t][j][i] = cu(j) * cv(i) / (4 * Q_t[i*8+j]) ; qinv[t][k] = 1.0 / Q_t[k]
+    float qscale_f[2][8][8];
+    double qinv[2][64];
 };
+
+// The exact-path counter is sharded over COUNTER_SHARDS words: thousands of waves adding to ONE word serialise
+// at ~12 ns per atomic (88 per us, MI355X_MICROARCH.md 'dequeue') and held every wave slot until they drained.
+constexpr int COUNTER_SHARDS = 1024;
+
+// Waves per workgroup.  Waves never talk to each other, and a workgroup's LDS and wave slots are only released
+// when its LAST wave ends -- with the rare exact path stretching single waves, one wave per workgroup keeps the
+// other three from being held hostage (measured: 52 -> see DESIGN.md).
+constexpr int WPB = 1;
 
 struct EncParams {
     const uint8_t* r;
@@ -30,6 +42,7 @@ struct EncParams {
     const DeviceTables* tab;
     unsigned long long* fallback_count;
     int W, H, mcu_cols, mcu_rows, quads_per_row, n_frames;
+    unsigned qpr_magic, qpr_shift;   // fast_div by quads_per_row (f32 kernel)
 };
 
 struct DecParams {
@@ -45,7 +58,21 @@ struct DecParams {
     int W, H, mcu_cols, mcu_rows, quads_per_row, n_frames;
 };
 
+// (magic, shift) such that n / d == (((n - mulhi(n, magic)) >> 1) + mulhi(n, magic)) >> shift for all 32-bit n;
+// magic == 0 encodes d == 1
+inline void fast_div_setup(unsigned d, unsigned* magic, unsigned* shift)
+{
+    unsigned l = 0;
+    while ((1ull << l) < d) ++l;                       // ceil(log2 d)
+    *magic = (unsigned)(((1ull << 32) * ((1ull << l) - d)) / d + 1);
+    *shift = l ? l - 1 : 0;
+    if (d == 1) { *magic = 0; *shift = 0; }
+}
+
 hipError_t launch_fdct_quant(const EncParams& p, bool gray, bool force_exact, hipStream_t stream);
+// variant 1: FP32 first level, FP64 second level, reference-order third level.  force: 0 normal, 1 every
+// coefficient through the reference-order chain, 2 every coefficient through the FP64 second level.
+hipError_t launch_fdct_quant_f32(const EncParams& p, bool gray, int force, hipStream_t stream);
 hipError_t launch_dequant_idct(const DecParams& p, bool gray, bool force_exact, hipStream_t stream);
 
 }  // namespace jpezy_dev

@@ -196,8 +196,8 @@ __device__ __forceinline__ void quant_block_column(const double* F, const double
     constexpr int MASK = (1 << QFRAC_BITS) - 1;
     int n[8], q[8];
     const bool cand = quant8(F, ks, j == 0, rq_dc, n, q);
-    if (cand && live) {   // rare
-#pragma unroll 1
+    if (cand && live) {   // rare.  Fully unrolled: a runtime index into n[] would send the array to scratch
+#pragma unroll
         for (int i = 0; i < 8; ++i) {
             // within one unit of a multiple of 2^24 -- except around 0, which is not a truncation boundary;
             // the DC term of the j == 0 lane is already exact
@@ -222,15 +222,15 @@ __device__ __forceinline__ double byte_of(const uint32_t* w, int k)
 // ENCODE
 // ======================================================================================================
 template <bool GRAY, bool ALIGNED, bool FORCE_EXACT>
-__global__ __launch_bounds__(256, 4) void fdct_quant_kernel(EncParams p)
+__global__ __launch_bounds__(64 * WPB, 4) void fdct_quant_kernel(EncParams p)
 {
-    __shared__ __attribute__((aligned(16))) uint32_t lds_all[4][WAVE_LDS_DWORDS];
+    __shared__ __attribute__((aligned(16))) uint32_t lds_all[WPB][WAVE_LDS_DWORDS];
     constexpr int BPM = GRAY ? 4 : 6;
     constexpr int STG_BASE = 4 * C_MCU * 4;                   // bytes: staging sits behind the chroma tile
     static_assert(STG_BASE + 4 * 6 * STG_BLK <= TILE_DWORDS * 4, "staging does not fit the tile area");
 
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const long quad = (long)blockIdx.x * 4 + wave;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;   // WPB waves per workgroup
+    const long quad = (long)blockIdx.x * WPB + wave;
     const long quads_per_frame = (long)p.mcu_rows * p.quads_per_row;
     if (quad >= quads_per_frame * p.n_frames) return;   // wave-uniform
     const int frame = (int)(quad / quads_per_frame);
@@ -391,7 +391,7 @@ __global__ __launch_bounds__(256, 4) void fdct_quant_kernel(EncParams p)
                 if (lane == 0) *reinterpret_cast<int16_t*>(stage + blk * STG_BLK + 2 * (int)c_zzinv[nat]) = (int16_t)qv;
                 ++done;
             }
-            if (lane == 0 && done) atomicAdd(p.fallback_count, (unsigned long long)done);
+            if (lane == 0 && done) atomicAdd(p.fallback_count + ((blockIdx.x * (unsigned)WPB + wave) & (COUNTER_SHARDS - 1)), (unsigned long long)done);
             wave_sync();
         }
     }
@@ -450,13 +450,13 @@ __device__ __forceinline__ uint32_t clamp_byte(double v)   // revise_value, ref 
 }
 
 template <bool GRAY, bool ALIGNED, bool FORCE_EXACT>
-__global__ __launch_bounds__(256) void dequant_idct_kernel(DecParams p)
+__global__ __launch_bounds__(64 * WPB) void dequant_idct_kernel(DecParams p)
 {
-    __shared__ __attribute__((aligned(16))) uint32_t lds_all[4][WAVE_LDS_DWORDS];
+    __shared__ __attribute__((aligned(16))) uint32_t lds_all[WPB][WAVE_LDS_DWORDS];
     constexpr int BPM = 6;
 
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const long quad = (long)blockIdx.x * 4 + wave;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;   // WPB waves per workgroup
+    const long quad = (long)blockIdx.x * WPB + wave;
     const long quads_per_frame = (long)p.mcu_rows * p.quads_per_row;
     if (quad >= quads_per_frame * p.n_frames) return;
     const int frame = (int)(quad / quads_per_frame);
@@ -639,7 +639,7 @@ __global__ __launch_bounds__(256) void dequant_idct_kernel(DecParams p)
                 }
                 wave_sync();
             }
-            if (done) atomicAdd(p.fallback_count, (unsigned long long)done);
+            if (done) atomicAdd(p.fallback_count + ((blockIdx.x * (unsigned)WPB + wave) & (COUNTER_SHARDS - 1)), (unsigned long long)done);
             if (myflags && live) {
 #pragma unroll
                 for (int k = 0; k < 16; ++k)
@@ -714,16 +714,16 @@ template <bool GRAY, bool ALIGNED>
 static void enc_launch2(const EncParams& p, bool force, dim3 grid, hipStream_t s)
 {
     if (force)
-        hipLaunchKernelGGL((fdct_quant_kernel<GRAY, ALIGNED, true>), grid, dim3(256), 0, s, p);
+        hipLaunchKernelGGL((fdct_quant_kernel<GRAY, ALIGNED, true>), grid, dim3(64 * WPB), 0, s, p);
     else
-        hipLaunchKernelGGL((fdct_quant_kernel<GRAY, ALIGNED, false>), grid, dim3(256), 0, s, p);
+        hipLaunchKernelGGL((fdct_quant_kernel<GRAY, ALIGNED, false>), grid, dim3(64 * WPB), 0, s, p);
 }
 
 hipError_t launch_fdct_quant(const EncParams& p, bool gray, bool force_exact, hipStream_t stream)
 {
     const long quads = (long)p.n_frames * p.mcu_rows * p.quads_per_row;
     if (quads <= 0) return hipSuccess;
-    const dim3 grid((unsigned)((quads + 3) / 4));
+    const dim3 grid((unsigned)((quads + WPB - 1) / WPB));
     const bool al = is_aligned16(p, p.r, p.g, p.b);
     if (gray) { if (al) enc_launch2<true, true>(p, force_exact, grid, stream); else enc_launch2<true, false>(p, force_exact, grid, stream); }
     else      { if (al) enc_launch2<false, true>(p, force_exact, grid, stream); else enc_launch2<false, false>(p, force_exact, grid, stream); }
@@ -734,16 +734,16 @@ template <bool GRAY, bool ALIGNED>
 static void dec_launch2(const DecParams& p, bool force, dim3 grid, hipStream_t s)
 {
     if (force)
-        hipLaunchKernelGGL((dequant_idct_kernel<GRAY, ALIGNED, true>), grid, dim3(256), 0, s, p);
+        hipLaunchKernelGGL((dequant_idct_kernel<GRAY, ALIGNED, true>), grid, dim3(64 * WPB), 0, s, p);
     else
-        hipLaunchKernelGGL((dequant_idct_kernel<GRAY, ALIGNED, false>), grid, dim3(256), 0, s, p);
+        hipLaunchKernelGGL((dequant_idct_kernel<GRAY, ALIGNED, false>), grid, dim3(64 * WPB), 0, s, p);
 }
 
 hipError_t launch_dequant_idct(const DecParams& p, bool gray, bool force_exact, hipStream_t stream)
 {
     const long quads = (long)p.n_frames * p.mcu_rows * p.quads_per_row;
     if (quads <= 0) return hipSuccess;
-    const dim3 grid((unsigned)((quads + 3) / 4));
+    const dim3 grid((unsigned)((quads + WPB - 1) / WPB));
     const bool al = is_aligned16(p, p.r, p.g, p.b);
     if (gray) { if (al) dec_launch2<true, true>(p, force_exact, grid, stream); else dec_launch2<true, false>(p, force_exact, grid, stream); }
     else      { if (al) dec_launch2<false, true>(p, force_exact, grid, stream); else dec_launch2<false, false>(p, force_exact, grid, stream); }

@@ -1,0 +1,512 @@
+// jpezy_kernels_f32.hip -- encode kernel, variant 1: three precision levels, same bits as the reference.
+//
+// Level 1 (every coefficient): colour conversion in exact FP32 integer arithmetic, separable 8-point butterflies in
+//   FP32.  A quantised coefficient t = F*cu*cv/(4Q) is accepted when it is further than DELTA1 = 2^-12 from every
+//   non-zero integer; the proven worst-case FP32 error of t is 9e-5 (DESIGN.md "exactness, f32 variant").
+// Level 2 (guard-band hits, ~0.5 per quad): the whole wave recomputes that one coefficient in FP64 from the pixels
+//   (lane k = term k, tree sum); accepted when further than 1e-6 from every boundary m*Q, m != 0.
+// Level 3 (true boundary cases, ~0.2 per quad): the 64 terms are added in the reference's exact order.
+// Colour conversion: Y = trunc(M/1000), M = 299R+587G+114B-128000 is exact in FP32 (integers < 2^24); when
+//   M mod 1000 == 0 (1 pixel in 1000) the reference's FP64 rounding decides and the FP64 formula is evaluated.
+// The DC coefficient is a sum of integers (exact in FP32) and always evaluated in the reference's FP64 order.
+// Compiled with -ffp-contract=off; every FMA below is explicit.
+#include "jpezy_device.h"
+#include "../../include/jpezy_constants.h"
+
+namespace jpezy_dev {
+namespace f32 {
+
+__constant__ double c_cos[64] = JPEZY_COS_INIT;
+__constant__ unsigned char c_zzinv[64] = JPEZY_ZZ_INV_INIT;
+
+#define JPEZY_S JPEZY_INV_SQRT2
+#define K1 0x1.f6297cff75cb0p-1f
+#define K2 0x1.d906bcf328d46p-1f
+#define K3 0x1.a9b66290ea1a3p-1f
+#define K4 0x1.6a09e667f3bcdp-1f
+#define K5 0x1.1c73b39ae68c8p-1f
+#define K6 0x1.87de2a6aea963p-2f
+#define K7 0x1.8f8b83c69a60bp-3f
+#define FMAF(a, b, c) __builtin_fmaf((a), (b), (c))
+#ifndef JPEZY_F32_WAVES
+#define JPEZY_F32_WAVES 5
+#endif
+
+constexpr float DELTA1_DEFAULT = 0x1p-12f;  // level-1 guard band on t = v/Q (proven error bound 9e-5)
+#ifdef JPEZY_DEBUG_NO_LEVEL2
+constexpr float DELTA1 = 0.f;               // timing experiment only: wrong results
+#else
+constexpr float DELTA1 = DELTA1_DEFAULT;
+#endif
+constexpr double DELTA2 = 1e-6;             // level-2 guard band on v (FP64 tree-sum error < 1e-9)
+
+// LDS geometry in dwords (floats).  Column reads are ds_read_b32 over 32-lane groups (32 banks): conflict free
+// when the per-MCU stride == 8 (mod 32); row writes are ds_write_b128 over 8-lane groups: pitch 20 keeps them apart.
+constexpr int Y_PITCH = 20;
+constexpr int Y_MCU = 16 * Y_PITCH + 8;     // 328
+constexpr int C_PITCH = 8;
+constexpr int C_COMP = 68;                  // Cb rows, then Cr rows 68 dwords later (== 4 mod 32)
+constexpr int C_MCU = 136;                  // == 8 mod 32
+constexpr int STG_BLK = 144;                // bytes per staged block (128 + 16 pad)
+constexpr int CT_BYTES = 4 * C_MCU * 4;     // 2176: chroma tile, then the staging area behind it
+constexpr int STG_BYTES = 4 * 6 * STG_BLK;  // 3456
+constexpr int TILE_BYTES = (4 * Y_MCU * 4 > CT_BYTES + STG_BYTES) ? 4 * Y_MCU * 4 : CT_BYTES + STG_BYTES;   // 5632
+constexpr int QUEUE_CAP = 126;
+constexpr int WAVE_LDS_DWORDS = TILE_BYTES / 4 + 64;   // 5888 B per wave: 6 waves per SIMD fit the 160 KB of a CU
+
+__device__ __forceinline__ unsigned fast_div(unsigned n, unsigned magic, unsigned shift)
+{
+    const unsigned q = __umulhi(n, magic);
+    return magic ? (((n - q) >> 1) + q) >> shift : n;
+}
+
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// X[u] = sum_x x[x] * cos((2x+1)u*pi/16); X[0] is the plain sum (exact for integers below 2^24)
+__device__ __forceinline__ void fdct8f(const float* x, float* X)
+{
+    const float s0 = x[0] + x[7], s1 = x[1] + x[6], s2 = x[2] + x[5], s3 = x[3] + x[4];
+    const float d0 = x[0] - x[7], d1 = x[1] - x[6], d2 = x[2] - x[5], d3 = x[3] - x[4];
+    const float e0 = s0 + s3, e1 = s1 + s2, e2 = s0 - s3, e3 = s1 - s2;
+    X[0] = e0 + e1;
+    X[4] = (e0 - e1) * K4;
+    X[2] = FMAF(e3, K6, e2 * K2);
+    X[6] = FMAF(-e3, K2, e2 * K6);
+    X[1] = FMAF(d3, K7, FMAF(d2, K5, FMAF(d1, K3, d0 * K1)));
+    X[3] = FMAF(-d3, K5, FMAF(-d2, K1, FMAF(-d1, K7, d0 * K3)));
+    X[5] = FMAF(d3, K3, FMAF(d2, K7, FMAF(-d1, K1, d0 * K5)));
+    X[7] = FMAF(-d3, K1, FMAF(d2, K3, FMAF(-d1, K5, d0 * K7)));
+}
+
+// ---- colour conversion in the reference's exact FP64 order (ref encoder/jpezy_encoder.hpp:244-256) ----
+__device__ __forceinline__ double ref_y(double r, double g, double b)
+{
+    return __builtin_trunc((0.2990 * r) + (0.5870 * g) + (0.1140 * b) - 128.0);
+}
+__device__ __forceinline__ double ref_cb(double r, double g, double b)
+{
+    return __builtin_trunc(-(0.1687 * r) - (0.3313 * g) + (0.5000 * b));
+}
+__device__ __forceinline__ double ref_cr(double r, double g, double b)
+{
+    return __builtin_trunc((0.5000 * r) - (0.4187 * g) - (0.0813 * b));
+}
+
+template <int B>
+__device__ __forceinline__ float ubyte(uint32_t w)
+{
+    return (float)((w >> (8 * B)) & 0xFFu);      // selected as v_cvt_f32_ubyteB
+}
+
+// Y of pixel byte B of the three words: exact unless M mod 1000 == 0 (flag)
+template <int B>
+__device__ __forceinline__ float luma_px(uint32_t wr, uint32_t wg, uint32_t wb, bool& flag)
+{
+    const float rf = ubyte<B>(wr), gf = ubyte<B>(wg), bf = ubyte<B>(wb);
+    const float M = FMAF(114.f, bf, FMAF(587.f, gf, FMAF(299.f, rf, -128000.f)));   // exact integer
+    const float Yt = __builtin_truncf(M * 0.001f);
+    const float r = FMAF(-1000.f, Yt, M);                                            // exact remainder
+    flag = __builtin_fabsf(__builtin_fabsf(r) - 500.f) == 500.f;                     // r == 0 or |r| == 1000
+    return Yt;
+}
+template <int B>
+__device__ __forceinline__ float luma_px_ref(uint32_t wr, uint32_t wg, uint32_t wb)
+{
+    return (float)ref_y((double)ubyte<B>(wr), (double)ubyte<B>(wg), (double)ubyte<B>(wb));
+}
+
+// 8 luma samples of words wr[0..1] etc. (pixels 0..7 of a half row)
+__device__ __forceinline__ void luma8(const uint32_t* wr, const uint32_t* wg, const uint32_t* wb, float* y)
+{
+    bool f[8];
+    y[0] = luma_px<0>(wr[0], wg[0], wb[0], f[0]);
+    y[1] = luma_px<1>(wr[0], wg[0], wb[0], f[1]);
+    y[2] = luma_px<2>(wr[0], wg[0], wb[0], f[2]);
+    y[3] = luma_px<3>(wr[0], wg[0], wb[0], f[3]);
+    y[4] = luma_px<0>(wr[1], wg[1], wb[1], f[4]);
+    y[5] = luma_px<1>(wr[1], wg[1], wb[1], f[5]);
+    y[6] = luma_px<2>(wr[1], wg[1], wb[1], f[6]);
+    y[7] = luma_px<3>(wr[1], wg[1], wb[1], f[7]);
+    const bool any = f[0] | f[1] | f[2] | f[3] | f[4] | f[5] | f[6] | f[7];
+    if (__any(any)) {   // one pixel in 1000: the reference's FP64 rounding decides
+        if (__any(f[0])) { if (f[0]) y[0] = luma_px_ref<0>(wr[0], wg[0], wb[0]); }
+        if (__any(f[1])) { if (f[1]) y[1] = luma_px_ref<1>(wr[0], wg[0], wb[0]); }
+        if (__any(f[2])) { if (f[2]) y[2] = luma_px_ref<2>(wr[0], wg[0], wb[0]); }
+        if (__any(f[3])) { if (f[3]) y[3] = luma_px_ref<3>(wr[0], wg[0], wb[0]); }
+        if (__any(f[4])) { if (f[4]) y[4] = luma_px_ref<0>(wr[1], wg[1], wb[1]); }
+        if (__any(f[5])) { if (f[5]) y[5] = luma_px_ref<1>(wr[1], wg[1], wb[1]); }
+        if (__any(f[6])) { if (f[6]) y[6] = luma_px_ref<2>(wr[1], wg[1], wb[1]); }
+        if (__any(f[7])) { if (f[7]) y[7] = luma_px_ref<3>(wr[1], wg[1], wb[1]); }
+    }
+}
+
+// chroma sample (Cb on even-row lanes, Cr on odd-row lanes) of pixel byte B: N = k1 R + k2 G + k3 B with the
+// integer constants x 10000 is exact in FP32; exact unless N mod 10000 == 0
+template <int B>
+__device__ __forceinline__ float chroma_px(uint32_t wr, uint32_t wg, uint32_t wb, float k1, float k2, float k3, bool odd,
+                                           bool& flag)
+{
+    const float rf = ubyte<B>(wr), gf = ubyte<B>(wg), bf = ubyte<B>(wb);
+    const float N = FMAF(k3, bf, FMAF(k2, gf, k1 * rf));
+    const float Ct = __builtin_truncf(N * 0.0001f);
+    const float r = FMAF(-10000.f, Ct, N);
+    flag = __builtin_fabsf(__builtin_fabsf(r) - 5000.f) == 5000.f;
+    (void)odd;
+    return Ct;
+}
+template <int B>
+__device__ __forceinline__ float chroma_px_ref(uint32_t wr, uint32_t wg, uint32_t wb, bool odd)
+{
+    const double r = (double)ubyte<B>(wr), g = (double)ubyte<B>(wg), b = (double)ubyte<B>(wb);
+    return (float)(odd ? ref_cr(r, g, b) : ref_cb(r, g, b));
+}
+
+typedef __fp16 half2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t pack_h2(float a, float b)   // small integers: exact in fp16
+{
+    return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(a, b));
+}
+__device__ __forceinline__ double unpack_lo(uint32_t w) { return (double)(float)__builtin_bit_cast(half2_t, w).x; }
+__device__ __forceinline__ double unpack_hi(uint32_t w) { return (double)(float)__builtin_bit_cast(half2_t, w).y; }
+
+__device__ __forceinline__ double readlane_f64(double v, int src)   // src wave-uniform
+{
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b & 0xFFFFFFFFull), src);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), src);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+
+// Levels 2 and 3 for ONE coefficient (i, j) of one block, by the 8 lanes that hold the block's 8 rows of samples
+// (w[0..3]: this lane's 8 samples as packed fp16 pairs; part: this lane holds row y of the block; first/stride:
+// lane of row 0 and lane distance between rows -- all but w, part, y wave-uniform).  ref jpezy_encoder.hpp:146-172.
+template <int FORCE>
+__device__ __forceinline__ int resolve_coef(const uint32_t* w, bool part, int y, int first, int stride, int i, int j,
+                                            int Q, double qinv)
+{
+    double t[8];
+    {
+        const double cy = c_cos[i * 8 + y];
+        const double* cj = c_cos + j * 8;
+        // the reference's term (pic * cos[j][x]) * cos[i][y], plain multiplications
+        t[0] = unpack_lo(w[0]) * cj[0] * cy; t[1] = unpack_hi(w[0]) * cj[1] * cy;
+        t[2] = unpack_lo(w[1]) * cj[2] * cy; t[3] = unpack_hi(w[1]) * cj[3] * cy;
+        t[4] = unpack_lo(w[2]) * cj[4] * cy; t[5] = unpack_hi(w[2]) * cj[5] * cy;
+        t[6] = unpack_lo(w[3]) * cj[6] * cy; t[7] = unpack_hi(w[3]) * cj[7] * cy;
+    }
+    const double cu = j ? 1.0 : JPEZY_S, cv = i ? 1.0 : JPEZY_S;
+    if (FORCE != 1) {
+        // level 2: accurate sum in any order -- row sums, then a butterfly over the 8 participating lanes
+        double s = ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
+        s = part ? s : 0.0;
+        s += __shfl_xor(s, stride, 64);
+        s += __shfl_xor(s, stride * 2, 64);
+        s += __shfl_xor(s, stride * 4, 64);
+        const double v2 = readlane_f64(s, first) * cu * cv / 4;
+        const double mq = __builtin_rint(v2 * qinv);
+        const bool ambiguous = mq != 0.0 && __builtin_fabs(v2 - mq * (double)Q) < DELTA2;   // wave-uniform
+        if (!ambiguous) return (int)(v2 * qinv);                                              // trunc toward zero
+    }
+    // level 3: the reference's order, y outer, x inner; the running sum hops from row lane to row lane
+    double S = 0;
+#pragma unroll
+    for (int yy = 0; yy < 8; ++yy) {
+        double sl = S;
+#pragma unroll
+        for (int x = 0; x < 8; ++x) sl += t[x];
+        S = readlane_f64(sl, first + yy * stride);
+    }
+    const int dct = (int)(S * cu * cv / 4);
+    return dct / Q;
+}
+
+// quantise 8 coefficients of one block column; returns true when some coefficient needs level 2
+__device__ __forceinline__ bool quant8f(const float* F, const float* ks, bool dc_lane, double rq_dc, int* q)
+{
+    bool cand = false;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float t = F[i] * ks[i];
+        q[i] = (int)t;                                                    // v_cvt_i32_f32 truncates toward zero
+        const float d = t - __builtin_rintf(t);
+        const bool c = __builtin_fabsf(d) < DELTA1 && __builtin_fabsf(t) > 0.5f;
+        cand |= (i == 0) ? (c && !dc_lane) : c;
+    }
+    {   // DC: exact integer sum -> the reference's FP64 sequence (ref :163), exact division
+        const double iv = __builtin_trunc((double)F[0] * JPEZY_S * JPEZY_S / 4);
+        int nq = (int)((__builtin_fabs(iv) + 0.5) * rq_dc);
+        nq = iv < 0 ? -nq : nq;
+        if (dc_lane) q[0] = nq;
+    }
+    return cand;
+}
+
+__device__ __forceinline__ void quant_block_column(const float* F, const float* ks, int j, double rq_dc, bool live,
+                                                   const int* zoff, char* stage_blk, int blk, unsigned* queue, bool force)
+{
+    int q[8];
+    bool cand = quant8f(F, ks, j == 0, rq_dc, q);
+    if (force) cand = true;
+    if (cand && live) {   // rare.  Fully unrolled: a runtime index into F/ks would send both arrays to scratch
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float t = F[i] * ks[i];
+            bool f = __builtin_fabsf(t - __builtin_rintf(t)) < DELTA1 && __builtin_fabsf(t) > 0.5f && !(i == 0 && j == 0);
+            if (force) f = true;
+            if (f) {
+                const unsigned slot = atomicAdd(&queue[0], 1u);
+                if (slot < (unsigned)QUEUE_CAP)
+                    reinterpret_cast<unsigned short*>(queue + 1)[slot] = (unsigned short)((blk << 6) | (i * 8 + j));
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) *reinterpret_cast<int16_t*>(stage_blk + zoff[i]) = (int16_t)q[i];
+}
+
+template <bool GRAY, bool ALIGNED, int FORCE>
+__global__ __launch_bounds__(64 * WPB, JPEZY_F32_WAVES) void fdct_quant_f32_kernel(EncParams p)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t lds_all[WPB][WAVE_LDS_DWORDS];
+    constexpr int BPM = GRAY ? 4 : 6;
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;   // WPB waves per workgroup
+    const unsigned qidx = blockIdx.x * (unsigned)WPB + (unsigned)wave;          // quad index inside the frame
+    if (qidx >= (unsigned)(p.mcu_rows * p.quads_per_row)) return;     // wave-uniform
+    const int frame = (int)blockIdx.y;
+    const int mcu_y = (int)fast_div(qidx, p.qpr_magic, p.qpr_shift);
+    const int quad_x = (int)qidx - mcu_y * p.quads_per_row;
+
+    uint32_t* lds = lds_all[wave];
+    float* ldsf = reinterpret_cast<float*>(lds);
+    unsigned* queue = lds + TILE_BYTES / 4;                            // [0] = count, then 16-bit entries
+    if (lane == 0) queue[0] = 0;
+    const int row = lane >> 2, m = lane & 3;
+    const int mcu_x_raw = quad_x * 4 + m;
+    const bool live = mcu_x_raw < p.mcu_cols;
+    const int mcu_x = live ? mcu_x_raw : p.mcu_cols - 1;
+    const int W = p.W, H = p.H;
+    const uint8_t* pr = p.r + (size_t)frame * p.plane_stride;
+    const uint8_t* pg = p.g + (size_t)frame * p.plane_stride;
+    const uint8_t* pb = p.b + (size_t)frame * p.plane_stride;
+    const DeviceTables* tab = p.tab;
+
+    // ---- 1. this lane's 16-pixel row segment of the three planes ----
+    uint32_t R[4], G[4], B[4];
+    {
+        const int y = min(mcu_y * 16 + row, H - 1);                   // edge replication, ref :101
+        const size_t rowoff = (size_t)y * W;
+        if (ALIGNED) {
+            const size_t off = rowoff + (size_t)mcu_x * 16;
+            const uint4 vr = *reinterpret_cast<const uint4*>(pr + off);
+            const uint4 vg = *reinterpret_cast<const uint4*>(pg + off);
+            const uint4 vb = *reinterpret_cast<const uint4*>(pb + off);
+            R[0] = vr.x; R[1] = vr.y; R[2] = vr.z; R[3] = vr.w;
+            G[0] = vg.x; G[1] = vg.y; G[2] = vg.z; G[3] = vg.w;
+            B[0] = vb.x; B[1] = vb.y; B[2] = vb.z; B[3] = vb.w;
+        } else {
+#pragma unroll
+            for (int w4 = 0; w4 < 4; ++w4) {
+                uint32_t ar = 0, ag = 0, ab = 0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int x = min(mcu_x * 16 + w4 * 4 + k, W - 1);   // ref :104
+                    ar |= (uint32_t)pr[rowoff + x] << (8 * k);
+                    ag |= (uint32_t)pg[rowoff + x] << (8 * k);
+                    ab |= (uint32_t)pb[rowoff + x] << (8 * k);
+                }
+                R[w4] = ar; G[w4] = ag; B[w4] = ab;
+            }
+        }
+    }
+
+    // ---- 2. luma + row pass of the left and right block, into the transpose tile.  The integer samples stay in
+    //         registers as packed fp16 pairs (ph: luma 16, pc: chroma 8) for the rare levels 2 and 3. ----
+    uint32_t ph[8], pc[4] = { 0, 0, 0, 0 };
+    {
+        float4* dst = reinterpret_cast<float4*>(ldsf + m * Y_MCU + row * Y_PITCH);
+        float yv[8], X[8];
+        luma8(R, G, B, yv);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) ph[k] = pack_h2(yv[2 * k], yv[2 * k + 1]);
+        fdct8f(yv, X);
+        dst[0] = make_float4(X[0], X[1], X[2], X[3]);
+        dst[1] = make_float4(X[4], X[5], X[6], X[7]);
+        luma8(R + 2, G + 2, B + 2, yv);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) ph[4 + k] = pack_h2(yv[2 * k], yv[2 * k + 1]);
+        fdct8f(yv, X);
+        dst[2] = make_float4(X[0], X[1], X[2], X[3]);
+        dst[3] = make_float4(X[4], X[5], X[6], X[7]);
+    }
+    wave_sync();
+
+    // ---- 3. luma column pass ----
+    const int cq = row, j = cq & 7;
+    float Ftop[8], Fbot[8];
+    {
+        float col[16];
+        const float* src = ldsf + m * Y_MCU + cq;
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) col[rr] = src[rr * Y_PITCH];
+        fdct8f(col, Ftop);
+        fdct8f(col + 8, Fbot);
+    }
+    wave_sync();   // tile consumed; the slice is reused (chroma tile | staging)
+
+    // ---- 4. quantise + zig-zag the two luma block columns into the staging area ----
+    char* stage = reinterpret_cast<char*>(lds) + CT_BYTES;
+    int zoff[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) zoff[i] = 2 * (int)c_zzinv[i * 8 + j];
+    {
+        float ks[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ks[i] = tab->qscale_f[0][j][i];
+        const double rq = tab->rq_dc[0];
+        const int bx = cq >> 3;
+        quant_block_column(Ftop, ks, j, rq, live, zoff, stage + (m * BPM + bx) * STG_BLK, m * BPM + bx, queue, FORCE != 0);
+        quant_block_column(Fbot, ks, j, rq, live, zoff, stage + (m * BPM + 2 + bx) * STG_BLK, m * BPM + 2 + bx, queue, FORCE != 0);
+    }
+
+    // ---- 5. chroma (top-left pixel of every 2x2, ref :134-142): the odd-row lane takes its even neighbour's
+    //         pixels (DPP row_shr:4) and computes Cr, the even-row lane Cb ----
+    if (!GRAY) {
+        const bool odd = (row & 1) != 0;
+        uint32_t R2[4], G2[4], B2[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            R2[k] = (uint32_t)__builtin_amdgcn_update_dpp((int)R[k], (int)R[k], 0x114, 0xF, 0xA, false);
+            G2[k] = (uint32_t)__builtin_amdgcn_update_dpp((int)G[k], (int)G[k], 0x114, 0xF, 0xA, false);
+            B2[k] = (uint32_t)__builtin_amdgcn_update_dpp((int)B[k], (int)B[k], 0x114, 0xF, 0xA, false);
+        }
+        // 10000 * (Cb, Cr) = (-1687 R - 3313 G + 5000 B), (5000 R - 4187 G - 813 B)   (ref :249-256)
+        const float k1 = odd ? 5000.f : -1687.f, k2 = odd ? -4187.f : -3313.f, k3 = odd ? -813.f : 5000.f;
+        float cv[8], cX[8];
+        bool f[8];
+        cv[0] = chroma_px<0>(R2[0], G2[0], B2[0], k1, k2, k3, odd, f[0]);
+        cv[1] = chroma_px<2>(R2[0], G2[0], B2[0], k1, k2, k3, odd, f[1]);
+        cv[2] = chroma_px<0>(R2[1], G2[1], B2[1], k1, k2, k3, odd, f[2]);
+        cv[3] = chroma_px<2>(R2[1], G2[1], B2[1], k1, k2, k3, odd, f[3]);
+        cv[4] = chroma_px<0>(R2[2], G2[2], B2[2], k1, k2, k3, odd, f[4]);
+        cv[5] = chroma_px<2>(R2[2], G2[2], B2[2], k1, k2, k3, odd, f[5]);
+        cv[6] = chroma_px<0>(R2[3], G2[3], B2[3], k1, k2, k3, odd, f[6]);
+        cv[7] = chroma_px<2>(R2[3], G2[3], B2[3], k1, k2, k3, odd, f[7]);
+        const bool any = f[0] | f[1] | f[2] | f[3] | f[4] | f[5] | f[6] | f[7];
+        if (__any(any)) {
+            if (__any(f[0])) { if (f[0]) cv[0] = chroma_px_ref<0>(R2[0], G2[0], B2[0], odd); }
+            if (__any(f[1])) { if (f[1]) cv[1] = chroma_px_ref<2>(R2[0], G2[0], B2[0], odd); }
+            if (__any(f[2])) { if (f[2]) cv[2] = chroma_px_ref<0>(R2[1], G2[1], B2[1], odd); }
+            if (__any(f[3])) { if (f[3]) cv[3] = chroma_px_ref<2>(R2[1], G2[1], B2[1], odd); }
+            if (__any(f[4])) { if (f[4]) cv[4] = chroma_px_ref<0>(R2[2], G2[2], B2[2], odd); }
+            if (__any(f[5])) { if (f[5]) cv[5] = chroma_px_ref<2>(R2[2], G2[2], B2[2], odd); }
+            if (__any(f[6])) { if (f[6]) cv[6] = chroma_px_ref<0>(R2[3], G2[3], B2[3], odd); }
+            if (__any(f[7])) { if (f[7]) cv[7] = chroma_px_ref<2>(R2[3], G2[3], B2[3], odd); }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) pc[k] = pack_h2(cv[2 * k], cv[2 * k + 1]);
+        fdct8f(cv, cX);
+        float4* dst = reinterpret_cast<float4*>(ldsf + m * C_MCU + (odd ? C_COMP : 0) + (row >> 1) * C_PITCH);
+        dst[0] = make_float4(cX[0], cX[1], cX[2], cX[3]);
+        dst[1] = make_float4(cX[4], cX[5], cX[6], cX[7]);
+        wave_sync();
+
+        float Fc[8];
+        {
+            float col[8];
+            const float* src = ldsf + m * C_MCU + (cq >> 3) * C_COMP + j;
+#pragma unroll
+            for (int rr = 0; rr < 8; ++rr) col[rr] = src[rr * C_PITCH];
+            fdct8f(col, Fc);
+        }
+        float ks[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ks[i] = tab->qscale_f[1][j][i];
+        const int comp = 1 + (cq >> 3);
+        quant_block_column(Fc, ks, j, tab->rq_dc[1], live, zoff, stage + (m * BPM + 3 + comp) * STG_BLK, m * BPM + 3 + comp,
+                           queue, FORCE != 0);
+    }
+    wave_sync();
+
+    // ---- 5b. levels 2 and 3 for the queued coefficients (FORCE / queue overflow: every coefficient of the quad) ----
+    {
+        const unsigned nq = queue[0];
+        const bool all = FORCE != 0 || nq > (unsigned)QUEUE_CAP;
+        const unsigned total = all ? (unsigned)(4 * BPM * 64) : nq;
+        if (total) {
+            const int valid_mcus = min(4, p.mcu_cols - quad_x * 4);
+            unsigned done = 0;
+#pragma unroll 1
+            for (unsigned e = 0; e < total; ++e) {
+                const unsigned code = all ? e : reinterpret_cast<const unsigned short*>(queue + 1)[e];
+                const int blk = __builtin_amdgcn_readfirstlane((int)(code >> 6)), nat = __builtin_amdgcn_readfirstlane((int)(code & 63));
+                const int em = blk / BPM, eb = blk - em * BPM;
+                if (em >= valid_mcus) continue;
+                const int ei = nat >> 3, ej = nat & 7;
+                const int comp = eb < 4 ? 0 : eb - 3, tbl = comp ? 1 : 0;
+                // the 8 lanes that hold the block's rows: luma block (by,bx): rows by*8+y, words ph[4bx..]; chroma:
+                // Cb on even-row lanes, Cr on odd-row lanes, words pc[]
+                const int by = (eb >> 1) & 1, bx = eb & 1;
+                const int first = comp ? (comp == 2 ? 4 : 0) + em : by * 32 + em;
+                const int stride = comp ? 8 : 4;
+                const bool part = (m == em) && (comp ? ((row & 1) == (comp == 2)) : ((row >> 3) == by));
+                const int yrow = comp ? (row >> 1) : (row & 7);
+                uint32_t w[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) w[k] = comp ? pc[k] : (bx ? ph[4 + k] : ph[k]);
+                const int qv = resolve_coef<FORCE>(w, part, yrow, first, stride, ei, ej, tab->qt[tbl][nat], tab->qinv[tbl][nat]);
+                if (lane == 0) *reinterpret_cast<int16_t*>(stage + blk * STG_BLK + 2 * (int)c_zzinv[nat]) = (int16_t)qv;
+                ++done;
+            }
+            if (lane == 0 && done) atomicAdd(p.fallback_count + ((blockIdx.x * (unsigned)WPB + wave) & (COUNTER_SHARDS - 1)), (unsigned long long)done);
+            wave_sync();
+        }
+    }
+
+    // ---- 6. coalesced store of the quad's coefficients ----
+    {
+        const int valid_chunks = min(4, p.mcu_cols - quad_x * 4) * BPM * 8;         // 16-byte chunks
+        int16_t* gbase = p.coeffs + (size_t)frame * p.coeffs_per_frame +
+                         ((size_t)mcu_y * p.mcu_cols + (size_t)quad_x * 4) * (BPM * 64);
+        uint4* g4 = reinterpret_cast<uint4*>(gbase);
+#pragma unroll
+        for (int k = 0; k < BPM * 128 * 4 / 1024; ++k) {
+            const int c = k * 64 + lane;
+            if (c < valid_chunks) g4[c] = *reinterpret_cast<const uint4*>(stage + (c >> 3) * STG_BLK + (c & 7) * 16);
+        }
+    }
+}
+
+}  // namespace f32
+
+template <bool GRAY, bool ALIGNED>
+static void enc_f32_launch2(const EncParams& p, int force, dim3 grid, hipStream_t s)
+{
+    if (force == 1)
+        hipLaunchKernelGGL((f32::fdct_quant_f32_kernel<GRAY, ALIGNED, 1>), grid, dim3(64 * WPB), 0, s, p);
+    else if (force == 2)
+        hipLaunchKernelGGL((f32::fdct_quant_f32_kernel<GRAY, ALIGNED, 2>), grid, dim3(64 * WPB), 0, s, p);
+    else
+        hipLaunchKernelGGL((f32::fdct_quant_f32_kernel<GRAY, ALIGNED, 0>), grid, dim3(64 * WPB), 0, s, p);
+}
+
+hipError_t launch_fdct_quant_f32(const EncParams& p, bool gray, int force, hipStream_t stream)
+{
+    const long quads = (long)p.mcu_rows * p.quads_per_row;
+    if (quads <= 0 || p.n_frames <= 0) return hipSuccess;
+    if (p.n_frames > 65535) return hipErrorInvalidValue;               // grid.y limit; callers chunk larger batches
+    const dim3 grid((unsigned)((quads + WPB - 1) / WPB), (unsigned)p.n_frames);
+    const bool al = (p.W % 16 == 0) && (p.plane_stride % 16 == 0) &&
+                    (((uintptr_t)p.r | (uintptr_t)p.g | (uintptr_t)p.b) % 16 == 0);
+    if (gray) { if (al) enc_f32_launch2<true, true>(p, force, grid, stream); else enc_f32_launch2<true, false>(p, force, grid, stream); }
+    else      { if (al) enc_f32_launch2<false, true>(p, force, grid, stream); else enc_f32_launch2<false, false>(p, force, grid, stream); }
+    return hipGetLastError();
+}
+
+}  // namespace jpezy_dev

@@ -23,9 +23,13 @@ def J():
     return jpezy_amd
 
 
-@pytest.fixture(scope="module")
-def ctx(J):
+@pytest.fixture(scope="module", params=[0, 1], ids=["enc-f64", "enc-f32"])
+def ctx(J, request):
+    """every test runs with both encode kernel variants (0: FP64 butterflies, 1: FP32 first level + FP64 second
+    level + reference-order third level); the decode kernel is the same in both."""
     c = J.Context(0)
+    c.set_variant(request.param)
+    c.variant = request.param
     yield c
     c.close()
 
@@ -34,7 +38,7 @@ def ctx(J):
 def test_golden_fixtures(J, ctx, golden_dir, name):
     z = np.load(golden_dir / f"{name}.npz")
     W, H = int(z["W"]), int(z["H"])
-    for force in (False, True):
+    for force in (0, 1, 2):
         ctx.set_force_exact(force)
         co = ctx.fdct_quant(z["r"], z["g"], z["b"], W, H, gray=False)
         cog = ctx.fdct_quant(z["r"], z["g"], z["b"], W, H, gray=True)
@@ -83,16 +87,19 @@ def test_exact_fallback_branch_alone(J, ctx, oracle):
     r, g, b = oracle.synth_rgb(W, H, frame=99)
     want = oracle.encode_coeffs(r, g, b, W, H)
     ctx.fallback_count()
-    ctx.set_force_exact(True)
+    ctx.set_force_exact(2)                         # variant 1: every coefficient through the FP64 second level
     try:
+        got2 = ctx.fdct_quant(r, g, b, W, H)
+        n_enc2 = ctx.fallback_count()
+        ctx.set_force_exact(1)                     # every coefficient through the reference-order path
         got = ctx.fdct_quant(r, g, b, W, H)
         n_enc = ctx.fallback_count()
         dec = ctx.dequant_idct(want, W, H)
         n_dec = ctx.fallback_count()
     finally:
-        ctx.set_force_exact(False)
-    assert np.array_equal(got, want)
-    assert n_enc == want.size                      # every coefficient went through the exact path
+        ctx.set_force_exact(0)
+    assert np.array_equal(got, want) and np.array_equal(got2, want)
+    assert n_enc == want.size and n_enc2 == want.size    # every coefficient went through the exact path
     assert n_dec == W * H + 2 * (W // 2) * (H // 2) * 2   # luma samples + chroma samples (each chroma row is held by 2 lanes)
     for a, e in zip(dec, oracle.decode_planes(want, oracle.make_info(W, H))):
         assert np.array_equal(a, e)

@@ -29,7 +29,7 @@ __constant__ unsigned char c_zzinv[64] = JPEZY_ZZ_INV_INIT;
 #define K7 0x1.8f8b83c69a60bp-3f
 #define FMAF(a, b, c) __builtin_fmaf((a), (b), (c))
 #ifndef JPEZY_F32_WAVES
-#define JPEZY_F32_WAVES 5
+#define JPEZY_F32_WAVES 6
 #endif
 
 constexpr float DELTA1_DEFAULT = 0x1p-12f;  // level-1 guard band on t = v/Q (proven error bound 9e-5)
@@ -51,8 +51,8 @@ constexpr int STG_BLK = 144;                // bytes per staged block (128 + 16 
 constexpr int CT_BYTES = 4 * C_MCU * 4;     // 2176: chroma tile, then the staging area behind it
 constexpr int STG_BYTES = 4 * 6 * STG_BLK;  // 3456
 constexpr int TILE_BYTES = (4 * Y_MCU * 4 > CT_BYTES + STG_BYTES) ? 4 * Y_MCU * 4 : CT_BYTES + STG_BYTES;   // 5632
-constexpr int QUEUE_CAP = 126;
-constexpr int WAVE_LDS_DWORDS = TILE_BYTES / 4 + 64;   // 5888 B per wave: 6 waves per SIMD fit the 160 KB of a CU
+constexpr int QUEUE_CAP = 94;
+constexpr int WAVE_LDS_DWORDS = TILE_BYTES / 4 + 48;   // 5888 B per wave: 6 waves per SIMD fit the 160 KB of a CU
 
 __device__ __forceinline__ unsigned fast_div(unsigned n, unsigned magic, unsigned shift)
 {
@@ -128,6 +128,7 @@ __device__ __forceinline__ void luma8(const uint32_t* wr, const uint32_t* wg, co
     y[1] = luma_px<1>(wr[0], wg[0], wb[0], f[1]);
     y[2] = luma_px<2>(wr[0], wg[0], wb[0], f[2]);
     y[3] = luma_px<3>(wr[0], wg[0], wb[0], f[3]);
+    __builtin_amdgcn_sched_barrier(0);   // 4 pixels at a time: more in flight only costs registers
     y[4] = luma_px<0>(wr[1], wg[1], wb[1], f[4]);
     y[5] = luma_px<1>(wr[1], wg[1], wb[1], f[5]);
     y[6] = luma_px<2>(wr[1], wg[1], wb[1], f[6]);
@@ -345,38 +346,10 @@ __global__ __launch_bounds__(64 * WPB, JPEZY_F32_WAVES) void fdct_quant_f32_kern
         dst[2] = make_float4(X[0], X[1], X[2], X[3]);
         dst[3] = make_float4(X[4], X[5], X[6], X[7]);
     }
-    wave_sync();
-
-    // ---- 3. luma column pass ----
-    const int cq = row, j = cq & 7;
-    float Ftop[8], Fbot[8];
-    {
-        float col[16];
-        const float* src = ldsf + m * Y_MCU + cq;
-#pragma unroll
-        for (int rr = 0; rr < 16; ++rr) col[rr] = src[rr * Y_PITCH];
-        fdct8f(col, Ftop);
-        fdct8f(col + 8, Fbot);
-    }
-    wave_sync();   // tile consumed; the slice is reused (chroma tile | staging)
-
-    // ---- 4. quantise + zig-zag the two luma block columns into the staging area ----
-    char* stage = reinterpret_cast<char*>(lds) + CT_BYTES;
-    int zoff[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) zoff[i] = 2 * (int)c_zzinv[i * 8 + j];
-    {
-        float ks[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) ks[i] = tab->qscale_f[0][j][i];
-        const double rq = tab->rq_dc[0];
-        const int bx = cq >> 3;
-        quant_block_column(Ftop, ks, j, rq, live, zoff, stage + (m * BPM + bx) * STG_BLK, m * BPM + bx, queue, FORCE != 0);
-        quant_block_column(Fbot, ks, j, rq, live, zoff, stage + (m * BPM + 2 + bx) * STG_BLK, m * BPM + 2 + bx, queue, FORCE != 0);
-    }
-
-    // ---- 5. chroma (top-left pixel of every 2x2, ref :134-142): the odd-row lane takes its even neighbour's
-    //         pixels (DPP row_shr:4) and computes Cr, the even-row lane Cb ----
+    __builtin_amdgcn_sched_barrier(0);   // keep the phases apart: the scheduler otherwise overlaps them and needs >80 VGPRs
+    // ---- 2b. chroma samples (top-left pixel of every 2x2, ref :134-142): the odd-row lane takes its even neighbour's
+    //         pixels (DPP row_shr:4) and computes Cr, the even-row lane Cb.  Only the packed samples survive, so the
+    //         raw pixel registers die here. ----
     if (!GRAY) {
         const bool odd = (row & 1) != 0;
         uint32_t R2[4], G2[4], B2[4];
@@ -388,12 +361,13 @@ __global__ __launch_bounds__(64 * WPB, JPEZY_F32_WAVES) void fdct_quant_f32_kern
         }
         // 10000 * (Cb, Cr) = (-1687 R - 3313 G + 5000 B), (5000 R - 4187 G - 813 B)   (ref :249-256)
         const float k1 = odd ? 5000.f : -1687.f, k2 = odd ? -4187.f : -3313.f, k3 = odd ? -813.f : 5000.f;
-        float cv[8], cX[8];
+        float cv[8];
         bool f[8];
         cv[0] = chroma_px<0>(R2[0], G2[0], B2[0], k1, k2, k3, odd, f[0]);
         cv[1] = chroma_px<2>(R2[0], G2[0], B2[0], k1, k2, k3, odd, f[1]);
         cv[2] = chroma_px<0>(R2[1], G2[1], B2[1], k1, k2, k3, odd, f[2]);
         cv[3] = chroma_px<2>(R2[1], G2[1], B2[1], k1, k2, k3, odd, f[3]);
+        __builtin_amdgcn_sched_barrier(0);
         cv[4] = chroma_px<0>(R2[2], G2[2], B2[2], k1, k2, k3, odd, f[4]);
         cv[5] = chroma_px<2>(R2[2], G2[2], B2[2], k1, k2, k3, odd, f[5]);
         cv[6] = chroma_px<0>(R2[3], G2[3], B2[3], k1, k2, k3, odd, f[6]);
@@ -411,6 +385,54 @@ __global__ __launch_bounds__(64 * WPB, JPEZY_F32_WAVES) void fdct_quant_f32_kern
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) pc[k] = pack_h2(cv[2 * k], cv[2 * k + 1]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    wave_sync();
+
+    // ---- 3+4. luma column pass, quantise + zig-zag into the staging area; top block first, then the bottom block
+    //           (kept apart so that only one block column of coefficients is live at a time) ----
+    const int cq = row, j = cq & 7;
+    float col[16];
+    {
+        const float* src = ldsf + m * Y_MCU + cq;
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) col[rr] = src[rr * Y_PITCH];
+    }
+    wave_sync();   // tile consumed; the slice is reused (chroma tile | staging)
+    char* stage = reinterpret_cast<char*>(lds) + CT_BYTES;
+    int zoff[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) zoff[i] = 2 * (int)c_zzinv[i * 8 + j];
+    {
+        float ks[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ks[i] = tab->qscale_f[0][j][i];
+        const double rq = tab->rq_dc[0];
+        const int bx = cq >> 3;
+        {
+            float F[8];
+            fdct8f(col, F);
+            quant_block_column(F, ks, j, rq, live, zoff, stage + (m * BPM + bx) * STG_BLK, m * BPM + bx, queue, FORCE != 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            float F[8];
+            fdct8f(col + 8, F);
+            quant_block_column(F, ks, j, rq, live, zoff, stage + (m * BPM + 2 + bx) * STG_BLK, m * BPM + 2 + bx, queue, FORCE != 0);
+        }
+    }
+
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- 5. chroma row pass, transpose, column pass ----
+    if (!GRAY) {
+        const bool odd = (row & 1) != 0;
+        float cv[8], cX[8];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const half2_t h = __builtin_bit_cast(half2_t, pc[k]);
+            cv[2 * k] = (float)h.x;
+            cv[2 * k + 1] = (float)h.y;
+        }
         fdct8f(cv, cX);
         float4* dst = reinterpret_cast<float4*>(ldsf + m * C_MCU + (odd ? C_COMP : 0) + (row >> 1) * C_PITCH);
         dst[0] = make_float4(cX[0], cX[1], cX[2], cX[3]);

@@ -107,7 +107,7 @@ jpezy_ctx* jpezy_ctx_create(int device)
     }
     jpezy_ctx* c = new jpezy_ctx;
     c->device = device;
-    DeviceTables h;
+    static DeviceTables h;             // 33 KB: keep it off the stack
     const double S = JPEZY_INV_SQRT2;
     for (int t = 0; t < 2; ++t) {
         for (int j = 0; j < 8; ++j)
@@ -126,6 +126,12 @@ jpezy_ctx* jpezy_ctx_create(int device)
                 h.qscale_f[t][j][i] = (float)(cu * cv / (4.0 * kQt[t][i * 8 + j]));
             }
     }
+    for (int t = 0; t < 2; ++t)
+        for (int sum = -8192; sum <= 8192; ++sum) {
+            const double cu = S, cv = S;
+            const int dct = (int)((double)sum * cu * cv / 4);          // int(sum * cu * cv / 4), no contraction (build flag)
+            h.dcq[t][sum + 8192] = (signed char)(dct / kQt[t][0]);
+        }
     bool ok = hipSetDevice(device) == hipSuccess;
     ok = ok && hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
     ok = ok && hipMalloc((void**)&c->d_tab, sizeof(DeviceTables)) == hipSuccess;

@@ -21,6 +21,10 @@ struct DeviceTables {
     // f32 first-level kernel: qscale_f[t][j][i] = cu(j) * cv(i) / (4 * Q_t[i*8+j]) ; qinv[t][k] = 1.0 / Q_t[k]
     float qscale_f[2][8][8];
     double qinv[2][64];
+    // quantised DC as a function of the block's integer sample sum S in [-8192, 8192] (index S + 8192):
+    // dcq[t][.] = int(((S * s) * s) / 4) / Q_t[0] with s = 1/sqrt(2), evaluated on the host in the reference's
+    // exact FP64 order (ref encoder/jpezy_encoder.hpp:163,171)
+    signed char dcq[2][16385];
 };
 
 // The exact-path counter is sharded over COUNTER_SHARDS words: thousands of waves adding to ONE word serialise

@@ -29,7 +29,7 @@ __constant__ unsigned char c_zzinv[64] = JPEZY_ZZ_INV_INIT;
 #define K7 0x1.8f8b83c69a60bp-3f
 #define FMAF(a, b, c) __builtin_fmaf((a), (b), (c))
 #ifndef JPEZY_F32_WAVES
-#define JPEZY_F32_WAVES 6
+#define JPEZY_F32_WAVES 5
 #endif
 
 constexpr float DELTA1_DEFAULT = 0x1p-12f;  // level-1 guard band on t = v/Q (proven error bound 9e-5)
@@ -227,9 +227,13 @@ __device__ __forceinline__ int resolve_coef(const uint32_t* w, bool part, int y,
     return dct / Q;
 }
 
-// quantise 8 coefficients of one block column; returns true when some coefficient needs level 2
-__device__ __forceinline__ bool quant8f(const float* F, const float* ks, bool dc_lane, double rq_dc, int* q)
+// quantise 8 coefficients of one block column; returns true when some coefficient needs level 2.
+// dcq: this table's DC lookup (exact, see DeviceTables::dcq) -- F[0] of the j == 0 lane is the block's integer sum.
+__device__ __forceinline__ bool quant8f(const float* F, const float* ks, bool dc_lane, const signed char* dcq, int* q)
 {
+    // issue the DC lookup first: its latency hides behind the other seven coefficients
+    const int si = min(max((int)F[0], -8192), 8192) + 8192;            // clamp: non-DC lanes carry arbitrary values
+    const int dc = dcq[si];
     bool cand = false;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -239,20 +243,17 @@ __device__ __forceinline__ bool quant8f(const float* F, const float* ks, bool dc
         const bool c = __builtin_fabsf(d) < DELTA1 && __builtin_fabsf(t) > 0.5f;
         cand |= (i == 0) ? (c && !dc_lane) : c;
     }
-    {   // DC: exact integer sum -> the reference's FP64 sequence (ref :163), exact division
-        const double iv = __builtin_trunc((double)F[0] * JPEZY_S * JPEZY_S / 4);
-        int nq = (int)((__builtin_fabs(iv) + 0.5) * rq_dc);
-        nq = iv < 0 ? -nq : nq;
-        if (dc_lane) q[0] = nq;
-    }
+    if (dc_lane) q[0] = dc;
     return cand;
 }
 
-__device__ __forceinline__ void quant_block_column(const float* F, const float* ks, int j, double rq_dc, bool live,
-                                                   const int* zoff, char* stage_blk, int blk, unsigned* queue, bool force)
+// addr[i]: LDS byte address of natural coefficient (i, j) inside this lane's FIRST block; blk_off: byte offset of the
+// block to write (an immediate after inlining)
+__device__ __forceinline__ void quant_block_column(const float* F, const float* ks, int j, const signed char* dcq, bool live,
+                                                   char* const* addr, int blk_off, int blk, unsigned* queue, bool force)
 {
     int q[8];
-    bool cand = quant8f(F, ks, j == 0, rq_dc, q);
+    bool cand = quant8f(F, ks, j == 0, dcq, q);
     if (force) cand = true;
     if (cand && live) {   // rare.  Fully unrolled: a runtime index into F/ks would send both arrays to scratch
 #pragma unroll
@@ -268,7 +269,7 @@ __device__ __forceinline__ void quant_block_column(const float* F, const float* 
         }
     }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) *reinterpret_cast<int16_t*>(stage_blk + zoff[i]) = (int16_t)q[i];
+    for (int i = 0; i < 8; ++i) *reinterpret_cast<int16_t*>(addr[i] + blk_off) = (int16_t)q[i];
 }
 
 template <bool GRAY, bool ALIGNED, int FORCE>
@@ -400,25 +401,24 @@ __global__ __launch_bounds__(64 * WPB, JPEZY_F32_WAVES) void fdct_quant_f32_kern
     }
     wave_sync();   // tile consumed; the slice is reused (chroma tile | staging)
     char* stage = reinterpret_cast<char*>(lds) + CT_BYTES;
-    int zoff[8];
+    const int bx = cq >> 3;
+    char* addr[8];   // this lane's 8 zig-zag slots in its first block (m, bx); the other blocks are immediates away
 #pragma unroll
-    for (int i = 0; i < 8; ++i) zoff[i] = 2 * (int)c_zzinv[i * 8 + j];
+    for (int i = 0; i < 8; ++i) addr[i] = stage + (m * BPM + bx) * STG_BLK + 2 * (int)c_zzinv[i * 8 + j];
     {
         float ks[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) ks[i] = tab->qscale_f[0][j][i];
-        const double rq = tab->rq_dc[0];
-        const int bx = cq >> 3;
         {
             float F[8];
             fdct8f(col, F);
-            quant_block_column(F, ks, j, rq, live, zoff, stage + (m * BPM + bx) * STG_BLK, m * BPM + bx, queue, FORCE != 0);
+            quant_block_column(F, ks, j, tab->dcq[0], live, addr, 0, m * BPM + bx, queue, FORCE != 0);
         }
         __builtin_amdgcn_sched_barrier(0);
         {
             float F[8];
             fdct8f(col + 8, F);
-            quant_block_column(F, ks, j, rq, live, zoff, stage + (m * BPM + 2 + bx) * STG_BLK, m * BPM + 2 + bx, queue, FORCE != 0);
+            quant_block_column(F, ks, j, tab->dcq[0], live, addr, 2 * STG_BLK, m * BPM + 2 + bx, queue, FORCE != 0);
         }
     }
 
@@ -450,9 +450,7 @@ __global__ __launch_bounds__(64 * WPB, JPEZY_F32_WAVES) void fdct_quant_f32_kern
         float ks[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) ks[i] = tab->qscale_f[1][j][i];
-        const int comp = 1 + (cq >> 3);
-        quant_block_column(Fc, ks, j, tab->rq_dc[1], live, zoff, stage + (m * BPM + 3 + comp) * STG_BLK, m * BPM + 3 + comp,
-                           queue, FORCE != 0);
+        quant_block_column(Fc, ks, j, tab->dcq[1], live, addr, 4 * STG_BLK, m * BPM + 4 + bx, queue, FORCE != 0);
     }
     wave_sync();
 

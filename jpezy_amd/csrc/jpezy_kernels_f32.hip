@@ -32,12 +32,7 @@ __constant__ unsigned char c_zzinv[64] = JPEZY_ZZ_INV_INIT;
 #define JPEZY_F32_WAVES 5
 #endif
 
-constexpr float DELTA1_DEFAULT = 0x1p-12f;  // level-1 guard band on t = v/Q (proven error bound 9e-5)
-#ifdef JPEZY_DEBUG_NO_LEVEL2
-constexpr float DELTA1 = 0.f;               // timing experiment only: wrong results
-#else
-constexpr float DELTA1 = DELTA1_DEFAULT;
-#endif
+constexpr float DELTA1 = 0x1p-12f;          // level-1 guard band on t = v/Q (proven error bound 9e-5)
 constexpr double DELTA2 = 1e-6;             // level-2 guard band on v (FP64 tree-sum error < 1e-9)
 
 // LDS geometry in dwords (floats).  Column reads are ds_read_b32 over 32-lane groups (32 banks): conflict free

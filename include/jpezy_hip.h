@@ -120,6 +120,14 @@ long jpezy_ctx_last_fallback_count(jpezy_ctx* ctx);
 long jpezy_write_jpeg(const int16_t* coeffs, int W, int H, int gray, const char* comment, uint8_t* out,
                       size_t cap);
 size_t jpezy_jpeg_bound(int W, int H);   /* a cap that always suffices */
+/*
+ * The same serial tail for a batch of independent frames, spread over `threads` host threads (0 = all cores):
+ * frame f reads coeffs + f*jpezy_coeff_count(W,H,gray) and writes at most `cap` bytes at out + f*cap; sizes[f]
+ * receives the bytes written or a negative status.  Returns 0 if every frame succeeded.  Frames are independent
+ * (pre_DC and the bit cursor are per file, encoder/jpezy_encoder.hpp:180-181), so this is plain host parallelism.
+ */
+int jpezy_write_jpeg_batch(const int16_t* coeffs, int W, int H, int gray, int n_frames, const char* comment,
+                           uint8_t* out, size_t cap, long* sizes, int threads);
 
 typedef struct jpezy_frame_info {
     int width, height, ncomp, precision;

@@ -20,9 +20,10 @@ from .api import (  # noqa: F401
     mcu_grid,
     read_jpeg,
     write_jpeg,
+    write_jpeg_batch,
 )
 
 __all__ = [
     "Context", "Decoder", "Encoder", "FrameInfo", "JpezyError", "coeff_count", "library_path",
-    "load_library", "mcu_grid", "read_jpeg", "write_jpeg",
+    "load_library", "mcu_grid", "read_jpeg", "write_jpeg", "write_jpeg_batch",
 ]

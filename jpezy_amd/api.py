@@ -56,6 +56,7 @@ ABI = [
     ("jpezy_ctx_last_fallback_count", C.c_long, [_vp]),
     ("jpezy_write_jpeg", C.c_long, [_vp, C.c_int, C.c_int, C.c_int, C.c_char_p, _vp, C.c_size_t]),
     ("jpezy_jpeg_bound", C.c_size_t, [C.c_int, C.c_int]),
+    ("jpezy_write_jpeg_batch", C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, _vp, C.c_size_t, C.POINTER(C.c_long), C.c_int]),
     ("jpezy_read_jpeg", C.c_int, [_vp, C.c_size_t, C.POINTER(FrameInfo), _vp, C.c_size_t]),
 ]
 
@@ -210,6 +211,21 @@ def write_jpeg(coeffs, W, H, gray=False, comment=None):
     buf = np.empty(cap, dtype=np.uint8)
     n = _check(lib.jpezy_write_jpeg(_np_ptr(coeffs), W, H, int(gray), comment, _np_ptr(buf), cap))
     return buf[:n].tobytes()
+
+
+def write_jpeg_batch(coeffs, W, H, n_frames, gray=False, comment=None, threads=0):
+    """n_frames independent frames through the host Huffman/JFIF tail on `threads` host threads; returns a list of bytes."""
+    lib = load_library()
+    coeffs = np.ascontiguousarray(coeffs, dtype=np.int16)
+    if coeffs.size != lib.jpezy_coeff_count(W, H, int(gray)) * n_frames:
+        raise JpezyError("coefficient buffer size does not match W, H, gray, n_frames")
+    if comment is None:
+        comment = b"Encoded by JPEZY" if gray else b"Encoded by jpezy"
+    cap = lib.jpezy_jpeg_bound(W, H)
+    buf = np.empty(cap * n_frames, dtype=np.uint8)
+    sizes = (C.c_long * n_frames)()
+    _check(lib.jpezy_write_jpeg_batch(_np_ptr(coeffs), W, H, int(gray), n_frames, comment, _np_ptr(buf), cap, sizes, threads))
+    return [buf[f * cap: f * cap + sizes[f]].tobytes() for f in range(n_frames)]
 
 
 def read_jpeg(data):

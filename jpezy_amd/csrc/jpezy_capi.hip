@@ -6,7 +6,10 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <atomic>
 #include <string>
+#include <thread>
+#include <vector>
 
 #include "../../include/jpezy_constants.h"
 #include "../../include/jpezy_hip.h"
@@ -350,6 +353,30 @@ long jpezy_write_jpeg(const int16_t* coeffs, int W, int H, int gray, const char*
 }
 
 size_t jpezy_jpeg_bound(int W, int H) { return jpezy_host::jpeg_bound(W, H); }
+
+int jpezy_write_jpeg_batch(const int16_t* coeffs, int W, int H, int gray, int n_frames, const char* comment, uint8_t* out,
+                           size_t cap, long* sizes, int threads)
+{
+    if (!coeffs || !out || !sizes || n_frames <= 0) return set_err(JPEZY_E_BADARG, "write_jpeg_batch: bad argument");
+    const size_t cpf = jpezy_coeff_count(W, H, gray);
+    if (!cpf) return set_err(JPEZY_E_BADARG, "write_jpeg_batch: bad dimensions");
+    unsigned nt = threads > 0 ? (unsigned)threads : std::thread::hardware_concurrency();
+    if (nt == 0) nt = 1;
+    if (nt > (unsigned)n_frames) nt = (unsigned)n_frames;
+    std::atomic<int> next{ 0 };
+    std::atomic<int> failed{ 0 };
+    auto work = [&]() {
+        for (int f = next.fetch_add(1); f < n_frames; f = next.fetch_add(1)) {
+            sizes[f] = jpezy_host::write_jpeg(coeffs + (size_t)f * cpf, W, H, gray != 0, comment, out + (size_t)f * cap, cap, nullptr);
+            if (sizes[f] < 0) failed.store(1);
+        }
+    };
+    std::vector<std::thread> pool;
+    for (unsigned t = 1; t < nt; ++t) pool.emplace_back(work);
+    work();
+    for (auto& t : pool) t.join();
+    return failed.load() ? set_err(JPEZY_E_FORMAT, "write_jpeg_batch: at least one frame failed (see sizes[])") : JPEZY_OK;
+}
 
 int jpezy_read_jpeg(const uint8_t* data, size_t len, jpezy_frame_info* info, int16_t* coeffs, size_t coeff_cap)
 {

@@ -162,3 +162,17 @@ def test_malformed_streams_fail_cleanly(golden_dir):
     for bad in [b"", b"\x00" * 64, jpg[:100], jpg[:700], jpg[:2] + b"\xff\xd9", jpg.replace(b"\xff\xc0", b"\xff\xc2", 1)]:
         with pytest.raises(J.JpezyError):
             J.read_jpeg(bad)
+
+
+def test_write_jpeg_batch_is_threaded_and_byte_identical(oracle):
+    import time
+    W, H, F = 160, 112, 12
+    co = np.stack([oracle.encode_coeffs(*oracle.synth_rgb(W, H, frame=f), W, H) for f in range(F)])
+    want = [oracle.write_jpeg(co[f], W, H) for f in range(F)]
+    for threads in (1, 4, 0):
+        got = J.write_jpeg_batch(co, W, H, F, threads=threads)
+        assert got == want
+    bad = co.copy()
+    bad[3, 0, 0, 0, 5] = 2000          # outside K.5: that frame fails, the call reports it
+    with pytest.raises(J.JpezyError):
+        J.write_jpeg_batch(bad, W, H, F)

@@ -71,6 +71,7 @@ struct jpezy_ctx {
     double* d_dqscale = nullptr;   // [3][8][8]
     int* d_dqt = nullptr;          // [3][64]
     uint16_t dq_cache[3][64];
+    int coef_limit = 0;
     bool dq_valid = false;
     int force_exact = 0;           // 0 normal, 1 everything through the reference-order path, 2 (f32 variant) through level 2
     int variant = 1;               // encode kernel: 0 = FP64 butterflies, 1 = FP32 first level (default: faster)
@@ -285,6 +286,10 @@ static int upload_dequant(jpezy_ctx* c, const uint16_t qt[4][64], const uint8_t 
     HIP_TRY(hipMemcpy(c->d_dqscale, h_scale, sizeof h_scale, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(c->d_dqt, h_qt, sizeof h_qt, hipMemcpyHostToDevice));
     std::memcpy(c->dq_cache, sel, sizeof sel);
+    int qmax = 1;
+    for (int k = 0; k < 3; ++k)
+        for (int i = 0; i < 64; ++i) qmax = sel[k][i] > qmax ? sel[k][i] : qmax;
+    c->coef_limit = 32768 / qmax;
     c->dq_valid = true;
     return JPEZY_OK;
 }
@@ -306,6 +311,7 @@ int jpezy_dequant_idct_dev(jpezy_ctx* c, const int16_t* d_coeffs, const uint16_t
     p.plane_stride = plane_stride;
     p.dqscale = c->d_dqscale;
     p.dqt = c->d_dqt;
+    p.coef_limit = c->coef_limit;
     p.fallback_count = c->d_counter;
     p.W = W; p.H = H;
     p.mcu_cols = jpezy_mcu_cols(W);

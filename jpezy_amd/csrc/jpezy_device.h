@@ -58,6 +58,7 @@ struct DecParams {
     size_t plane_stride;
     const double* dqscale;    // [3 comps][8 (u=lane col)][8 (v)] : cu*cv*Q[v*8+u]   (dequant folded in)
     const int* dqt;           // [3 comps][64] natural order quant values (exact path)
+    int coef_limit;           // 32768 / largest quantiser: raw coefficients above it send the wave to the exact path
     unsigned long long* fallback_count;
     int W, H, mcu_cols, mcu_rows, quads_per_row, n_frames;
 };

@@ -437,9 +437,10 @@ __device__ __forceinline__ int sample_fx(double sum, bool& flag)
 {
     constexpr int MASK = (1 << SFRAC_BITS) - 1;
     const double t = FMA(sum, (double)(1 << (SFRAC_BITS - 2)), (double)(128 << SFRAC_BITS));   // (sum/4+128)*2^18
-    const bool wild = !(__builtin_fabs(t) < (double)(1 << 30));
+    // v_cvt_i32_f64 saturates (and maps NaN to 0): an out-of-range sample yields INT_MAX / INT_MIN / 0, all of which
+    // satisfy the boundary test below, so wild values take the exact path without a separate range check
     const int n = (int)t;
-    flag = wild || ((unsigned)((n + 1) & MASK) <= 2u);
+    flag = (unsigned)((n + 1) & MASK) <= 2u;
     return (n + ((n >> 31) & MASK)) >> SFRAC_BITS;
 }
 
@@ -493,7 +494,7 @@ __global__ __launch_bounds__(64 * WPB) void dequant_idct_kernel(DecParams p)
     const int cq = row, u = cq & 7;
     const int16_t* stage = reinterpret_cast<const int16_t*>(lds);
     double gtop[8], gbot[8], gc[8];
-    float amax = 0.f;
+    int cmx = 0, cmn = 0;               // largest / smallest raw coefficient this lane touches
     {
         double dq[8], in[8];
         unsigned char zp[8];
@@ -506,24 +507,27 @@ __global__ __launch_bounds__(64 * WPB) void dequant_idct_kernel(DecParams p)
         const int16_t* bt = stage + (m * BPM + bx) * 64;
         const int16_t* bb = stage + (m * BPM + 2 + bx) * 64;
 #pragma unroll
-        for (int v = 0; v < 8; ++v) { in[v] = (double)bt[zp[v]] * dq[v]; amax = fmaxf(amax, fabsf((float)in[v])); }
+        for (int v = 0; v < 8; ++v) { const int c = bt[zp[v]]; in[v] = (double)c * dq[v]; cmx = max(cmx, c); cmn = min(cmn, c); }
         idct8(in, gtop);
 #pragma unroll
-        for (int v = 0; v < 8; ++v) { in[v] = (double)bb[zp[v]] * dq[v]; amax = fmaxf(amax, fabsf((float)in[v])); }
+        for (int v = 0; v < 8; ++v) { const int c = bb[zp[v]]; in[v] = (double)c * dq[v]; cmx = max(cmx, c); cmn = min(cmn, c); }
         idct8(in, gbot);
         if (!GRAY) {
             const int comp = 1 + (cq >> 3);
             const int16_t* bc = stage + (m * BPM + 3 + comp) * 64;
 #pragma unroll
             for (int v = 0; v < 8; ++v) {
-                in[v] = (double)bc[zp[v]] * p.dqscale[(comp * 8 + u) * 8 + v];
-                amax = fmaxf(amax, fabsf((float)in[v]));
+                const int c = bc[zp[v]];
+                in[v] = (double)c * p.dqscale[(comp * 8 + u) * 8 + v];
+                cmx = max(cmx, c);
+                cmn = min(cmn, c);
             }
             idct8(in, gc);
         }
     }
-    // fast path is only trusted for sane magnitudes (error bound); wave-uniform decision
-    const bool force = FORCE_EXACT || __any(amax > 32768.f);
+    // fast path is only trusted for sane magnitudes: |coef| <= coef_limit = 32768 / max quantiser keeps every
+    // dequantised input below 2^15 (error bound); wave-uniform decision
+    const bool force = FORCE_EXACT || __any(max(cmx, -cmn) > p.coef_limit);
     wave_sync();   // staging consumed (the exact path re-reads coefficients from global memory)
 
     // ---- 3. transpose: luma tile [y 0..15][x-col 0..15]; chroma tiles after it is consumed ----

@@ -56,6 +56,14 @@ constexpr int TILE_DWORDS = 4 * Y_MCU;      // 2368 dwords = 9472 B: transpose t
 constexpr int QUEUE_CAP = 126;
 constexpr int WAVE_LDS_DWORDS = TILE_DWORDS + 64;   // 9728 B per wave, 38912 B per workgroup (4 per CU)
 
+// Decode kernel LDS slice (dwords): the luma tile is exchanged in two halves (left blocks, then right blocks) so that
+// the slice is 5.4 KB instead of 9.5 KB and LDS no longer caps the kernel at 4 waves per SIMD.
+constexpr int DH_PITCH = 20;                  // 8 doubles + 2 pad
+constexpr int DH_MCU = 16 * DH_PITCH + 16;    // 336
+constexpr int DEC_TILE_DWORDS = 4 * DH_MCU;   // 1344 dwords = 5376 B (== the chroma tile: 4 * C_MCU)
+constexpr int DEC_LDS_DWORDS = DEC_TILE_DWORDS + 16;
+static_assert(4 * C_MCU <= DEC_TILE_DWORDS && 768 <= DEC_TILE_DWORDS && 1024 + 128 <= DEC_TILE_DWORDS, "decode slice too small");
+
 __device__ __forceinline__ void wave_sync()
 {
     // LDS traffic of one wave is executed in order; this only stops the compiler from moving LDS
@@ -451,9 +459,9 @@ __device__ __forceinline__ uint32_t clamp_byte(double v)   // revise_value, ref 
 }
 
 template <bool GRAY, bool ALIGNED, bool FORCE_EXACT>
-__global__ __launch_bounds__(64 * WPB) void dequant_idct_kernel(DecParams p)
+__global__ __launch_bounds__(64 * WPB, 5) void dequant_idct_kernel(DecParams p)
 {
-    __shared__ __attribute__((aligned(16))) uint32_t lds_all[WPB][WAVE_LDS_DWORDS];
+    __shared__ __attribute__((aligned(16))) uint32_t lds_all[WPB][DEC_LDS_DWORDS];
     constexpr int BPM = 6;
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;   // WPB waves per workgroup
@@ -466,7 +474,7 @@ __global__ __launch_bounds__(64 * WPB) void dequant_idct_kernel(DecParams p)
     const int quad_x = qrem - mcu_y * p.quads_per_row;
 
     uint32_t* lds = lds_all[wave];
-    if (lane == 0) lds[TILE_DWORDS] = 0;                        // guard-band queue count
+    if (lane == 0) lds[DEC_TILE_DWORDS] = 0;                    // exact-path block mask
     const int row = lane >> 2, m = lane & 3;
     const int mcu_x = quad_x * 4 + m;
     const bool live = mcu_x < p.mcu_cols;
@@ -530,37 +538,40 @@ __global__ __launch_bounds__(64 * WPB) void dequant_idct_kernel(DecParams p)
     const bool force = FORCE_EXACT || __any(max(cmx, -cmn) > p.coef_limit);
     wave_sync();   // staging consumed (the exact path re-reads coefficients from global memory)
 
-    // ---- 3. transpose: luma tile [y 0..15][x-col 0..15]; chroma tiles after it is consumed ----
-    {
-        uint32_t* dst = lds + m * Y_MCU + cq * 2;
-#pragma unroll
-        for (int y = 0; y < 8; ++y) {
-            *reinterpret_cast<double*>(dst + y * Y_PITCH) = gtop[y];
-            *reinterpret_cast<double*>(dst + (8 + y) * Y_PITCH) = gbot[y];
-        }
-    }
-    wave_sync();
+    // ---- 3. transpose in two halves: the lanes holding the LEFT block columns (cq < 8) publish them, every lane
+    //         runs the row pass of its 8 left pixels; then the same for the right blocks ----
     int Y[16];
     unsigned yflags = 0;
-    {
-        double in[16], out[16];
-        const double2* src = reinterpret_cast<const double2*>(lds + m * Y_MCU + row * Y_PITCH);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) { const double2 t = src[k]; in[2 * k] = t.x; in[2 * k + 1] = t.y; }
-        idct8(in, out);
-        idct8(in + 8, out + 8);
+    for (int half = 0; half < 2; ++half) {
+        if ((cq >> 3) == half) {
+            uint32_t* dst = lds + m * DH_MCU + u * 2;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            bool f;
-            Y[k] = sample_fx(out[k], f);
-            yflags |= (f ? 1u : 0u) << k;
+            for (int y = 0; y < 8; ++y) {
+                *reinterpret_cast<double*>(dst + y * DH_PITCH) = gtop[y];
+                *reinterpret_cast<double*>(dst + (8 + y) * DH_PITCH) = gbot[y];
+            }
         }
+        wave_sync();
+        {
+            double in[8], out[8];
+            const double2* src = reinterpret_cast<const double2*>(lds + m * DH_MCU + row * DH_PITCH);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const double2 t = src[k]; in[2 * k] = t.x; in[2 * k + 1] = t.y; }
+            idct8(in, out);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                bool f;
+                Y[half * 8 + k] = sample_fx(out[k], f);
+                yflags |= (f ? 1u : 0u) << (half * 8 + k);
+            }
+        }
+        wave_sync();   // the half tile was read; it is rewritten next
     }
     if (force) yflags = 0xFFFFu;
     int Cb[8], Cr[8];
     unsigned cflags = 0;
     if (!GRAY) {
-        wave_sync();
         {
             uint32_t* dst = lds + m * C_MCU + (cq >> 3) * C_COMP + u * 2;
 #pragma unroll
@@ -590,17 +601,16 @@ __global__ __launch_bounds__(64 * WPB) void dequant_idct_kernel(DecParams p)
     }
     if (!live) { yflags = 0; cflags = 0; }
 
-    // ---- 4. exact path for flagged samples.  Lanes OR the blocks they need into a mask; for each such block
-    //         the wave builds the list of its non-zero dequantised coefficients (in the reference's summation
-    //         order), then every lane re-evaluates its own flagged samples of that block in exact order and
-    //         leaves them in a patch table [lane][k] (k: 0-15 luma, 16-23 Cb, 24-31 Cr) it reads back.
-    //         Cost grows with the number of non-zero coefficients: DC-only blocks (every sample sits on an
+    // ---- 4. exact path for flagged samples.  Lanes OR the blocks they need into a mask; for each such block the
+    //         wave builds the list of its non-zero dequantised coefficients (in the reference's summation order),
+    //         then every lane re-evaluates its own flagged samples of that block in exact order and leaves them in
+    //         a patch table [lane][16] it reads back.  Two rounds -- luma blocks, then chroma blocks -- share the
+    //         table.  Cost grows with the number of non-zero coefficients: DC-only blocks (every sample sits on an
     //         integer) cost one term per sample. ----
     {
-        unsigned* need_blocks = lds + TILE_DWORDS;                 // zeroed at kernel start
-        int* patch = reinterpret_cast<int*>(lds);                  // tiles are dead by now: 64 x 32 x 4 B = 8 KB
-        int2* list = reinterpret_cast<int2*>(lds + 2048);          // 64 entries x 8 B behind the patch table
-        static_assert(2048 + 128 <= TILE_DWORDS, "patch table + list do not fit the tile area");
+        unsigned* need_blocks = lds + DEC_TILE_DWORDS;             // zeroed at kernel start
+        int* patch = reinterpret_cast<int*>(lds);                  // tiles are dead by now: 64 x 16 x 4 B = 4 KB
+        int2* list = reinterpret_cast<int2*>(lds + 1024);          // 64 entries x 8 B behind the patch table
         const unsigned myflags = force ? (GRAY ? 0xFFFFu : 0xFFFFFFFFu) : (yflags | (cflags << 16));
         const int by = row >> 3;
         unsigned myblocks = 0;
@@ -613,49 +623,57 @@ __global__ __launch_bounds__(64 * WPB) void dequant_idct_kernel(DecParams p)
         wave_sync();                                               // all tile reads are done
         if (myblocks) atomicOr(need_blocks, myblocks);
         wave_sync();
-        unsigned todo = __builtin_amdgcn_readfirstlane((int)need_blocks[0]);
-        if (todo) {
+        const unsigned all_todo = __builtin_amdgcn_readfirstlane((int)need_blocks[0]);
+        if (all_todo) {
+            constexpr unsigned LUMA_BLOCKS = 0x0F | (0x0F << 6) | (0x0F << 12) | (0x0F << 18);   // blocks 0-3 of the 4 MCUs
             unsigned done = 0;
 #pragma unroll 1
-            while (todo) {
-                const int blk = __builtin_ctz(todo);
-                todo &= todo - 1;
-                const int em = blk / BPM, eb = blk - em * BPM;
-                const int comp = eb < 4 ? 0 : eb - 3;
-                // build the non-zero list: lane k looks at natural index k
-                const int16_t* gblk = gbase + (size_t)blk * 64;
-                const int d = (int)gblk[c_zzinv[lane]] * p.dqt[comp * 64 + lane];      // inverse_quantization :645-650
-                const unsigned long long nzmask = __ballot(d != 0);
-                const int K = __builtin_popcountll(nzmask);
-                if (d != 0) list[__builtin_popcountll(nzmask & ((1ull << lane) - 1ull))] = make_int2(lane, d);
-                wave_sync();
-                if (m == em && ((myblocks >> blk) & 1u)) {
-                    // my flagged samples inside this block: 8 consecutive k
-                    const int k0 = eb < 4 ? (eb & 1) * 8 : 16 + (eb - 4) * 8;
-                    const int yy = eb < 4 ? (row & 7) : (row >> 1);
+            for (int round = 0; round < 2; ++round) {
+                unsigned todo = all_todo & (round ? ~LUMA_BLOCKS : LUMA_BLOCKS);
+                if (!todo) continue;
 #pragma unroll 1
-                    for (int k = k0; k < k0 + 8; ++k) {
-                        if ((myflags >> k) & 1u) {
-                            patch[lane * 32 + k] = exact_idct_sample_sparse(list, K, k & 7, yy);
-                            ++done;
+                while (todo) {
+                    const int blk = __builtin_ctz(todo);
+                    todo &= todo - 1;
+                    const int em = blk / BPM, eb = blk - em * BPM;
+                    const int comp = eb < 4 ? 0 : eb - 3;
+                    // build the non-zero list: lane k looks at natural index k
+                    const int16_t* gblk = gbase + (size_t)blk * 64;
+                    const int d = (int)gblk[c_zzinv[lane]] * p.dqt[comp * 64 + lane];      // inverse_quantization :645-650
+                    const unsigned long long nzmask = __ballot(d != 0);
+                    const int K = __builtin_popcountll(nzmask);
+                    if (d != 0) list[__builtin_popcountll(nzmask & ((1ull << lane) - 1ull))] = make_int2(lane, d);
+                    wave_sync();
+                    if (m == em && ((myblocks >> blk) & 1u)) {
+                        // my flagged samples inside this block: 8 consecutive k (bits of myflags), 8 consecutive patch slots
+                        const int k0 = eb < 4 ? (eb & 1) * 8 : 16 + (eb - 4) * 8;
+                        const int yy = eb < 4 ? (row & 7) : (row >> 1);
+#pragma unroll 1
+                        for (int k = k0; k < k0 + 8; ++k) {
+                            if ((myflags >> k) & 1u) {
+                                patch[lane * 16 + (k & 15)] = exact_idct_sample_sparse(list, K, k & 7, yy);
+                                ++done;
+                            }
+                        }
+                    }
+                    wave_sync();
+                }
+                if (myflags && live) {
+                    if (round == 0) {
+#pragma unroll
+                        for (int k = 0; k < 16; ++k)
+                            if ((myflags >> k) & 1u) Y[k] = patch[lane * 16 + k];
+                    } else if (!GRAY) {
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) {
+                            if ((myflags >> (16 + k)) & 1u) Cb[k] = patch[lane * 16 + k];
+                            if ((myflags >> (24 + k)) & 1u) Cr[k] = patch[lane * 16 + 8 + k];
                         }
                     }
                 }
                 wave_sync();
             }
             if (done) atomicAdd(p.fallback_count + ((blockIdx.x * (unsigned)WPB + wave) & (COUNTER_SHARDS - 1)), (unsigned long long)done);
-            if (myflags && live) {
-#pragma unroll
-                for (int k = 0; k < 16; ++k)
-                    if ((myflags >> k) & 1u) Y[k] = patch[lane * 32 + k];
-                if (!GRAY) {
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        if ((myflags >> (16 + k)) & 1u) Cb[k] = patch[lane * 32 + 16 + k];
-                        if ((myflags >> (24 + k)) & 1u) Cr[k] = patch[lane * 32 + 24 + k];
-                    }
-                }
-            }
         }
     }
 

@@ -498,11 +498,17 @@ __global__ __launch_bounds__(64 * WPB, 5) void dequant_idct_kernel(DecParams p)
     }
     wave_sync();
 
-    // ---- 2. column pass (over v) for column u = cq&7 of two luma blocks and one chroma block ----
+    // ---- 2. column pass (over v) for column u = cq&7 of two luma blocks and one chroma block.
+    //         The DC term is dequantised in the reference's own order, ((cu*cv) * (coef*Q)), so that a block whose
+    //         AC coefficients are all zero (flat / DC-only blocks: the common case in real images, where EVERY
+    //         sample sits exactly on an integer) comes out of the fast path bit-identical to the reference: its only
+    //         non-zero term passes through the butterflies and the transposes unchanged.  Such blocks are found
+    //         with three ballots and their samples are exempt from the guard band below. ----
     const int cq = row, u = cq & 7;
     const int16_t* stage = reinterpret_cast<const int16_t*>(lds);
     double gtop[8], gbot[8], gc[8];
     int cmx = 0, cmn = 0;               // largest / smallest raw coefficient this lane touches
+    unsigned long long ac_top, ac_bot, ac_chr = 0;   // lanes whose block column holds a non-zero AC coefficient
     {
         double dq[8], in[8];
         unsigned char zp[8];
@@ -511,28 +517,45 @@ __global__ __launch_bounds__(64 * WPB, 5) void dequant_idct_kernel(DecParams p)
             dq[v] = p.dqscale[(0 * 8 + u) * 8 + v];
             zp[v] = c_zzinv[v * 8 + u];
         }
+        const double cucv_dc = JPEZY_S * JPEZY_S;                  // the reference's cu * cv for (0,0): 0.4999999999999999
         const int bx = cq >> 3;
         const int16_t* bt = stage + (m * BPM + bx) * 64;
         const int16_t* bb = stage + (m * BPM + 2 + bx) * 64;
+        int c[8], acor;
 #pragma unroll
-        for (int v = 0; v < 8; ++v) { const int c = bt[zp[v]]; in[v] = (double)c * dq[v]; cmx = max(cmx, c); cmn = min(cmn, c); }
+        for (int v = 0; v < 8; ++v) { c[v] = bt[zp[v]]; in[v] = (double)c[v] * dq[v]; cmx = max(cmx, c[v]); cmn = min(cmn, c[v]); }
+        if (u == 0) in[0] = cucv_dc * (double)(c[0] * p.dqt[0]);
+        acor = (u ? c[0] : 0) | c[1] | c[2] | c[3] | c[4] | c[5] | c[6] | c[7];
+        ac_top = __ballot(acor != 0);
         idct8(in, gtop);
 #pragma unroll
-        for (int v = 0; v < 8; ++v) { const int c = bb[zp[v]]; in[v] = (double)c * dq[v]; cmx = max(cmx, c); cmn = min(cmn, c); }
+        for (int v = 0; v < 8; ++v) { c[v] = bb[zp[v]]; in[v] = (double)c[v] * dq[v]; cmx = max(cmx, c[v]); cmn = min(cmn, c[v]); }
+        if (u == 0) in[0] = cucv_dc * (double)(c[0] * p.dqt[0]);
+        acor = (u ? c[0] : 0) | c[1] | c[2] | c[3] | c[4] | c[5] | c[6] | c[7];
+        ac_bot = __ballot(acor != 0);
         idct8(in, gbot);
         if (!GRAY) {
             const int comp = 1 + (cq >> 3);
             const int16_t* bc = stage + (m * BPM + 3 + comp) * 64;
 #pragma unroll
             for (int v = 0; v < 8; ++v) {
-                const int c = bc[zp[v]];
-                in[v] = (double)c * p.dqscale[(comp * 8 + u) * 8 + v];
-                cmx = max(cmx, c);
-                cmn = min(cmn, c);
+                c[v] = bc[zp[v]];
+                in[v] = (double)c[v] * p.dqscale[(comp * 8 + u) * 8 + v];
+                cmx = max(cmx, c[v]);
+                cmn = min(cmn, c[v]);
             }
+            if (u == 0) in[0] = cucv_dc * (double)(c[0] * p.dqt[comp * 64]);
+            acor = (u ? c[0] : 0) | c[1] | c[2] | c[3] | c[4] | c[5] | c[6] | c[7];
+            ac_chr = __ballot(acor != 0);
             idct8(in, gc);
         }
     }
+    // The block columns of block (m, side) sit in lanes (8*side + k)*4 + m, k = 0..7: bits 0x11111111 << m of the low
+    // (side 0: left luma blocks / Cb) or high (side 1: right luma blocks / Cr) half of a ballot.
+    const unsigned colbits = 0x11111111u << m;
+    const unsigned long long ac_luma = (row >> 3) ? ac_bot : ac_top;                 // this lane's pixel row: top or bottom blocks
+    const bool dc_only_l = ((unsigned)ac_luma & colbits) == 0, dc_only_r = ((unsigned)(ac_luma >> 32) & colbits) == 0;
+    const bool dc_only_cb = ((unsigned)ac_chr & colbits) == 0, dc_only_cr = ((unsigned)(ac_chr >> 32) & colbits) == 0;
     // fast path is only trusted for sane magnitudes: |coef| <= coef_limit = 32768 / max quantiser keeps every
     // dequantised input below 2^15 (error bound); wave-uniform decision
     const bool force = FORCE_EXACT || __any(max(cmx, -cmn) > p.coef_limit);
@@ -568,6 +591,7 @@ __global__ __launch_bounds__(64 * WPB, 5) void dequant_idct_kernel(DecParams p)
         }
         wave_sync();   // the half tile was read; it is rewritten next
     }
+    yflags &= ~((dc_only_l ? 0x00FFu : 0u) | (dc_only_r ? 0xFF00u : 0u));   // exact by construction, see step 2
     if (force) yflags = 0xFFFFu;
     int Cb[8], Cr[8];
     unsigned cflags = 0;
@@ -597,6 +621,7 @@ __global__ __launch_bounds__(64 * WPB, 5) void dequant_idct_kernel(DecParams p)
             Cr[k] = sample_fx(out[8 + k], f);
             cflags |= (f ? 1u : 0u) << (8 + k);
         }
+        cflags &= ~((dc_only_cb ? 0x00FFu : 0u) | (dc_only_cr ? 0xFF00u : 0u));
         if (force) cflags = 0xFFFFu;
     }
     if (!live) { yflags = 0; cflags = 0; }

@@ -98,6 +98,18 @@ int jpezy_dequant_idct_dev(jpezy_ctx* ctx, const int16_t* d_coeffs, const uint16
                            const uint8_t comp_tq[3], size_t plane_stride, int W, int H, int gray,
                            int n_frames, uint8_t* d_r, uint8_t* d_g, uint8_t* d_b, void* stream);
 
+/*
+ * DECODE compute stage for ANY baseline layout the reference's decode_mcu handles (decoder/jpezy_decoder.hpp:504-565):
+ * 1 or 3 components, sampling factors 1..2 per direction, any table selectors.  coeffs as jpezy_read_jpeg delivers them
+ * ([mcu][component blocks, ky outer, kx inner][64], zig-zag).  This is the reference's own arithmetic executed one
+ * sample per lane (the 64-term sum in its exact order) followed by the replication upsample and make_rgb -- correct for
+ * every layout, an order of magnitude slower than jpezy_dequant_idct, which handles jpezy_encode's own 2x2,1x1,1x1 files.
+ * With ncomp == 1 the missing chroma planes read 0x80 as in the reference (:104-105).
+ */
+int jpezy_dequant_idct_generic(jpezy_ctx* ctx, const int16_t* coeffs, const uint16_t qt[4][64], int ncomp,
+                               const uint8_t comp_h[3], const uint8_t comp_v[3], const uint8_t comp_tq[3], int W, int H,
+                               int gray, uint8_t* r, uint8_t* g, uint8_t* b);
+
 /* Test hook: route EVERY coefficient / sample through the kernels' exact-order fallback (the path a
  * guard-band hit takes).  0 = normal, 1 = reference-order path, 2 = (encode variant 1 only) the FP64 second
  * level, which may still defer to the reference-order path.  Exists so the rare branches have parity tests. */

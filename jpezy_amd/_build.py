@@ -19,7 +19,8 @@ HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 COMMON = ["-std=c++17", "-O3", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
 DEVICE = ["--offload-arch=gfx950"]
 
-LIB_SOURCES = [CSRC / "jpezy_kernels.hip", CSRC / "jpezy_kernels_f32.hip", CSRC / "jpezy_capi.hip",
+LIB_SOURCES = [CSRC / "jpezy_kernels.hip", CSRC / "jpezy_kernels_f32.hip", CSRC / "jpezy_kernels_generic.hip",
+               CSRC / "jpezy_capi.hip",
                CSRC / "jpezy_host_codec.cpp"]
 LIB_DEPS = LIB_SOURCES + [CSRC / "jpezy_device.h", CSRC / "jpezy_host_codec.h",
                           ROOT / "include" / "jpezy_hip.h", ROOT / "include" / "jpezy_constants.h"]

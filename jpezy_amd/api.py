@@ -51,6 +51,7 @@ ABI = [
     ("jpezy_fdct_quant_dev", C.c_int, [_vp, _vp, _vp, _vp, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp]),
     ("jpezy_dequant_idct", C.c_int, [_vp, _vp, _QT, _TQ, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp]),
     ("jpezy_dequant_idct_dev", C.c_int, [_vp, _vp, _QT, _TQ, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp]),
+    ("jpezy_dequant_idct_generic", C.c_int, [_vp, _vp, _QT, C.c_int, _TQ, _TQ, _TQ, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp]),
     ("jpezy_ctx_set_force_exact", None, [_vp, C.c_int]),
     ("jpezy_ctx_set_variant", C.c_int, [_vp, C.c_int]),
     ("jpezy_ctx_last_fallback_count", C.c_long, [_vp]),
@@ -176,6 +177,19 @@ class Context:
                                                  n_frames, _np_ptr(planes[0]), _np_ptr(planes[1]), _np_ptr(planes[2])))
         return planes
 
+    def dequant_idct_generic(self, coeffs, info, gray=False):
+        """any baseline layout (1/3 components, sampling 1..2): info is the FrameInfo of read_jpeg"""
+        coeffs = np.ascontiguousarray(coeffs, dtype=np.int16)
+        W, H = info.width, info.height
+        hs = (C.c_uint8 * 3)(*[max(1, info.H[i]) for i in range(3)])
+        vs = (C.c_uint8 * 3)(*[max(1, info.V[i]) for i in range(3)])
+        tq = (C.c_uint8 * 3)(*[info.Tq[i] for i in range(3)])
+        planes = [np.empty(W * H, dtype=np.uint8) for _ in range(3)]
+        _check(load_library().jpezy_dequant_idct_generic(self._h, _np_ptr(coeffs), C.byref(info.qt), info.ncomp, C.byref(hs),
+                                                         C.byref(vs), C.byref(tq), W, H, int(gray), _np_ptr(planes[0]),
+                                                         _np_ptr(planes[1]), _np_ptr(planes[2])))
+        return planes
+
     # ---- device-pointer entry points (torch tensors on this context's device) ----
     def fdct_quant_dev(self, d_r, d_g, d_b, W, H, d_coeffs, gray=False, n_frames=1, plane_stride=None, stream=None):
         import torch
@@ -294,8 +308,8 @@ class Decoder:
             return None
         self.pr = info
         layout = [(info.H[i], info.V[i]) for i in range(info.ncomp)]
-        if info.ncomp != 3 or layout != [(2, 2), (1, 1), (1, 1)] or info.precision != 8:
-            raise JpezyError("decode layout other than 2x2,1x1,1x1 is not on the GPU path yet (JPEZY_E_UNSUPPORTED)")
         ctx = self.ctx or default_context()
+        if info.ncomp != 3 or layout != [(2, 2), (1, 1), (1, 1)] or info.precision != 8:
+            return ctx.dequant_idct_generic(coeffs, info, gray=gray)      # any other baseline layout: generic kernels
         tq = tuple(info.Tq[i] for i in range(3))
         return ctx.dequant_idct(coeffs, info.width, info.height, qt=info.qt, comp_tq=tq, gray=gray)

@@ -63,10 +63,6 @@ struct decoder {
 
         const bool own_layout = info.ncomp == 3 && info.precision == 8 && info.H[0] == 2 && info.V[0] == 2 && info.H[1] == 1 &&
                                 info.V[1] == 1 && info.H[2] == 1 && info.V[2] == 1;
-        if (!own_layout) {   // the GPU path covers jpezy_encode's own layout; other samplings are a listed gap
-            std::cerr << "decode_mcu(): sampling layout other than 2x2,1x1,1x1 is not supported by the MI355X path" << std::endl;
-            return {};
-        }
         const std::size_t ncoef = static_cast<std::size_t>(info.mcu_cols) * info.mcu_rows * info.blocks_per_mcu * 64;
         std::vector<std::int16_t> coeffs(ncoef);
         if (jpezy_read_jpeg(file.data(), file.size(), &info, coeffs.data(), coeffs.size()) != JPEZY_OK) {
@@ -75,14 +71,24 @@ struct decoder {
         }
         // the reference sizes its planes to the padded MCU grid (:94-101); the first W*H entries are the image
         const std::size_t W = info.width, H = info.height;
-        const std::size_t rgb_s = static_cast<std::size_t>(info.mcu_rows) * 16 * static_cast<std::size_t>(info.mcu_cols) * 16;
+        const std::size_t rgb_s = static_cast<std::size_t>(info.mcu_rows) * info.vmax * 8 * static_cast<std::size_t>(info.mcu_cols) * info.hmax * 8;
         std::array<std::vector<byte>, 3> rgb;
         for (auto& v : rgb) v.resize(rgb_s);
         const std::uint8_t tq[3] = { static_cast<std::uint8_t>(info.Tq[0]), static_cast<std::uint8_t>(info.Tq[1]), static_cast<std::uint8_t>(info.Tq[2]) };
         jpezy_ctx* ctx = detail::device_context();
-        if (jpezy_dequant_idct(ctx, coeffs.data(), info.qt, tq, static_cast<int>(W), static_cast<int>(H), gray, 1,
-                               reinterpret_cast<std::uint8_t*>(rgb[0].data()), reinterpret_cast<std::uint8_t*>(rgb[1].data()),
-                               reinterpret_cast<std::uint8_t*>(rgb[2].data())) != JPEZY_OK) {
+        int rc;
+        if (own_layout) {   // jpezy_encode's own layout: the fused kernel
+            rc = jpezy_dequant_idct(ctx, coeffs.data(), info.qt, tq, static_cast<int>(W), static_cast<int>(H), gray, 1,
+                                    reinterpret_cast<std::uint8_t*>(rgb[0].data()), reinterpret_cast<std::uint8_t*>(rgb[1].data()),
+                                    reinterpret_cast<std::uint8_t*>(rgb[2].data()));
+        } else {            // any other baseline layout decode_mcu handles (:504-528): the generic kernels
+            const std::uint8_t hs[3] = { static_cast<std::uint8_t>(info.H[0]), static_cast<std::uint8_t>(info.H[1]), static_cast<std::uint8_t>(info.H[2]) };
+            const std::uint8_t vs[3] = { static_cast<std::uint8_t>(info.V[0]), static_cast<std::uint8_t>(info.V[1]), static_cast<std::uint8_t>(info.V[2]) };
+            rc = jpezy_dequant_idct_generic(ctx, coeffs.data(), info.qt, info.ncomp, hs, vs, tq, static_cast<int>(W), static_cast<int>(H), gray,
+                                            reinterpret_cast<std::uint8_t*>(rgb[0].data()), reinterpret_cast<std::uint8_t*>(rgb[1].data()),
+                                            reinterpret_cast<std::uint8_t*>(rgb[2].data()));
+        }
+        if (rc != JPEZY_OK) {
             std::cerr << "make_rgb(): throw exception from " << jpezy_hip_last_error() << std::endl;
             return {};
         }

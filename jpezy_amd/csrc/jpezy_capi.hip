@@ -75,7 +75,7 @@ struct jpezy_ctx {
     bool dq_valid = false;
     int force_exact = 0;           // 0 normal, 1 everything through the reference-order path, 2 (f32 variant) through level 2
     int variant = 1;               // encode kernel: 0 = FP64 butterflies, 1 = FP32 first level (default: faster)
-    DevBuf in[3], out;             // staging for the host-buffer entry points
+    DevBuf in[3], out, scratch;    // staging for the host-buffer entry points; scratch: samples of the generic decoder
 };
 
 extern "C" {
@@ -163,6 +163,7 @@ void jpezy_ctx_destroy(jpezy_ctx* c)
     if (c->d_dqt) (void)hipFree(c->d_dqt);
     for (auto& b : c->in) b.release();
     c->out.release();
+    c->scratch.release();
     delete c;
 }
 
@@ -346,6 +347,55 @@ int jpezy_dequant_idct(jpezy_ctx* c, const int16_t* coeffs, const uint16_t qt[4]
             HIP_TRY(hipMemcpy2DAsync(dst[k], plane, c->in[k].p, stride, plane, (size_t)n_frames, hipMemcpyDeviceToHost, c->stream));
         }
     }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return JPEZY_OK;
+}
+
+int jpezy_dequant_idct_generic(jpezy_ctx* c, const int16_t* coeffs, const uint16_t qt[4][64], int ncomp, const uint8_t comp_h[3],
+                               const uint8_t comp_v[3], const uint8_t comp_tq[3], int W, int H, int gray, uint8_t* r, uint8_t* g,
+                               uint8_t* b)
+{
+    if (int rc = check_dims(c, W, H, 1)) return rc;
+    if (!coeffs || !qt || !comp_h || !comp_v || !comp_tq || !r || !g || !b) return set_err(JPEZY_E_BADARG, "null pointer");
+    if (ncomp != 1 && ncomp != 3) return set_err(JPEZY_E_UNSUPPORTED, "dimension not supported (the reference accepts 1 or 3)");
+    GenericDecParams p;
+    p.W = W; p.H = H; p.ncomp = ncomp; p.gray = gray != 0;
+    p.hmax = p.vmax = 0;
+    p.blocks_per_mcu = 0;
+    for (int k = 0; k < 3; ++k) { p.ch[k] = p.cv[k] = 1; p.blk_start[k] = 1 << 20; }
+    for (int k = 0; k < ncomp; ++k) {
+        p.ch[k] = comp_h[k]; p.cv[k] = comp_v[k];
+        if (p.ch[k] < 1 || p.ch[k] > 2 || p.cv[k] < 1 || p.cv[k] > 2)
+            return set_err(JPEZY_E_UNSUPPORTED, "sampling factors outside 1..2");
+        p.hmax = p.ch[k] > p.hmax ? p.ch[k] : p.hmax;
+        p.vmax = p.cv[k] > p.vmax ? p.cv[k] : p.vmax;
+        p.blk_start[k] = p.blocks_per_mcu;
+        p.blocks_per_mcu += p.ch[k] * p.cv[k];
+    }
+    const int Hblock = (W >> 3) + ((W & 7) > 0), Vblock = (H >> 3) + ((H & 7) > 0);   // get_blocks, ref :166-169
+    p.mcu_cols = Hblock / p.hmax + ((Hblock % p.hmax) ? 1 : 0);
+    p.mcu_rows = Vblock / p.vmax + ((Vblock % p.vmax) ? 1 : 0);
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t nblk = (size_t)p.mcu_cols * p.mcu_rows * p.blocks_per_mcu;
+    const size_t plane = (size_t)W * H;
+    if (int rc = c->out.reserve(nblk * 64 * sizeof(int16_t))) return rc;
+    if (int rc = c->scratch.reserve(nblk * 64 * sizeof(int) + 3 * 64 * sizeof(int))) return rc;
+    for (int k = 0; k < 3; ++k)
+        if (int rc = c->in[k].reserve(plane)) return rc;
+    int h_qt[3][64];
+    for (int k = 0; k < 3; ++k)
+        for (int i = 0; i < 64; ++i) h_qt[k][i] = qt[(k < ncomp ? comp_tq[k] : 0) & 3][i];
+    int* d_qt = (int*)((char*)c->scratch.p + nblk * 64 * sizeof(int));
+    HIP_TRY(hipMemcpyAsync(d_qt, h_qt, sizeof h_qt, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->out.p, coeffs, nblk * 64 * sizeof(int16_t), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));                  // h_qt lives on this stack frame
+    p.coeffs = (const int16_t*)c->out.p;
+    p.samples = (int*)c->scratch.p;
+    p.qt = d_qt;
+    p.r = (uint8_t*)c->in[0].p; p.g = (uint8_t*)c->in[1].p; p.b = (uint8_t*)c->in[2].p;
+    HIP_TRY(launch_dequant_idct_generic(p, c->stream));
+    uint8_t* dst[3] = { r, g, b };
+    for (int k = 0; k < 3; ++k) HIP_TRY(hipMemcpyAsync(dst[k], c->in[k].p, plane, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return JPEZY_OK;
 }

@@ -80,4 +80,18 @@ hipError_t launch_fdct_quant(const EncParams& p, bool gray, bool force_exact, hi
 hipError_t launch_fdct_quant_f32(const EncParams& p, bool gray, int force, hipStream_t stream);
 hipError_t launch_dequant_idct(const DecParams& p, bool gray, bool force_exact, hipStream_t stream);
 
+// any-layout decode (jpezy_kernels_generic.hip)
+struct GenericDecParams {
+    const int16_t* coeffs;
+    int* samples;             // [block][64] natural order, scratch
+    const int* qt;            // [3 comps][64] natural order
+    uint8_t* r;
+    uint8_t* g;
+    uint8_t* b;
+    int W, H, ncomp, gray;
+    int ch[3], cv[3], hmax, vmax, mcu_cols, mcu_rows, blocks_per_mcu;
+    int blk_start[3];         // first block of each component inside an MCU
+};
+hipError_t launch_dequant_idct_generic(const GenericDecParams& p, hipStream_t stream);
+
 }  // namespace jpezy_dev

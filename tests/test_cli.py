@@ -120,12 +120,22 @@ def test_cli_roundtrip_is_byte_exact(cli, oracle, tmp_path, size):
 
 
 @pytest.mark.gpu
-def test_cli_rejects_foreign_sampling(cli, tmp_path):
-    """4:4:4 files parse, but their layout is outside the GPU decode kernel: decode failed, exit 1 (listed gap)."""
+@pytest.mark.parametrize("kind", ["444", "422", "gray1"])
+def test_cli_decodes_foreign_layouts(cli, oracle, tmp_path, kind):
+    """files jpezy_encode never writes (4:4:4, 4:2:2, one component) decode through the generic kernels, like the
+    reference's general decode_mcu loop does on the CPU -- compared with the oracle byte for byte"""
     from PIL import Image
     _, dec = cli
-    rng = np.random.default_rng(1)
+    rng = np.random.default_rng(4)
+    img = rng.integers(0, 256, (45, 70, 3), dtype=np.uint8)
     p = tmp_path / "x.jpg"
-    Image.fromarray(rng.integers(0, 256, (32, 32, 3), dtype=np.uint8)).save(p, "JPEG", subsampling=0)
-    r = _run(dec, p, tmp_path / "x.ppm")
-    assert r.returncode == 1 and "decode failed" in r.stderr
+    if kind == "gray1":
+        Image.fromarray(img[..., 0]).save(p, "JPEG", quality=80)
+    else:
+        Image.fromarray(img).save(p, "JPEG", quality=80, subsampling=0 if kind == "444" else 1)
+    for dgray in (False, True):
+        out = tmp_path / "x.ppm"
+        r = _run(dec, p, out, *(["--gray"] if dgray else []))
+        assert r.returncode == 0, r.stderr
+        info, dr, dg, db = oracle.decode_jpeg(p.read_bytes(), gray=dgray)
+        assert out.read_bytes() == oracle.format_ppm_p3(70, 45, dr, dg, db)

@@ -46,8 +46,8 @@ constexpr int STG_BLK = 144;                // bytes per staged block (128 + 16 
 constexpr int CT_BYTES = 4 * C_MCU * 4;     // 2176: chroma tile, then the staging area behind it
 constexpr int STG_BYTES = 4 * 6 * STG_BLK;  // 3456
 constexpr int TILE_BYTES = (4 * Y_MCU * 4 > CT_BYTES + STG_BYTES) ? 4 * Y_MCU * 4 : CT_BYTES + STG_BYTES;   // 5632
-constexpr int QUEUE_CAP = 94;
-constexpr int WAVE_LDS_DWORDS = TILE_BYTES / 4 + 48;   // 5888 B per wave: 6 waves per SIMD fit the 160 KB of a CU
+constexpr int QUEUE_CAP = 510;              // entries; beyond it every coefficient of the quad is resolved (pathological input)
+constexpr int WAVE_LDS_DWORDS = TILE_BYTES / 4 + 256;   // + count word + 510 16-bit entries: 6656 B, 6 waves/SIMD fit in 160 KB
 
 __device__ __forceinline__ unsigned fast_div(unsigned n, unsigned magic, unsigned shift)
 {

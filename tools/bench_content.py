@@ -22,6 +22,10 @@ def images(W, H):
     yield "flat", [np.full((H, W), v, np.uint8) for v in (200, 100, 50)]
     cb = (((xx.astype(np.int32) // 4) + (yy.astype(np.int32) // 4)) % 2 * 215 + 20).astype(np.uint8)
     yield "checker4", [cb, cb, cb]
+    two = (rng.integers(0, 2, (H, W)) * 255).astype(np.uint8)
+    yield "2-level noise", [two, np.roll(two, 1), two[::-1].copy()]
+    four = (rng.integers(0, 4, (H, W)) * 64 + 31).astype(np.uint8)
+    yield "4-level noise", [four, four, four]
 
 
 def timeit(fn, n=20):

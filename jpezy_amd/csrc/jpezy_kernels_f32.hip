@@ -1,8 +1,8 @@
 // jpezy_kernels_f32.hip -- encode kernel, variant 1: three precision levels, same bits as the reference.
 //
 // Level 1 (every coefficient): colour conversion in exact FP32 integer arithmetic, separable 8-point butterflies in
-//   FP32.  A quantised coefficient t = F*cu*cv/(4Q) is accepted when it is further than DELTA1 = 2^-12 from every
-//   non-zero integer; the proven worst-case FP32 error of t is 9e-5 (DESIGN.md "exactness, f32 variant").
+//   FP32.  A quantised coefficient t = F*cu*cv/(4Q) is accepted when it is further than DELTA1 (luma 2^-13, chroma
+//   2^-14) from every non-zero integer; the worst-case FP32 error of t is 8.6e-5 / 5.3e-5 (DESIGN.md "exactness").
 // Level 2 (guard-band hits, ~0.5 per quad): the whole wave recomputes that one coefficient in FP64 from the pixels
 //   (lane k = term k, tree sum); accepted when further than 1e-6 from every boundary m*Q, m != 0.
 // Level 3 (true boundary cases, ~0.2 per quad): the 64 terms are added in the reference's exact order.
@@ -32,7 +32,12 @@ __constant__ unsigned char c_zzinv[64] = JPEZY_ZZ_INV_INIT;
 #define JPEZY_F32_WAVES 5
 #endif
 
-constexpr float DELTA1 = 0x1p-12f;          // level-1 guard band on t = v/Q (proven error bound 9e-5)
+// Level-1 guard bands on t = v/Q.  Norm-wise bound of the FP32 error of F[i][j]: gamma_13 * sum|cos_i| * sum|cos_j| * 128
+// (at most 13 roundings on any input->output path, u = 2^-24), times the coefficient's scale factor cu*cv/(4Q), plus
+// the rounding of the product: at most 8.6e-5 (luma) / 5.3e-5 (chroma) over the Annex-K tables.
+// tests/test_f32_error_bound.py recomputes these bounds and measures 7.0e-6 / 3.2e-6 on adversarial blocks.
+constexpr float DELTA1_LUMA = 0x1p-13f;     // 1.22e-4
+constexpr float DELTA1_CHROMA = 0x1p-14f;   // 6.1e-5
 constexpr double DELTA2 = 1e-6;             // level-2 guard band on v (FP64 tree-sum error < 1e-9)
 
 // LDS geometry in dwords (floats).  Column reads are ds_read_b32 over 32-lane groups (32 banks): conflict free
@@ -224,6 +229,7 @@ __device__ __forceinline__ int resolve_coef(const uint32_t* w, bool part, int y,
 
 // quantise 8 coefficients of one block column; returns true when some coefficient needs level 2.
 // dcq: this table's DC lookup (exact, see DeviceTables::dcq) -- F[0] of the j == 0 lane is the block's integer sum.
+template <bool CHROMA>
 __device__ __forceinline__ bool quant8f(const float* F, const float* ks, bool dc_lane, const signed char* dcq, int* q)
 {
     // issue the DC lookup first: its latency hides behind the other seven coefficients
@@ -235,7 +241,7 @@ __device__ __forceinline__ bool quant8f(const float* F, const float* ks, bool dc
         const float t = F[i] * ks[i];
         q[i] = (int)t;                                                    // v_cvt_i32_f32 truncates toward zero
         const float d = t - __builtin_rintf(t);
-        const bool c = __builtin_fabsf(d) < DELTA1 && __builtin_fabsf(t) > 0.5f;
+        const bool c = __builtin_fabsf(d) < (CHROMA ? DELTA1_CHROMA : DELTA1_LUMA) && __builtin_fabsf(t) > 0.5f;
         cand |= (i == 0) ? (c && !dc_lane) : c;
     }
     if (dc_lane) q[0] = dc;
@@ -244,17 +250,19 @@ __device__ __forceinline__ bool quant8f(const float* F, const float* ks, bool dc
 
 // addr[i]: LDS byte address of natural coefficient (i, j) inside this lane's FIRST block; blk_off: byte offset of the
 // block to write (an immediate after inlining)
+template <bool CHROMA>
 __device__ __forceinline__ void quant_block_column(const float* F, const float* ks, int j, const signed char* dcq, bool live,
                                                    char* const* addr, int blk_off, int blk, unsigned* queue, bool force)
 {
     int q[8];
-    bool cand = quant8f(F, ks, j == 0, dcq, q);
+    bool cand = quant8f<CHROMA>(F, ks, j == 0, dcq, q);
     if (force) cand = true;
     if (cand && live) {   // rare.  Fully unrolled: a runtime index into F/ks would send both arrays to scratch
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const float t = F[i] * ks[i];
-            bool f = __builtin_fabsf(t - __builtin_rintf(t)) < DELTA1 && __builtin_fabsf(t) > 0.5f && !(i == 0 && j == 0);
+            bool f = __builtin_fabsf(t - __builtin_rintf(t)) < (CHROMA ? DELTA1_CHROMA : DELTA1_LUMA) && __builtin_fabsf(t) > 0.5f &&
+                     !(i == 0 && j == 0);
             if (force) f = true;
             if (f) {
                 const unsigned slot = atomicAdd(&queue[0], 1u);
@@ -407,13 +415,13 @@ __global__ __launch_bounds__(64 * WPB, JPEZY_F32_WAVES) void fdct_quant_f32_kern
         {
             float F[8];
             fdct8f(col, F);
-            quant_block_column(F, ks, j, tab->dcq[0], live, addr, 0, m * BPM + bx, queue, FORCE != 0);
+            quant_block_column<false>(F, ks, j, tab->dcq[0], live, addr, 0, m * BPM + bx, queue, FORCE != 0);
         }
         __builtin_amdgcn_sched_barrier(0);
         {
             float F[8];
             fdct8f(col + 8, F);
-            quant_block_column(F, ks, j, tab->dcq[0], live, addr, 2 * STG_BLK, m * BPM + 2 + bx, queue, FORCE != 0);
+            quant_block_column<false>(F, ks, j, tab->dcq[0], live, addr, 2 * STG_BLK, m * BPM + 2 + bx, queue, FORCE != 0);
         }
     }
 
@@ -445,7 +453,7 @@ __global__ __launch_bounds__(64 * WPB, JPEZY_F32_WAVES) void fdct_quant_f32_kern
         float ks[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) ks[i] = tab->qscale_f[1][j][i];
-        quant_block_column(Fc, ks, j, tab->dcq[1], live, addr, 4 * STG_BLK, m * BPM + 4 + bx, queue, FORCE != 0);
+        quant_block_column<true>(Fc, ks, j, tab->dcq[1], live, addr, 4 * STG_BLK, m * BPM + 4 + bx, queue, FORCE != 0);
     }
     wave_sync();
 

@@ -1,0 +1,89 @@
+"""The FP32 first level of encode kernel variant 1 accepts a quantised coefficient t = F*cu*cv/(4Q) only when it is
+further than DELTA1 (luma 2^-13, chroma 2^-14) from every non-zero integer.  DESIGN.md derives a worst-case FP32 error of
+8.6e-5 / 5.3e-5 for t;
+this test emulates the kernel's exact FP32 instruction sequence (same butterflies, same FMA placement) in numpy and
+measures the error against a float64 evaluation on adversarial blocks (extreme amplitudes, every basis-function sign
+pattern, checkerboards) and random blocks -- the measured maximum must stay far inside the guard band."""
+import numpy as np
+
+f32 = np.float32
+
+
+def fma(a, b, c):
+    # float32 fused multiply-add: the product of two float32 is exact in float64
+    return (a.astype(np.float64) * np.float64(b) + c.astype(np.float64)).astype(f32)
+
+
+def cosk(k):
+    return np.float32(np.cos(k * np.pi / 16))
+
+
+K1, K2, K3, K4, K5, K6, K7 = (cosk(k) for k in range(1, 8))
+
+
+def fdct8f(x):
+    """x: [..., 8] float32 -> [..., 8]; mirrors f32::fdct8f of jpezy_kernels_f32.hip instruction by instruction"""
+    x = x.astype(f32)
+    s0, s1, s2, s3 = x[..., 0] + x[..., 7], x[..., 1] + x[..., 6], x[..., 2] + x[..., 5], x[..., 3] + x[..., 4]
+    d0, d1, d2, d3 = x[..., 0] - x[..., 7], x[..., 1] - x[..., 6], x[..., 2] - x[..., 5], x[..., 3] - x[..., 4]
+    e0, e1, e2, e3 = s0 + s3, s1 + s2, s0 - s3, s1 - s2
+    X = [None] * 8
+    X[0] = e0 + e1
+    X[4] = (e0 - e1) * K4
+    X[2] = fma(e3, K6, e2 * K2)
+    X[6] = fma(-e3, K2, e2 * K6)
+    X[1] = fma(d3, K7, fma(d2, K5, fma(d1, K3, d0 * K1)))
+    X[3] = fma(-d3, K5, fma(-d2, K1, fma(-d1, K7, d0 * K3)))
+    X[5] = fma(d3, K3, fma(d2, K7, fma(-d1, K1, d0 * K5)))
+    X[7] = fma(-d3, K1, fma(d2, K3, fma(-d1, K5, d0 * K7)))
+    return np.stack(X, axis=-1).astype(f32)
+
+
+def blocks():
+    rng = np.random.default_rng(0)
+    out = [rng.integers(-128, 128, (4000, 8, 8))]
+    out.append(rng.choice([-128, 127], (4000, 8, 8)))                       # extreme amplitudes
+    # sign pattern of every 2-D basis function at full amplitude: maximises |F[i][j]|
+    c = np.array([[np.cos((2 * x + 1) * u * np.pi / 16) for x in range(8)] for u in range(8)])
+    basis = []
+    for i in range(8):
+        for j in range(8):
+            sgn = np.sign(np.outer(c[i], c[j]))
+            basis.append(np.where(sgn >= 0, 127, -128))
+            basis.append(np.where(sgn >= 0, -128, 127))
+    out.append(np.array(basis))
+    yy, xx = np.mgrid[0:8, 0:8]
+    out.append(np.array([np.where((xx // k + yy // k) % 2 == 0, 127, -128) for k in (1, 2, 4)]))
+    out.append(np.full((2, 8, 8), 127) * np.array([1, -1])[:, None, None] - np.array([0, 1])[:, None, None])
+    return np.concatenate(out).astype(np.int64)
+
+
+def test_level1_error_is_far_inside_the_guard_band(oracle):
+    c = oracle.constants()
+    pic = blocks()
+    rows = fdct8f(pic.astype(f32))                       # row pass: along x (last axis) -> [blk][y][j]
+    F = fdct8f(np.swapaxes(rows, 1, 2))                  # column pass along y            -> [blk][j][i]
+    F = np.swapaxes(F, 1, 2)                             # [blk][i][j]
+    cos = c["cos"].reshape(8, 8)
+    exact = np.einsum("iy,byx,jx->bij", cos, pic.astype(np.float64), cos)
+    S = c["inv_sqrt2"]
+    cu = np.where(np.arange(8) == 0, S, 1.0)
+    # norm-wise bound of the FP32 transform, per coefficient: gamma_13 * sum_y|cos_i| * sum_x|cos_j| * 128  (at most 13
+    # roundings on any input->output path, u = 2^-24), plus the rounding of the product t = F * ks (|t| <= 103)
+    gamma = 13 * 2.0 ** -24
+    absum = np.abs(cos).sum(axis=1)
+    bound_F = gamma * np.outer(absum, absum) * 128
+    assert np.all(np.abs(F.astype(np.float64) - exact).max(axis=0) <= bound_F)
+    # kernel constants: DELTA1_LUMA = 2^-13, DELTA1_CHROMA = 2^-14 (jpezy_kernels_f32.hip); bounds quoted in DESIGN.md
+    for qt, delta1, quoted in ((c["qt_luma"], 2.0 ** -13, 8.6e-5), (c["qt_chroma"], 2.0 ** -14, 5.3e-5)):
+        scale = np.outer(cu, cu) / (4.0 * qt.reshape(8, 8))
+        scale[0, 0] = 0                                  # the DC term never uses the guard band (exact lookup table)
+        bound_t = float((bound_F * scale).max() + 103 * 2.0 ** -23)
+        assert bound_t <= quoted < delta1, (bound_t, quoted, delta1)
+        ks = scale.astype(f32)                           # DeviceTables::qscale_f
+        t32 = (F * ks).astype(f32)
+        worst = float(np.abs(t32.astype(np.float64) - exact * scale).max())
+        assert worst < bound_t, (worst, bound_t)
+        assert worst < delta1 / 8, worst                 # measured: ~17x inside the guard band
+    # exact integer sums: the DC input of the lookup table
+    assert np.array_equal(F[:, 0, 0].astype(np.int64), pic.sum(axis=(1, 2)))

@@ -216,7 +216,8 @@ def main():
                        "inputs": "iid uniform u8 r,g,b planes resident in HBM", "parallelism": f"frames x{world}"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": "fdct_quant_kernel" if direction == "encode" else "dequant_idct_kernel",
+                         "kernel": ("f32::fdct_quant_f32_kernel" if args.variant in (None, 1) else "fdct_quant_kernel")
+                         if direction == "encode" else "dequant_idct_kernel",
                          "algorithmic_bytes_per_launch": step_bytes, "avg_launch_ms_hip_events": round(kern_ms, 5)},
             "exact_fallbacks_per_step": round(nfallback / max(1, args.steps), 2),
         }

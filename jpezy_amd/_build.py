@@ -17,7 +17,9 @@ BIN = PKG / "bin"
 HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 # -ffp-contract=off: the reference arithmetic is plain IEEE mul/add; every FMA in the kernels is explicit.
 COMMON = ["-std=c++17", "-O3", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
-DEVICE = ["--offload-arch=gfx950"]
+# -fno-slp-vectorize: hipcc otherwise pairs FP32 ops into v_pk_* (no faster on gfx950: tools/ubench/asm_rate.hip)
+# and pays v_mov shuffles for it -- the f32 encode kernel is 10 % faster without (33.8 vs 37.5 us per 4096^2 frame)
+DEVICE = ["--offload-arch=gfx950", "-fno-slp-vectorize"]
 
 LIB_SOURCES = [CSRC / "jpezy_kernels.hip", CSRC / "jpezy_kernels_f32.hip", CSRC / "jpezy_kernels_generic.hip",
                CSRC / "jpezy_capi.hip",

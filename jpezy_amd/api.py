@@ -6,12 +6,14 @@ Naming follows the reference: `Encoder(property, r, g, b).encode(output_file, gr
 (ref decoder/jpezy_decoder.hpp:39-134).  All compute goes through the C-ABI; nothing here touches oracle/.
 """
 import ctypes as C
+import os
 from pathlib import Path
 
 import numpy as np
 
 _PKG = Path(__file__).resolve().parent
-_LIBPATH = _PKG / "libjpezy_hip.so"
+# JPEZY_LIB: development aid (tools/ab.sh): load another build of the same library for A/B timing
+_LIBPATH = Path(os.environ["JPEZY_LIB"]) if os.environ.get("JPEZY_LIB") else _PKG / "libjpezy_hip.so"
 _LIB = None
 
 

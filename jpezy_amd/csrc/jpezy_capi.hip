@@ -38,6 +38,7 @@ int hip_err(hipError_t e, const char* what)
     } while (0)
 
 const int kQt[2][64] = { JPEZY_QT_LUMA_INIT, JPEZY_QT_CHROMA_INIT };
+const unsigned char kZzInv[64] = JPEZY_ZZ_INV_INIT;   // natural index -> zig-zag position
 
 struct DevBuf {
     void* p = nullptr;
@@ -135,6 +136,36 @@ jpezy_ctx* jpezy_ctx_create(int device)
             const double cu = S, cv = S;
             const int dct = (int)((double)sum * cu * cv / 4);          // int(sum * cu * cv / 4), no contraction (build flag)
             h.dcq[t][sum + 8192] = (signed char)(dct / kQt[t][0]);
+        }
+    {
+        // f32 kernel, level 1: |t_fp32 - t| <= gamma_13 * S_i * S_j * 128 * ks + 2^-23 * |t|max, S_u = sum_x |cos_u(x)|
+        // (13 roundings at most on any input->output path of the two butterfly passes; ks rounded to FP32 and the
+        // product rounded: 2 * 2^-24 relative to |t| <= 128 * S_i * S_j * ks).  tests/test_f32_error_bound.py re-derives it.
+        static const double kCos[64] = JPEZY_COS_INIT;
+        double S1[8];
+        for (int u = 0; u < 8; ++u) {
+            S1[u] = 0;
+            for (int x = 0; x < 8; ++x) S1[u] += std::fabs(kCos[u * 8 + x]);
+        }
+        for (int t = 0; t < 2; ++t)
+            for (int j = 0; j < 8; ++j) {
+                double worst = 0;
+                for (int i = 0; i < 8; ++i) {
+                    if (i == 0 && j == 0) continue;            // DC: exact table lookup, no guard band
+                    const double cu = j ? 1.0 : S, cv = i ? 1.0 : S;
+                    const double ks = cu * cv / (4.0 * kQt[t][i * 8 + j]);
+                    const double amp = 128.0 * S1[i] * S1[j] * ks;
+                    const double bound = 13.0 * 0x1p-24 * amp + 0x1p-23 * amp;
+                    if (bound > worst) worst = bound;
+                }
+                h.delta1[t][j] = (float)(1.25 * worst);
+            }
+    }
+    for (int j = 0; j < 8; ++j)
+        for (int hh = 0; hh < 2; ++hh) {
+            uint32_t w = 0;
+            for (int k = 0; k < 4; ++k) w |= (uint32_t)(2 * kZzInv[(4 * hh + k) * 8 + j]) << (8 * k);
+            h.zzpack[j][hh] = w;
         }
     bool ok = hipSetDevice(device) == hipSuccess;
     ok = ok && hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;

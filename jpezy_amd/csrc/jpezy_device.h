@@ -25,6 +25,12 @@ struct DeviceTables {
     // dcq[t][.] = int(((S * s) * s) / 4) / Q_t[0] with s = 1/sqrt(2), evaluated on the host in the reference's
     // exact FP64 order (ref encoder/jpezy_encoder.hpp:163,171)
     signed char dcq[2][16385];
+    // zzpack[j][h]: byte k = 2 * (zig-zag position of natural coefficient (i = 4h + k, j)): the byte offsets of one
+    // block column inside a staged block, packed so the f32 kernel spends two registers on them instead of eight
+    uint32_t zzpack[8][2];
+    // level-1 guard band of the f32 kernel per table and block column j: 1.25 x max over i of the worst-case FP32
+    // error of t[i][j] = F[i][j] * qscale_f[i][j] (jpezy_capi.hip: f32_level1_bound)
+    float delta1[2][8];
 };
 
 // The exact-path counter is sharded over COUNTER_SHARDS words: thousands of waves adding to ONE word serialise

@@ -1,14 +1,16 @@
 // jpezy_kernels_f32.hip -- encode kernel, variant 1: three precision levels, same bits as the reference.
 //
-// Level 1 (every coefficient): colour conversion in exact FP32 integer arithmetic, separable 8-point butterflies in
-//   FP32.  A quantised coefficient t = F*cu*cv/(4Q) is accepted when it is further than DELTA1 (luma 2^-13, chroma
-//   2^-14) from every non-zero integer; the worst-case FP32 error of t is 8.6e-5 / 5.3e-5 (DESIGN.md "exactness").
-// Level 2 (guard-band hits, ~0.5 per quad): the whole wave recomputes that one coefficient in FP64 from the pixels
-//   (lane k = term k, tree sum); accepted when further than 1e-6 from every boundary m*Q, m != 0.
+// Level 1 (every coefficient): colour conversion as an FP32 estimate with a guard band (below), separable 8-point
+//   butterflies in FP32.  A quantised coefficient t = F*cu*cv/(4Q) is accepted when it is further than delta1 from every
+//   non-zero integer; delta1 = 1.25 x the worst-case FP32 error of t over the coefficients of the lane's block column
+//   (DeviceTables::delta1, at most 1.06e-4 luma / 5.8e-5 chroma with the Annex-K tables; DESIGN.md "exactness").
+// Level 2 (guard-band hits, ~0.1 per quad): the 8 lanes holding the block's rows recompute that one coefficient in FP64
+//   from the integer samples; accepted when further than 1e-6 from every boundary m*Q, m != 0.
 // Level 3 (true boundary cases, ~0.2 per quad): the 64 terms are added in the reference's exact order.
-// Colour conversion: Y = trunc(M/1000), M = 299R+587G+114B-128000 is exact in FP32 (integers < 2^24); when
-//   M mod 1000 == 0 (1 pixel in 1000) the reference's FP64 rounding decides and the FP64 formula is evaluated.
-// The DC coefficient is a sum of integers (exact in FP32) and always evaluated in the reference's FP64 order.
+// Colour conversion: Y = trunc(fma chain in FP32) is exact unless the estimate is within 2^-12 of an integer, which
+//   happens exactly when 299R+587G+114B is a multiple of 1000 (1 pixel in 1000): there the reference's own FP64
+//   rounding decides and the FP64 formula is evaluated.  Same for Cb/Cr (multiples of 10000, 2^-14).
+// The DC coefficient is a sum of integers (exact in FP32) and is read from a table built in the reference's FP64 order.
 // Compiled with -ffp-contract=off; every FMA below is explicit.
 #include "jpezy_device.h"
 #include "../../include/jpezy_constants.h"
@@ -32,12 +34,10 @@ __constant__ unsigned char c_zzinv[64] = JPEZY_ZZ_INV_INIT;
 #define JPEZY_F32_WAVES 5
 #endif
 
-// Level-1 guard bands on t = v/Q.  Norm-wise bound of the FP32 error of F[i][j]: gamma_13 * sum|cos_i| * sum|cos_j| * 128
-// (at most 13 roundings on any input->output path, u = 2^-24), times the coefficient's scale factor cu*cv/(4Q), plus
-// the rounding of the product: at most 8.6e-5 (luma) / 5.3e-5 (chroma) over the Annex-K tables.
-// tests/test_f32_error_bound.py recomputes these bounds and measures 7.0e-6 / 3.2e-6 on adversarial blocks.
-constexpr float DELTA1_LUMA = 0x1p-13f;     // 1.22e-4
-constexpr float DELTA1_CHROMA = 0x1p-14f;   // 6.1e-5
+// Level-1 guard bands on t = v/Q: DeviceTables::delta1[table][j].  Norm-wise bound of the FP32 error of F[i][j]:
+// gamma_13 * sum|cos_i| * sum|cos_j| * 128 (at most 13 roundings on any input->output path, u = 2^-24), times the
+// coefficient's scale factor cu*cv/(4Q), plus the roundings of ks and of the product.  tests/test_f32_error_bound.py
+// recomputes the table and measures errors 10x smaller on adversarial blocks.
 constexpr double DELTA2 = 1e-6;             // level-2 guard band on v (FP64 tree-sum error < 1e-9)
 
 // LDS geometry in dwords (floats).  Column reads are ds_read_b32 over 32-lane groups (32 banks): conflict free
@@ -103,15 +103,23 @@ __device__ __forceinline__ float ubyte(uint32_t w)
     return (float)((w >> (8 * B)) & 0xFFu);      // selected as v_cvt_f32_ubyteB
 }
 
-// Y of pixel byte B of the three words: exact unless M mod 1000 == 0 (flag)
+// Colour conversion, level 1.  Y = trunc(y*) with y* = (299R + 587G + 114B - 128000) / 1000.  The FP32 estimate
+//   t = fma(.114f, B, fma(.587f, G, fma(.299f, R, -128)))
+// is within 2.4e-5 of y* (three roundings of at most 2^-18 each, three constants rounded to FP32: 1.2e-5), and y* is
+// either an integer or at least 1e-3 away from one.  So trunc(t) = trunc(y*) unless t is within LUMA_EPS = 2^-12 of an
+// integer -- exactly the pixels with y* integral (1 in 1000), where the reference's own FP64 rounding sequence decides
+// and the FP64 formula is evaluated instead.  The test costs one subtraction and one add per pixel: d = t - trunc(t)
+// is exact, e = |d| - 1/2, near an integer <=> |e| > 1/2 - eps; the eight |e| of a half row are reduced with v_max3.
+// Chroma: c* = N / 10000 (N integer), FP32 error 1.7e-5, non-integral c* at least 1e-4 from an integer, CHROMA_EPS 2^-14.
+constexpr float LUMA_EPS = 0x1p-12f;
+constexpr float CHROMA_EPS = 0x1p-14f;
+
 template <int B>
-__device__ __forceinline__ float luma_px(uint32_t wr, uint32_t wg, uint32_t wb, bool& flag)
+__device__ __forceinline__ float luma_px(uint32_t wr, uint32_t wg, uint32_t wb, float& e)
 {
-    const float rf = ubyte<B>(wr), gf = ubyte<B>(wg), bf = ubyte<B>(wb);
-    const float M = FMAF(114.f, bf, FMAF(587.f, gf, FMAF(299.f, rf, -128000.f)));   // exact integer
-    const float Yt = __builtin_truncf(M * 0.001f);
-    const float r = FMAF(-1000.f, Yt, M);                                            // exact remainder
-    flag = __builtin_fabsf(__builtin_fabsf(r) - 500.f) == 500.f;                     // r == 0 or |r| == 1000
+    const float t = FMAF(0.114f, ubyte<B>(wb), FMAF(0.587f, ubyte<B>(wg), FMAF(0.299f, ubyte<B>(wr), -128.f)));
+    const float Yt = __builtin_truncf(t);
+    e = __builtin_fabsf(t - Yt) - 0.5f;
     return Yt;
 }
 template <int B>
@@ -119,45 +127,48 @@ __device__ __forceinline__ float luma_px_ref(uint32_t wr, uint32_t wg, uint32_t 
 {
     return (float)ref_y((double)ubyte<B>(wr), (double)ubyte<B>(wg), (double)ubyte<B>(wb));
 }
+__device__ __forceinline__ float absmax8(const float* e)
+{
+    return __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(e[0]), __builtin_fabsf(e[1])),
+                                           __builtin_fmaxf(__builtin_fabsf(e[2]), __builtin_fabsf(e[3]))),
+                           __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(e[4]), __builtin_fabsf(e[5])),
+                                           __builtin_fmaxf(__builtin_fabsf(e[6]), __builtin_fabsf(e[7]))));
+}
 
 // 8 luma samples of words wr[0..1] etc. (pixels 0..7 of a half row)
 __device__ __forceinline__ void luma8(const uint32_t* wr, const uint32_t* wg, const uint32_t* wb, float* y)
 {
-    bool f[8];
-    y[0] = luma_px<0>(wr[0], wg[0], wb[0], f[0]);
-    y[1] = luma_px<1>(wr[0], wg[0], wb[0], f[1]);
-    y[2] = luma_px<2>(wr[0], wg[0], wb[0], f[2]);
-    y[3] = luma_px<3>(wr[0], wg[0], wb[0], f[3]);
+    float e[8];
+    y[0] = luma_px<0>(wr[0], wg[0], wb[0], e[0]);
+    y[1] = luma_px<1>(wr[0], wg[0], wb[0], e[1]);
+    y[2] = luma_px<2>(wr[0], wg[0], wb[0], e[2]);
+    y[3] = luma_px<3>(wr[0], wg[0], wb[0], e[3]);
     __builtin_amdgcn_sched_barrier(0);   // 4 pixels at a time: more in flight only costs registers
-    y[4] = luma_px<0>(wr[1], wg[1], wb[1], f[4]);
-    y[5] = luma_px<1>(wr[1], wg[1], wb[1], f[5]);
-    y[6] = luma_px<2>(wr[1], wg[1], wb[1], f[6]);
-    y[7] = luma_px<3>(wr[1], wg[1], wb[1], f[7]);
-    const bool any = f[0] | f[1] | f[2] | f[3] | f[4] | f[5] | f[6] | f[7];
-    if (__any(any)) {   // one pixel in 1000: the reference's FP64 rounding decides
-        if (__any(f[0])) { if (f[0]) y[0] = luma_px_ref<0>(wr[0], wg[0], wb[0]); }
-        if (__any(f[1])) { if (f[1]) y[1] = luma_px_ref<1>(wr[0], wg[0], wb[0]); }
-        if (__any(f[2])) { if (f[2]) y[2] = luma_px_ref<2>(wr[0], wg[0], wb[0]); }
-        if (__any(f[3])) { if (f[3]) y[3] = luma_px_ref<3>(wr[0], wg[0], wb[0]); }
-        if (__any(f[4])) { if (f[4]) y[4] = luma_px_ref<0>(wr[1], wg[1], wb[1]); }
-        if (__any(f[5])) { if (f[5]) y[5] = luma_px_ref<1>(wr[1], wg[1], wb[1]); }
-        if (__any(f[6])) { if (f[6]) y[6] = luma_px_ref<2>(wr[1], wg[1], wb[1]); }
-        if (__any(f[7])) { if (f[7]) y[7] = luma_px_ref<3>(wr[1], wg[1], wb[1]); }
+    y[4] = luma_px<0>(wr[1], wg[1], wb[1], e[4]);
+    y[5] = luma_px<1>(wr[1], wg[1], wb[1], e[5]);
+    y[6] = luma_px<2>(wr[1], wg[1], wb[1], e[6]);
+    y[7] = luma_px<3>(wr[1], wg[1], wb[1], e[7]);
+    constexpr float TH = 0.5f - LUMA_EPS;
+    if (__any(absmax8(e) > TH)) {   // one pixel in 1000: the reference's FP64 rounding decides
+        bool f;
+        f = __builtin_fabsf(e[0]) > TH; if (__any(f)) { if (f) y[0] = luma_px_ref<0>(wr[0], wg[0], wb[0]); }
+        f = __builtin_fabsf(e[1]) > TH; if (__any(f)) { if (f) y[1] = luma_px_ref<1>(wr[0], wg[0], wb[0]); }
+        f = __builtin_fabsf(e[2]) > TH; if (__any(f)) { if (f) y[2] = luma_px_ref<2>(wr[0], wg[0], wb[0]); }
+        f = __builtin_fabsf(e[3]) > TH; if (__any(f)) { if (f) y[3] = luma_px_ref<3>(wr[0], wg[0], wb[0]); }
+        f = __builtin_fabsf(e[4]) > TH; if (__any(f)) { if (f) y[4] = luma_px_ref<0>(wr[1], wg[1], wb[1]); }
+        f = __builtin_fabsf(e[5]) > TH; if (__any(f)) { if (f) y[5] = luma_px_ref<1>(wr[1], wg[1], wb[1]); }
+        f = __builtin_fabsf(e[6]) > TH; if (__any(f)) { if (f) y[6] = luma_px_ref<2>(wr[1], wg[1], wb[1]); }
+        f = __builtin_fabsf(e[7]) > TH; if (__any(f)) { if (f) y[7] = luma_px_ref<3>(wr[1], wg[1], wb[1]); }
     }
 }
 
-// chroma sample (Cb on even-row lanes, Cr on odd-row lanes) of pixel byte B: N = k1 R + k2 G + k3 B with the
-// integer constants x 10000 is exact in FP32; exact unless N mod 10000 == 0
+// chroma sample (Cb on even-row lanes, Cr on odd-row lanes) of pixel byte B; k1..k3: this lane's three coefficients
 template <int B>
-__device__ __forceinline__ float chroma_px(uint32_t wr, uint32_t wg, uint32_t wb, float k1, float k2, float k3, bool odd,
-                                           bool& flag)
+__device__ __forceinline__ float chroma_px(uint32_t wr, uint32_t wg, uint32_t wb, float k1, float k2, float k3, float& e)
 {
-    const float rf = ubyte<B>(wr), gf = ubyte<B>(wg), bf = ubyte<B>(wb);
-    const float N = FMAF(k3, bf, FMAF(k2, gf, k1 * rf));
-    const float Ct = __builtin_truncf(N * 0.0001f);
-    const float r = FMAF(-10000.f, Ct, N);
-    flag = __builtin_fabsf(__builtin_fabsf(r) - 5000.f) == 5000.f;
-    (void)odd;
+    const float t = FMAF(k3, ubyte<B>(wb), FMAF(k2, ubyte<B>(wg), k1 * ubyte<B>(wr)));
+    const float Ct = __builtin_truncf(t);
+    e = __builtin_fabsf(t - Ct) - 0.5f;
     return Ct;
 }
 template <int B>
@@ -202,7 +213,10 @@ __device__ __forceinline__ int resolve_coef(const uint32_t* w, bool part, int y,
         t[6] = unpack_lo(w[3]) * cj[6] * cy; t[7] = unpack_hi(w[3]) * cj[7] * cy;
     }
     const double cu = j ? 1.0 : JPEZY_S, cv = i ? 1.0 : JPEZY_S;
-    if (FORCE != 1) {
+    // (i, j) in {0,4}x{0,4}: every cosine is +-cos(pi/4) or 1, the exact value of v is a multiple of 1/8 and t a multiple
+    // of 1/(8Q) >= 1e-3: such a coefficient is queued only when it sits exactly on a boundary -- level 2 cannot decide
+    const bool rational = ((i | j) & 3) == 0;
+    if (FORCE == 2 || (FORCE == 0 && !rational)) {
         // level 2: accurate sum in any order -- row sums, then a butterfly over the 8 participating lanes
         double s = ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
         s = part ? s : 0.0;
@@ -227,52 +241,59 @@ __device__ __forceinline__ int resolve_coef(const uint32_t* w, bool part, int y,
     return dct / Q;
 }
 
-// quantise 8 coefficients of one block column; returns true when some coefficient needs level 2.
+// quantise 8 coefficients of one block column.  Returns the smallest distance |t - rint(t)| over the column (the DC
+// lane skips i == 0): below DELTA1 some coefficient MAY need level 2 -- the caller then looks coefficient by coefficient
+// (a distance below DELTA1 around rint(t) == 0 is not a truncation boundary and is sorted out there, off the hot path).
 // dcq: this table's DC lookup (exact, see DeviceTables::dcq) -- F[0] of the j == 0 lane is the block's integer sum.
-template <bool CHROMA>
-__device__ __forceinline__ bool quant8f(const float* F, const float* ks, bool dc_lane, const signed char* dcq, int* q)
+__device__ __forceinline__ float quant8f(const float* F, const float* ks, bool dc_lane, const signed char* dcq, int* q)
 {
     // issue the DC lookup first: its latency hides behind the other seven coefficients
     const int si = min(max((int)F[0], -8192), 8192) + 8192;            // clamp: non-DC lanes carry arbitrary values
     const int dc = dcq[si];
-    bool cand = false;
+    float d[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const float t = F[i] * ks[i];
         q[i] = (int)t;                                                    // v_cvt_i32_f32 truncates toward zero
-        const float d = t - __builtin_rintf(t);
-        const bool c = __builtin_fabsf(d) < (CHROMA ? DELTA1_CHROMA : DELTA1_LUMA) && __builtin_fabsf(t) > 0.5f;
-        cand |= (i == 0) ? (c && !dc_lane) : c;
+        d[i] = __builtin_fabsf(t - __builtin_rintf(t));
     }
-    if (dc_lane) q[0] = dc;
-    return cand;
+    if (dc_lane) { q[0] = dc; d[0] = 1.f; }
+    // v_min3_f32: 3.5 instructions for 8 values
+    return __builtin_fminf(__builtin_fminf(__builtin_fminf(d[0], d[1]), __builtin_fminf(d[2], d[3])),
+                           __builtin_fminf(__builtin_fminf(d[4], d[5]), __builtin_fminf(d[6], d[7])));
 }
 
-// addr[i]: LDS byte address of natural coefficient (i, j) inside this lane's FIRST block; blk_off: byte offset of the
-// block to write (an immediate after inlining)
-template <bool CHROMA>
-__device__ __forceinline__ void quant_block_column(const float* F, const float* ks, int j, const signed char* dcq, bool live,
-                                                   char* const* addr, int blk_off, int blk, unsigned* queue, bool force)
+// base: LDS address of this lane's FIRST block; blk_off: byte offset of the block to write (an immediate after inlining)
+// delta1: this lane's level-1 guard band (DeviceTables::delta1, a function of the table and of the column j)
+__device__ __forceinline__ void quant_block_column(const float* F, const float* ks, float delta1, int j, const signed char* dcq,
+                                                   bool live, char* base, uint32_t zz_lo, uint32_t zz_hi, int blk_off, int blk,
+                                                   unsigned* queue, bool force)
 {
     int q[8];
-    bool cand = quant8f<CHROMA>(F, ks, j == 0, dcq, q);
-    if (force) cand = true;
-    if (cand && live) {   // rare.  Fully unrolled: a runtime index into F/ks would send both arrays to scratch
+    const float dmin = quant8f(F, ks, j == 0, dcq, q);
+    const bool cand = (force || dmin < delta1) && live;
+    if (__any(cand)) {    // rare on noisy content; flat content (exact zeros) enters and finds nothing to queue
+        if (cand) {       // Fully unrolled: a runtime index into F/ks would send both arrays to scratch
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const float t = F[i] * ks[i];
-            bool f = __builtin_fabsf(t - __builtin_rintf(t)) < (CHROMA ? DELTA1_CHROMA : DELTA1_LUMA) && __builtin_fabsf(t) > 0.5f &&
-                     !(i == 0 && j == 0);
-            if (force) f = true;
-            if (f) {
-                const unsigned slot = atomicAdd(&queue[0], 1u);
-                if (slot < (unsigned)QUEUE_CAP)
-                    reinterpret_cast<unsigned short*>(queue + 1)[slot] = (unsigned short)((blk << 6) | (i * 8 + j));
+            for (int i = 0; i < 8; ++i) {
+                const float t = F[i] * ks[i];
+                bool f = __builtin_fabsf(t - __builtin_rintf(t)) < delta1 && __builtin_fabsf(t) > 0.5f && !(i == 0 && j == 0);
+                if (force) f = true;
+                if (f) {
+                    const unsigned slot = atomicAdd(&queue[0], 1u);
+                    if (slot < (unsigned)QUEUE_CAP)
+                        reinterpret_cast<unsigned short*>(queue + 1)[slot] = (unsigned short)((blk << 6) | (i * 8 + j));
+                }
             }
         }
     }
+    // zz_lo/zz_hi: byte i = LDS byte offset of natural coefficient (i, j) inside a block (2 * zig-zag index < 128);
+    // packed so that the eight addresses cost two registers (one SDWA add per store instead)
 #pragma unroll
-    for (int i = 0; i < 8; ++i) *reinterpret_cast<int16_t*>(addr[i] + blk_off) = (int16_t)q[i];
+    for (int i = 0; i < 8; ++i) {
+        const uint32_t off = ((i < 4 ? zz_lo : zz_hi) >> (8 * (i & 3))) & 0xFFu;
+        *reinterpret_cast<int16_t*>(base + off + blk_off) = (int16_t)q[i];
+    }
 }
 
 template <bool GRAY, bool ALIGNED, int FORCE>
@@ -363,29 +384,29 @@ __global__ __launch_bounds__(64 * WPB, JPEZY_F32_WAVES) void fdct_quant_f32_kern
             G2[k] = (uint32_t)__builtin_amdgcn_update_dpp((int)G[k], (int)G[k], 0x114, 0xF, 0xA, false);
             B2[k] = (uint32_t)__builtin_amdgcn_update_dpp((int)B[k], (int)B[k], 0x114, 0xF, 0xA, false);
         }
-        // 10000 * (Cb, Cr) = (-1687 R - 3313 G + 5000 B), (5000 R - 4187 G - 813 B)   (ref :249-256)
-        const float k1 = odd ? 5000.f : -1687.f, k2 = odd ? -4187.f : -3313.f, k3 = odd ? -813.f : 5000.f;
-        float cv[8];
-        bool f[8];
-        cv[0] = chroma_px<0>(R2[0], G2[0], B2[0], k1, k2, k3, odd, f[0]);
-        cv[1] = chroma_px<2>(R2[0], G2[0], B2[0], k1, k2, k3, odd, f[1]);
-        cv[2] = chroma_px<0>(R2[1], G2[1], B2[1], k1, k2, k3, odd, f[2]);
-        cv[3] = chroma_px<2>(R2[1], G2[1], B2[1], k1, k2, k3, odd, f[3]);
+        // (Cb, Cr) = (-.1687 R - .3313 G + .5 B), (.5 R - .4187 G - .0813 B)   (ref :249-256)
+        const float k1 = odd ? 0.5f : -0.1687f, k2 = odd ? -0.4187f : -0.3313f, k3 = odd ? -0.0813f : 0.5f;
+        float cv[8], e[8];
+        cv[0] = chroma_px<0>(R2[0], G2[0], B2[0], k1, k2, k3, e[0]);
+        cv[1] = chroma_px<2>(R2[0], G2[0], B2[0], k1, k2, k3, e[1]);
+        cv[2] = chroma_px<0>(R2[1], G2[1], B2[1], k1, k2, k3, e[2]);
+        cv[3] = chroma_px<2>(R2[1], G2[1], B2[1], k1, k2, k3, e[3]);
         __builtin_amdgcn_sched_barrier(0);
-        cv[4] = chroma_px<0>(R2[2], G2[2], B2[2], k1, k2, k3, odd, f[4]);
-        cv[5] = chroma_px<2>(R2[2], G2[2], B2[2], k1, k2, k3, odd, f[5]);
-        cv[6] = chroma_px<0>(R2[3], G2[3], B2[3], k1, k2, k3, odd, f[6]);
-        cv[7] = chroma_px<2>(R2[3], G2[3], B2[3], k1, k2, k3, odd, f[7]);
-        const bool any = f[0] | f[1] | f[2] | f[3] | f[4] | f[5] | f[6] | f[7];
-        if (__any(any)) {
-            if (__any(f[0])) { if (f[0]) cv[0] = chroma_px_ref<0>(R2[0], G2[0], B2[0], odd); }
-            if (__any(f[1])) { if (f[1]) cv[1] = chroma_px_ref<2>(R2[0], G2[0], B2[0], odd); }
-            if (__any(f[2])) { if (f[2]) cv[2] = chroma_px_ref<0>(R2[1], G2[1], B2[1], odd); }
-            if (__any(f[3])) { if (f[3]) cv[3] = chroma_px_ref<2>(R2[1], G2[1], B2[1], odd); }
-            if (__any(f[4])) { if (f[4]) cv[4] = chroma_px_ref<0>(R2[2], G2[2], B2[2], odd); }
-            if (__any(f[5])) { if (f[5]) cv[5] = chroma_px_ref<2>(R2[2], G2[2], B2[2], odd); }
-            if (__any(f[6])) { if (f[6]) cv[6] = chroma_px_ref<0>(R2[3], G2[3], B2[3], odd); }
-            if (__any(f[7])) { if (f[7]) cv[7] = chroma_px_ref<2>(R2[3], G2[3], B2[3], odd); }
+        cv[4] = chroma_px<0>(R2[2], G2[2], B2[2], k1, k2, k3, e[4]);
+        cv[5] = chroma_px<2>(R2[2], G2[2], B2[2], k1, k2, k3, e[5]);
+        cv[6] = chroma_px<0>(R2[3], G2[3], B2[3], k1, k2, k3, e[6]);
+        cv[7] = chroma_px<2>(R2[3], G2[3], B2[3], k1, k2, k3, e[7]);
+        constexpr float TH = 0.5f - CHROMA_EPS;
+        if (__any(absmax8(e) > TH)) {
+            bool f;
+            f = __builtin_fabsf(e[0]) > TH; if (__any(f)) { if (f) cv[0] = chroma_px_ref<0>(R2[0], G2[0], B2[0], odd); }
+            f = __builtin_fabsf(e[1]) > TH; if (__any(f)) { if (f) cv[1] = chroma_px_ref<2>(R2[0], G2[0], B2[0], odd); }
+            f = __builtin_fabsf(e[2]) > TH; if (__any(f)) { if (f) cv[2] = chroma_px_ref<0>(R2[1], G2[1], B2[1], odd); }
+            f = __builtin_fabsf(e[3]) > TH; if (__any(f)) { if (f) cv[3] = chroma_px_ref<2>(R2[1], G2[1], B2[1], odd); }
+            f = __builtin_fabsf(e[4]) > TH; if (__any(f)) { if (f) cv[4] = chroma_px_ref<0>(R2[2], G2[2], B2[2], odd); }
+            f = __builtin_fabsf(e[5]) > TH; if (__any(f)) { if (f) cv[5] = chroma_px_ref<2>(R2[2], G2[2], B2[2], odd); }
+            f = __builtin_fabsf(e[6]) > TH; if (__any(f)) { if (f) cv[6] = chroma_px_ref<0>(R2[3], G2[3], B2[3], odd); }
+            f = __builtin_fabsf(e[7]) > TH; if (__any(f)) { if (f) cv[7] = chroma_px_ref<2>(R2[3], G2[3], B2[3], odd); }
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) pc[k] = pack_h2(cv[2 * k], cv[2 * k + 1]);
@@ -405,23 +426,23 @@ __global__ __launch_bounds__(64 * WPB, JPEZY_F32_WAVES) void fdct_quant_f32_kern
     wave_sync();   // tile consumed; the slice is reused (chroma tile | staging)
     char* stage = reinterpret_cast<char*>(lds) + CT_BYTES;
     const int bx = cq >> 3;
-    char* addr[8];   // this lane's 8 zig-zag slots in its first block (m, bx); the other blocks are immediates away
-#pragma unroll
-    for (int i = 0; i < 8; ++i) addr[i] = stage + (m * BPM + bx) * STG_BLK + 2 * (int)c_zzinv[i * 8 + j];
+    char* sbase = stage + (m * BPM + bx) * STG_BLK;   // this lane's first block (m, bx); the others are immediates away
+    const uint32_t zz_lo = tab->zzpack[j][0], zz_hi = tab->zzpack[j][1];
     {
         float ks[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) ks[i] = tab->qscale_f[0][j][i];
+        const float dl = tab->delta1[0][j];
         {
             float F[8];
             fdct8f(col, F);
-            quant_block_column<false>(F, ks, j, tab->dcq[0], live, addr, 0, m * BPM + bx, queue, FORCE != 0);
+            quant_block_column(F, ks, dl, j, tab->dcq[0], live, sbase, zz_lo, zz_hi, 0, m * BPM + bx, queue, FORCE != 0);
         }
         __builtin_amdgcn_sched_barrier(0);
         {
             float F[8];
             fdct8f(col + 8, F);
-            quant_block_column<false>(F, ks, j, tab->dcq[0], live, addr, 2 * STG_BLK, m * BPM + 2 + bx, queue, FORCE != 0);
+            quant_block_column(F, ks, dl, j, tab->dcq[0], live, sbase, zz_lo, zz_hi, 2 * STG_BLK, m * BPM + 2 + bx, queue, FORCE != 0);
         }
     }
 
@@ -453,7 +474,7 @@ __global__ __launch_bounds__(64 * WPB, JPEZY_F32_WAVES) void fdct_quant_f32_kern
         float ks[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) ks[i] = tab->qscale_f[1][j][i];
-        quant_block_column<true>(Fc, ks, j, tab->dcq[1], live, addr, 4 * STG_BLK, m * BPM + 4 + bx, queue, FORCE != 0);
+        quant_block_column(Fc, ks, tab->delta1[1][j], j, tab->dcq[1], live, sbase, zz_lo, zz_hi, 4 * STG_BLK, m * BPM + 4 + bx, queue, FORCE != 0);
     }
     wave_sync();
 

@@ -1,9 +1,10 @@
 """The FP32 first level of encode kernel variant 1 accepts a quantised coefficient t = F*cu*cv/(4Q) only when it is
-further than DELTA1 (luma 2^-13, chroma 2^-14) from every non-zero integer.  DESIGN.md derives a worst-case FP32 error of
-8.6e-5 / 5.3e-5 for t;
-this test emulates the kernel's exact FP32 instruction sequence (same butterflies, same FMA placement) in numpy and
-measures the error against a float64 evaluation on adversarial blocks (extreme amplitudes, every basis-function sign
-pattern, checkerboards) and random blocks -- the measured maximum must stay far inside the guard band."""
+further than delta1 from every non-zero integer, delta1 = 1.25 x the worst-case FP32 error of t over the lane's block
+column (DeviceTables::delta1, built in jpezy_capi.hip).  This test re-derives that table, emulates the kernel's exact FP32
+instruction sequence (same butterflies, same FMA placement) in numpy and measures the error against a float64
+evaluation on adversarial blocks (extreme amplitudes, every basis-function sign pattern, checkerboards) and random
+blocks -- the measured maximum must stay far inside the guard band.  The colour-conversion guard band is checked
+exhaustively over all 2^24 RGB triples."""
 import numpy as np
 
 f32 = np.float32
@@ -74,16 +75,55 @@ def test_level1_error_is_far_inside_the_guard_band(oracle):
     absum = np.abs(cos).sum(axis=1)
     bound_F = gamma * np.outer(absum, absum) * 128
     assert np.all(np.abs(F.astype(np.float64) - exact).max(axis=0) <= bound_F)
-    # kernel constants: DELTA1_LUMA = 2^-13, DELTA1_CHROMA = 2^-14 (jpezy_kernels_f32.hip); bounds quoted in DESIGN.md
-    for qt, delta1, quoted in ((c["qt_luma"], 2.0 ** -13, 8.6e-5), (c["qt_chroma"], 2.0 ** -14, 5.3e-5)):
+    # the table the kernel uses (jpezy_capi.hip): per table and column j, 1.25 x max_i of
+    #   gamma_13 * amp + 2^-23 * amp,  amp = 128 * S_i * S_j * ks  (ks and the product t = F * ks are rounded to FP32)
+    for qt, dmax in ((c["qt_luma"], 1.06e-4), (c["qt_chroma"], 5.8e-5)):
         scale = np.outer(cu, cu) / (4.0 * qt.reshape(8, 8))
-        scale[0, 0] = 0                                  # the DC term never uses the guard band (exact lookup table)
-        bound_t = float((bound_F * scale).max() + 103 * 2.0 ** -23)
-        assert bound_t <= quoted < delta1, (bound_t, quoted, delta1)
+        amp = 128.0 * np.outer(absum, absum) * scale
+        bound_t = gamma * amp + 2.0 ** -23 * amp
+        bound_t[0, 0] = 0                                # the DC term never uses the guard band (exact lookup table)
+        delta1 = (1.25 * bound_t.max(axis=0)).astype(f32)            # [j]
+        assert float(delta1.max()) <= dmax, delta1                   # the figures quoted in DESIGN.md / the kernel header
         ks = scale.astype(f32)                           # DeviceTables::qscale_f
         t32 = (F * ks).astype(f32)
-        worst = float(np.abs(t32.astype(np.float64) - exact * scale).max())
-        assert worst < bound_t, (worst, bound_t)
-        assert worst < delta1 / 8, worst                 # measured: ~17x inside the guard band
+        err = np.abs(t32.astype(np.float64) - exact * scale).max(axis=0)     # [i][j]
+        err[0, 0] = 0
+        assert np.all(err <= bound_t), (err / np.maximum(bound_t, 1e-30)).max()
+        assert np.all(err.max(axis=0) < delta1 / 8), (err.max(axis=0) / delta1).max()   # measured: >10x inside the band
     # exact integer sums: the DC input of the lookup table
     assert np.array_equal(F[:, 0, 0].astype(np.int64), pic.sum(axis=(1, 2)))
+
+
+def test_colour_level1_guard_band_exhaustive():
+    """f32::luma_px / chroma_px: Y = trunc(t), t an FP32 fma chain; flagged (-> FP64 reference formula) when t is within
+    2^-12 (luma) / 2^-14 (chroma) of an integer.  Over all 2^24 RGB triples: every unflagged pixel truncates to the exact
+    integer quotient, and every pixel whose exact value is an integer (where the reference's FP64 rounding decides) is
+    flagged."""
+    G, B = np.meshgrid(np.arange(256, dtype=np.int64), np.arange(256, dtype=np.int64), indexing="ij")
+    Gf, Bf = G.astype(f32), B.astype(f32)
+    worst = {"y": 0.0, "cb": 0.0, "cr": 0.0}
+    flagged = {"y": 0, "cb": 0, "cr": 0}
+    for R in range(256):
+        Rf = np.full_like(Gf, R)
+        cases = {
+            "y": (fma(Bf, f32(0.114), fma(Gf, f32(0.587), fma(Rf, f32(0.299), np.full_like(Gf, -128.0)))),
+                  299 * R + 587 * G + 114 * B - 128000, 1000, 2.0 ** -12, 2.4e-5),
+            "cb": (fma(Bf, f32(0.5), fma(Gf, f32(-0.3313), (Rf * f32(-0.1687)).astype(f32))),
+                   -1687 * R - 3313 * G + 5000 * B, 10000, 2.0 ** -14, 1.7e-5),
+            "cr": (fma(Bf, f32(-0.0813), fma(Gf, f32(-0.4187), (Rf * f32(0.5)).astype(f32))),
+                   5000 * R - 4187 * G - 813 * B, 10000, 2.0 ** -14, 1.7e-5),
+        }
+        for name, (t, num, den, eps, bound) in cases.items():
+            tr = np.trunc(t)
+            d = np.abs(t - tr)                                         # exact in FP32
+            e = (d - f32(0.5)).astype(f32)
+            flag = np.abs(e) > f32(0.5) - f32(eps)
+            exact_q = np.trunc(num / den)                              # float64 quotient: exact enough for integers < 2^24
+            integral = (num % den) == 0
+            assert np.all(flag[integral]), name                        # the reference's rounding decides: must be flagged
+            assert np.array_equal(tr[~flag], exact_q[~flag]), name     # everything else is already right
+            worst[name] = max(worst[name], float(np.abs(t.astype(np.float64) - num / den).max()))
+            flagged[name] += int(flag.sum())
+            assert worst[name] <= bound, (name, worst[name])
+            assert int(flag.sum()) == int(integral.sum()), name        # the band catches nothing else
+    assert flagged["y"] == 16777216 // 1000 + 1 or 16000 < flagged["y"] < 17500, flagged

@@ -128,7 +128,7 @@ jpezy_ctx* jpezy_ctx_create(int device)
         for (int j = 0; j < 8; ++j)
             for (int i = 0; i < 8; ++i) {
                 const double cu = j ? 1.0 : S, cv = i ? 1.0 : S;
-                h.qscale_f[t][j][i] = (float)(cu * cv / (4.0 * kQt[t][i * 8 + j]));
+                h.f32col[t][j].ks[i] = (float)(cu * cv / (4.0 * kQt[t][i * 8 + j]));
             }
     }
     for (int t = 0; t < 2; ++t)
@@ -158,14 +158,14 @@ jpezy_ctx* jpezy_ctx_create(int device)
                     const double bound = 13.0 * 0x1p-24 * amp + 0x1p-23 * amp;
                     if (bound > worst) worst = bound;
                 }
-                h.delta1[t][j] = (float)(1.25 * worst);
+                h.f32col[t][j].delta1 = (float)(1.25 * worst);
             }
     }
     for (int j = 0; j < 8; ++j)
         for (int hh = 0; hh < 2; ++hh) {
             uint32_t w = 0;
             for (int k = 0; k < 4; ++k) w |= (uint32_t)(2 * kZzInv[(4 * hh + k) * 8 + j]) << (8 * k);
-            h.zzpack[j][hh] = w;
+            for (int t = 0; t < 2; ++t) (hh ? h.f32col[t][j].zz_hi : h.f32col[t][j].zz_lo) = w;
         }
     bool ok = hipSetDevice(device) == hipSuccess;
     ok = ok && hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
@@ -257,6 +257,8 @@ int jpezy_fdct_quant_dev(jpezy_ctx* c, const uint8_t* d_r, const uint8_t* d_g, c
     p.coeffs = d_coeffs;
     p.coeffs_per_frame = jpezy_coeff_count(W, H, gray);
     p.tab = c->d_tab;
+    p.dcq_luma = c->d_tab->dcq[0];       // address arithmetic only: d_tab is a device pointer
+    p.dcq_chroma = c->d_tab->dcq[1];
     p.fallback_count = c->d_counter;
     p.W = W; p.H = H;
     p.mcu_cols = jpezy_mcu_cols(W);

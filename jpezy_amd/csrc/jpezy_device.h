@@ -12,25 +12,30 @@ constexpr int QFRAC_BITS = 24;
 // IDCT samples: (sum/4+128) * 2^SFRAC_BITS; samples outside +-2^(30-SFRAC_BITS) take the exact path.
 constexpr int SFRAC_BITS = 18;
 
+// Per (table, block column j) record of the f32 encode kernel: one 64-byte line per lane, three loads off one address.
+struct F32Column {
+    float ks[8];              // ks[i] = cu(j) * cv(i) / (4 * Q_t[i*8+j])
+    // level-1 guard band: 1.25 x max over i of the worst-case FP32 error of t[i][j] = F[i][j] * ks[i]
+    // (jpezy_capi.hip; tests/test_f32_error_bound.py re-derives it)
+    float delta1;
+    // byte k of zz_lo / zz_hi = 2 * (zig-zag position of natural coefficient (i = k / 4 + k, j)): the byte offsets of one
+    // block column inside a staged block, packed so the kernel spends two registers on them instead of eight
+    uint32_t zz_lo, zz_hi;
+    uint32_t pad[5];
+};
+
 // Device-resident tables built by the host at context creation (jpezy_capi.hip).
 struct DeviceTables {
-    // encode: qscale[t][j][i] = cu(j) * cv(i) / (4 * Q_t[i*8+j]) * 2^QFRAC_BITS   (t: 0 luma, 1 chroma)
-    double qscale[2][8][8];
-    double rq_dc[2];          // 1 / Q_t[0]
-    int qt[2][64];            // natural order
-    // f32 first-level kernel: qscale_f[t][j][i] = cu(j) * cv(i) / (4 * Q_t[i*8+j]) ; qinv[t][k] = 1.0 / Q_t[k]
-    float qscale_f[2][8][8];
-    double qinv[2][64];
+    F32Column f32col[2][8];   // first: every field at an immediate offset from the table pointer
     // quantised DC as a function of the block's integer sample sum S in [-8192, 8192] (index S + 8192):
     // dcq[t][.] = int(((S * s) * s) / 4) / Q_t[0] with s = 1/sqrt(2), evaluated on the host in the reference's
     // exact FP64 order (ref encoder/jpezy_encoder.hpp:163,171)
     signed char dcq[2][16385];
-    // zzpack[j][h]: byte k = 2 * (zig-zag position of natural coefficient (i = 4h + k, j)): the byte offsets of one
-    // block column inside a staged block, packed so the f32 kernel spends two registers on them instead of eight
-    uint32_t zzpack[8][2];
-    // level-1 guard band of the f32 kernel per table and block column j: 1.25 x max over i of the worst-case FP32
-    // error of t[i][j] = F[i][j] * qscale_f[i][j] (jpezy_capi.hip: f32_level1_bound)
-    float delta1[2][8];
+    // encode variant 0: qscale[t][j][i] = cu(j) * cv(i) / (4 * Q_t[i*8+j]) * 2^QFRAC_BITS   (t: 0 luma, 1 chroma)
+    double qscale[2][8][8];
+    double rq_dc[2];          // 1 / Q_t[0]
+    int qt[2][64];            // natural order
+    double qinv[2][64];       // 1.0 / Q_t[k] (levels 2/3 of the f32 kernel)
 };
 
 // The exact-path counter is sharded over COUNTER_SHARDS words: thousands of waves adding to ONE word serialise
@@ -50,6 +55,8 @@ struct EncParams {
     int16_t* coeffs;
     size_t coeffs_per_frame;  // int16 elements
     const DeviceTables* tab;
+    const signed char* dcq_luma;     // &tab->dcq[0][0], &tab->dcq[1][0]: separate kernel arguments so that the f32 kernel's
+    const signed char* dcq_chroma;   // DC lookups are scalar-base + 32-bit-offset loads
     unsigned long long* fallback_count;
     int W, H, mcu_cols, mcu_rows, quads_per_row, n_frames;
     unsigned qpr_magic, qpr_shift;   // fast_div by quads_per_row (f32 kernel)

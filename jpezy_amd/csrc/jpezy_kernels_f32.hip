@@ -60,6 +60,9 @@ __device__ __forceinline__ unsigned fast_div(unsigned n, unsigned magic, unsigne
     return magic ? (((n - q) >> 1) + q) >> shift : n;
 }
 
+// wave-uniform "some lane": one v_cmp into an SGPR pair + s_cmp (HIP's __any goes through a 0/1 VGPR)
+__device__ __forceinline__ bool wave_any(bool x) { return __builtin_amdgcn_ballot_w64(x) != 0ull; }
+
 __device__ __forceinline__ void wave_sync()
 {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -149,16 +152,16 @@ __device__ __forceinline__ void luma8(const uint32_t* wr, const uint32_t* wg, co
     y[6] = luma_px<2>(wr[1], wg[1], wb[1], e[6]);
     y[7] = luma_px<3>(wr[1], wg[1], wb[1], e[7]);
     constexpr float TH = 0.5f - LUMA_EPS;
-    if (__any(absmax8(e) > TH)) {   // one pixel in 1000: the reference's FP64 rounding decides
+    if (wave_any(absmax8(e) > TH)) {   // one pixel in 1000: the reference's FP64 rounding decides
         bool f;
-        f = __builtin_fabsf(e[0]) > TH; if (__any(f)) { if (f) y[0] = luma_px_ref<0>(wr[0], wg[0], wb[0]); }
-        f = __builtin_fabsf(e[1]) > TH; if (__any(f)) { if (f) y[1] = luma_px_ref<1>(wr[0], wg[0], wb[0]); }
-        f = __builtin_fabsf(e[2]) > TH; if (__any(f)) { if (f) y[2] = luma_px_ref<2>(wr[0], wg[0], wb[0]); }
-        f = __builtin_fabsf(e[3]) > TH; if (__any(f)) { if (f) y[3] = luma_px_ref<3>(wr[0], wg[0], wb[0]); }
-        f = __builtin_fabsf(e[4]) > TH; if (__any(f)) { if (f) y[4] = luma_px_ref<0>(wr[1], wg[1], wb[1]); }
-        f = __builtin_fabsf(e[5]) > TH; if (__any(f)) { if (f) y[5] = luma_px_ref<1>(wr[1], wg[1], wb[1]); }
-        f = __builtin_fabsf(e[6]) > TH; if (__any(f)) { if (f) y[6] = luma_px_ref<2>(wr[1], wg[1], wb[1]); }
-        f = __builtin_fabsf(e[7]) > TH; if (__any(f)) { if (f) y[7] = luma_px_ref<3>(wr[1], wg[1], wb[1]); }
+        f = __builtin_fabsf(e[0]) > TH; if (wave_any(f)) { if (f) y[0] = luma_px_ref<0>(wr[0], wg[0], wb[0]); }
+        f = __builtin_fabsf(e[1]) > TH; if (wave_any(f)) { if (f) y[1] = luma_px_ref<1>(wr[0], wg[0], wb[0]); }
+        f = __builtin_fabsf(e[2]) > TH; if (wave_any(f)) { if (f) y[2] = luma_px_ref<2>(wr[0], wg[0], wb[0]); }
+        f = __builtin_fabsf(e[3]) > TH; if (wave_any(f)) { if (f) y[3] = luma_px_ref<3>(wr[0], wg[0], wb[0]); }
+        f = __builtin_fabsf(e[4]) > TH; if (wave_any(f)) { if (f) y[4] = luma_px_ref<0>(wr[1], wg[1], wb[1]); }
+        f = __builtin_fabsf(e[5]) > TH; if (wave_any(f)) { if (f) y[5] = luma_px_ref<1>(wr[1], wg[1], wb[1]); }
+        f = __builtin_fabsf(e[6]) > TH; if (wave_any(f)) { if (f) y[6] = luma_px_ref<2>(wr[1], wg[1], wb[1]); }
+        f = __builtin_fabsf(e[7]) > TH; if (wave_any(f)) { if (f) y[7] = luma_px_ref<3>(wr[1], wg[1], wb[1]); }
     }
 }
 
@@ -248,7 +251,9 @@ __device__ __forceinline__ int resolve_coef(const uint32_t* w, bool part, int y,
 __device__ __forceinline__ float quant8f(const float* F, const float* ks, bool dc_lane, const signed char* dcq, int* q)
 {
     // issue the DC lookup first: its latency hides behind the other seven coefficients
-    const int si = min(max((int)F[0], -8192), 8192) + 8192;            // clamp: non-DC lanes carry arbitrary values
+    // index = block sum + 8192, formed in FP32 (exact) and clamped there (non-DC lanes carry arbitrary values); an
+    // unsigned index keeps the lookup a scalar-base + 32-bit-offset load
+    const unsigned si = (unsigned)(__builtin_fminf(__builtin_fmaxf(F[0], -8192.f), 8192.f) + 8192.f);
     const int dc = dcq[si];
     float d[8];
 #pragma unroll
@@ -271,9 +276,11 @@ __device__ __forceinline__ void quant_block_column(const float* F, const float* 
 {
     int q[8];
     const float dmin = quant8f(F, ks, j == 0, dcq, q);
-    const bool cand = (force || dmin < delta1) && live;
-    if (__any(cand)) {    // rare on noisy content; flat content (exact zeros) enters and finds nothing to queue
-        if (cand) {       // Fully unrolled: a runtime index into F/ks would send both arrays to scratch
+    const bool cand = force || dmin < delta1;
+    // rare on noisy content; flat content (exact zeros) enters and finds nothing to queue.  (Lanes that are not live
+    // repeat the quad's last MCU, so leaving them in the vote changes nothing and keeps it a bare v_cmp + s_cmp.)
+    if (wave_any(cand)) {
+        if (cand && live) {       // Fully unrolled: a runtime index into F/ks would send both arrays to scratch
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const float t = F[i] * ks[i];
@@ -302,7 +309,9 @@ __global__ __launch_bounds__(64 * WPB, JPEZY_F32_WAVES) void fdct_quant_f32_kern
     __shared__ __attribute__((aligned(16))) uint32_t lds_all[WPB][WAVE_LDS_DWORDS];
     constexpr int BPM = GRAY ? 4 : 6;
 
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;   // WPB waves per workgroup
+    // WPB waves per workgroup; the wave index is made an SGPR so that everything derived from it (quad position, plane
+    // and coefficient base addresses, the LDS slice) is computed once on the scalar unit
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const unsigned qidx = blockIdx.x * (unsigned)WPB + (unsigned)wave;          // quad index inside the frame
     if (qidx >= (unsigned)(p.mcu_rows * p.quads_per_row)) return;     // wave-uniform
     const int frame = (int)blockIdx.y;
@@ -327,9 +336,9 @@ __global__ __launch_bounds__(64 * WPB, JPEZY_F32_WAVES) void fdct_quant_f32_kern
     uint32_t R[4], G[4], B[4];
     {
         const int y = min(mcu_y * 16 + row, H - 1);                   // edge replication, ref :101
-        const size_t rowoff = (size_t)y * W;
+        const unsigned rowoff = (unsigned)y * (unsigned)W;            // W, H <= 65535 (launcher): fits 32 bits
         if (ALIGNED) {
-            const size_t off = rowoff + (size_t)mcu_x * 16;
+            const unsigned off = rowoff + (unsigned)mcu_x * 16u;
             const uint4 vr = *reinterpret_cast<const uint4*>(pr + off);
             const uint4 vg = *reinterpret_cast<const uint4*>(pg + off);
             const uint4 vb = *reinterpret_cast<const uint4*>(pb + off);
@@ -397,16 +406,16 @@ __global__ __launch_bounds__(64 * WPB, JPEZY_F32_WAVES) void fdct_quant_f32_kern
         cv[6] = chroma_px<0>(R2[3], G2[3], B2[3], k1, k2, k3, e[6]);
         cv[7] = chroma_px<2>(R2[3], G2[3], B2[3], k1, k2, k3, e[7]);
         constexpr float TH = 0.5f - CHROMA_EPS;
-        if (__any(absmax8(e) > TH)) {
+        if (wave_any(absmax8(e) > TH)) {
             bool f;
-            f = __builtin_fabsf(e[0]) > TH; if (__any(f)) { if (f) cv[0] = chroma_px_ref<0>(R2[0], G2[0], B2[0], odd); }
-            f = __builtin_fabsf(e[1]) > TH; if (__any(f)) { if (f) cv[1] = chroma_px_ref<2>(R2[0], G2[0], B2[0], odd); }
-            f = __builtin_fabsf(e[2]) > TH; if (__any(f)) { if (f) cv[2] = chroma_px_ref<0>(R2[1], G2[1], B2[1], odd); }
-            f = __builtin_fabsf(e[3]) > TH; if (__any(f)) { if (f) cv[3] = chroma_px_ref<2>(R2[1], G2[1], B2[1], odd); }
-            f = __builtin_fabsf(e[4]) > TH; if (__any(f)) { if (f) cv[4] = chroma_px_ref<0>(R2[2], G2[2], B2[2], odd); }
-            f = __builtin_fabsf(e[5]) > TH; if (__any(f)) { if (f) cv[5] = chroma_px_ref<2>(R2[2], G2[2], B2[2], odd); }
-            f = __builtin_fabsf(e[6]) > TH; if (__any(f)) { if (f) cv[6] = chroma_px_ref<0>(R2[3], G2[3], B2[3], odd); }
-            f = __builtin_fabsf(e[7]) > TH; if (__any(f)) { if (f) cv[7] = chroma_px_ref<2>(R2[3], G2[3], B2[3], odd); }
+            f = __builtin_fabsf(e[0]) > TH; if (wave_any(f)) { if (f) cv[0] = chroma_px_ref<0>(R2[0], G2[0], B2[0], odd); }
+            f = __builtin_fabsf(e[1]) > TH; if (wave_any(f)) { if (f) cv[1] = chroma_px_ref<2>(R2[0], G2[0], B2[0], odd); }
+            f = __builtin_fabsf(e[2]) > TH; if (wave_any(f)) { if (f) cv[2] = chroma_px_ref<0>(R2[1], G2[1], B2[1], odd); }
+            f = __builtin_fabsf(e[3]) > TH; if (wave_any(f)) { if (f) cv[3] = chroma_px_ref<2>(R2[1], G2[1], B2[1], odd); }
+            f = __builtin_fabsf(e[4]) > TH; if (wave_any(f)) { if (f) cv[4] = chroma_px_ref<0>(R2[2], G2[2], B2[2], odd); }
+            f = __builtin_fabsf(e[5]) > TH; if (wave_any(f)) { if (f) cv[5] = chroma_px_ref<2>(R2[2], G2[2], B2[2], odd); }
+            f = __builtin_fabsf(e[6]) > TH; if (wave_any(f)) { if (f) cv[6] = chroma_px_ref<0>(R2[3], G2[3], B2[3], odd); }
+            f = __builtin_fabsf(e[7]) > TH; if (wave_any(f)) { if (f) cv[7] = chroma_px_ref<2>(R2[3], G2[3], B2[3], odd); }
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) pc[k] = pack_h2(cv[2 * k], cv[2 * k + 1]);
@@ -417,6 +426,7 @@ __global__ __launch_bounds__(64 * WPB, JPEZY_F32_WAVES) void fdct_quant_f32_kern
     // ---- 3+4. luma column pass, quantise + zig-zag into the staging area; top block first, then the bottom block
     //           (kept apart so that only one block column of coefficients is live at a time) ----
     const int cq = row, j = cq & 7;
+    const unsigned ju = (unsigned)j;   // unsigned table indices: scalar base + 32-bit offset addressing
     float col[16];
     {
         const float* src = ldsf + m * Y_MCU + cq;
@@ -427,22 +437,25 @@ __global__ __launch_bounds__(64 * WPB, JPEZY_F32_WAVES) void fdct_quant_f32_kern
     char* stage = reinterpret_cast<char*>(lds) + CT_BYTES;
     const int bx = cq >> 3;
     char* sbase = stage + (m * BPM + bx) * STG_BLK;   // this lane's first block (m, bx); the others are immediates away
-    const uint32_t zz_lo = tab->zzpack[j][0], zz_hi = tab->zzpack[j][1];
+    const F32Column* lcol = &tab->f32col[0][ju];
+    const uint32_t zz_lo = lcol->zz_lo, zz_hi = lcol->zz_hi;
+    const signed char* dcq_l = p.dcq_luma;
+    const signed char* dcq_c = p.dcq_chroma;
     {
         float ks[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) ks[i] = tab->qscale_f[0][j][i];
-        const float dl = tab->delta1[0][j];
+        for (int i = 0; i < 8; ++i) ks[i] = lcol->ks[i];
+        const float dl = lcol->delta1;
         {
             float F[8];
             fdct8f(col, F);
-            quant_block_column(F, ks, dl, j, tab->dcq[0], live, sbase, zz_lo, zz_hi, 0, m * BPM + bx, queue, FORCE != 0);
+            quant_block_column(F, ks, dl, j, dcq_l, live, sbase, zz_lo, zz_hi, 0, m * BPM + bx, queue, FORCE != 0);
         }
         __builtin_amdgcn_sched_barrier(0);
         {
             float F[8];
             fdct8f(col + 8, F);
-            quant_block_column(F, ks, dl, j, tab->dcq[0], live, sbase, zz_lo, zz_hi, 2 * STG_BLK, m * BPM + 2 + bx, queue, FORCE != 0);
+            quant_block_column(F, ks, dl, j, dcq_l, live, sbase, zz_lo, zz_hi, 2 * STG_BLK, m * BPM + 2 + bx, queue, FORCE != 0);
         }
     }
 
@@ -473,8 +486,8 @@ __global__ __launch_bounds__(64 * WPB, JPEZY_F32_WAVES) void fdct_quant_f32_kern
         }
         float ks[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) ks[i] = tab->qscale_f[1][j][i];
-        quant_block_column(Fc, ks, tab->delta1[1][j], j, tab->dcq[1], live, sbase, zz_lo, zz_hi, 4 * STG_BLK, m * BPM + 4 + bx, queue, FORCE != 0);
+        for (int i = 0; i < 8; ++i) ks[i] = lcol[8].ks[i];
+        quant_block_column(Fc, ks, lcol[8].delta1, j, dcq_c, live, sbase, zz_lo, zz_hi, 4 * STG_BLK, m * BPM + 4 + bx, queue, FORCE != 0);
     }
     wave_sync();
 

@@ -76,6 +76,9 @@ struct jpezy_ctx {
     bool dq_valid = false;
     int force_exact = 0;           // 0 normal, 1 everything through the reference-order path, 2 (f32 variant) through level 2
     int variant = 1;               // encode kernel: 0 = FP64 butterflies, 1 = FP32 first level (default: faster)
+#ifdef JPEZY_TRACE
+    unsigned long long* d_trace = nullptr;
+#endif
     DevBuf in[3], out, scratch;    // staging for the host-buffer entry points; scratch: samples of the generic decoder
 };
 
@@ -260,6 +263,10 @@ int jpezy_fdct_quant_dev(jpezy_ctx* c, const uint8_t* d_r, const uint8_t* d_g, c
     p.dcq_luma = c->d_tab->dcq[0];       // address arithmetic only: d_tab is a device pointer
     p.dcq_chroma = c->d_tab->dcq[1];
     p.fallback_count = c->d_counter;
+#ifdef JPEZY_TRACE
+    if (!c->d_trace) HIP_TRY(hipMalloc((void**)&c->d_trace, sizeof(unsigned long long) * 4 * 65536));
+    p.trace = c->d_trace;
+#endif
     p.W = W; p.H = H;
     p.mcu_cols = jpezy_mcu_cols(W);
     p.mcu_rows = jpezy_mcu_rows(H);
@@ -272,6 +279,15 @@ int jpezy_fdct_quant_dev(jpezy_ctx* c, const uint8_t* d_r, const uint8_t* d_g, c
         HIP_TRY(launch_fdct_quant(p, gray != 0, c->force_exact != 0, s));
     return JPEZY_OK;
 }
+
+#ifdef JPEZY_TRACE
+int jpezy_debug_read_trace(jpezy_ctx* c, unsigned long long* host, size_t n)
+{
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(host, c->d_trace, n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return JPEZY_OK;
+}
+#endif
 
 int jpezy_fdct_quant(jpezy_ctx* c, const uint8_t* r, const uint8_t* g, const uint8_t* b, int W, int H, int gray,
                      int n_frames, int16_t* coeffs)

@@ -45,7 +45,10 @@ constexpr int COUNTER_SHARDS = 1024;
 // Waves per workgroup.  Waves never talk to each other (no s_barrier); the only effect of the grouping is which
 // quads share a CU.  Measured on 4096^2 / 32x1080p encode: 2 waves (two adjacent quads = one 128-byte line of every
 // pixel row) is ~4 % faster than 1 or 4.
-constexpr int WPB = 2;
+#ifndef JPEZY_WPB
+#define JPEZY_WPB 2
+#endif
+constexpr int WPB = JPEZY_WPB;
 
 struct EncParams {
     const uint8_t* r;
@@ -60,6 +63,9 @@ struct EncParams {
     unsigned long long* fallback_count;
     int W, H, mcu_cols, mcu_rows, quads_per_row, n_frames;
     unsigned qpr_magic, qpr_shift;   // fast_div by quads_per_row (f32 kernel)
+#ifdef JPEZY_TRACE
+    unsigned long long* trace;       // development builds only (tools/wave_trace.py): 4 words per wave
+#endif
 };
 
 struct DecParams {

@@ -30,6 +30,18 @@ namespace jpezy_dev {
 __constant__ double c_cos[64] = JPEZY_COS_INIT;            // [u*8+x] = cos((2x+1)u*pi/16)
 __constant__ unsigned char c_zzinv[64] = JPEZY_ZZ_INV_INIT;  // natural index -> zig-zag position
 
+// Outputs are streamed out and never re-read by the kernel: a non-temporal store leaves less dirty data in the eight
+// L2s for the end-of-kernel write-back (measured on the f32 encode kernel: 2 us per 4096^2 frame).
+#ifndef JPEZY_NO_NT
+__device__ __forceinline__ void nt_store16(uint4* dst, uint4 v)
+{
+    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+    __builtin_nontemporal_store(v4u{v.x, v.y, v.z, v.w}, reinterpret_cast<v4u*>(dst));
+}
+#else
+__device__ __forceinline__ void nt_store16(uint4* dst, uint4 v) { *dst = v; }
+#endif
+
 #define JPEZY_S JPEZY_INV_SQRT2
 
 // cos(k*pi/16) -- the same correctly rounded doubles as the cos table rows (fast path only)
@@ -414,7 +426,7 @@ __global__ __launch_bounds__(64 * WPB, 4) void fdct_quant_kernel(EncParams p)
 #pragma unroll
         for (int k = 0; k < BPM * 128 * 4 / 1024; ++k) {
             const int c = k * 64 + lane;
-            if (c < valid_chunks) g4[c] = *reinterpret_cast<const uint4*>(stage + (c >> 3) * STG_BLK + (c & 7) * 16);
+            if (c < valid_chunks) nt_store16(g4 + c, *reinterpret_cast<const uint4*>(stage + (c >> 3) * STG_BLK + (c & 7) * 16));
         }
     }
 }
@@ -731,9 +743,9 @@ __global__ __launch_bounds__(64 * WPB, 5) void dequant_idct_kernel(DecParams p)
         uint8_t* obp = p.b + (size_t)frame * p.plane_stride + (size_t)py * W;
         if (ALIGNED) {
             const size_t off = (size_t)mcu_x * 16;
-            *reinterpret_cast<uint4*>(orp + off) = make_uint4(Rw[0], Rw[1], Rw[2], Rw[3]);
-            *reinterpret_cast<uint4*>(ogp + off) = make_uint4(Gw[0], Gw[1], Gw[2], Gw[3]);
-            *reinterpret_cast<uint4*>(obp + off) = make_uint4(Bw[0], Bw[1], Bw[2], Bw[3]);
+            nt_store16(reinterpret_cast<uint4*>(orp + off), make_uint4(Rw[0], Rw[1], Rw[2], Rw[3]));
+            nt_store16(reinterpret_cast<uint4*>(ogp + off), make_uint4(Gw[0], Gw[1], Gw[2], Gw[3]));
+            nt_store16(reinterpret_cast<uint4*>(obp + off), make_uint4(Bw[0], Bw[1], Bw[2], Bw[3]));
         } else {
 #pragma unroll
             for (int k = 0; k < 16; ++k) {

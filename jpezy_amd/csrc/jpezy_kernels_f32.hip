@@ -51,8 +51,11 @@ constexpr int STG_BLK = 144;                // bytes per staged block (128 + 16 
 constexpr int CT_BYTES = 4 * C_MCU * 4;     // 2176: chroma tile, then the staging area behind it
 constexpr int STG_BYTES = 4 * 6 * STG_BLK;  // 3456
 constexpr int TILE_BYTES = (4 * Y_MCU * 4 > CT_BYTES + STG_BYTES) ? 4 * Y_MCU * 4 : CT_BYTES + STG_BYTES;   // 5632
-constexpr int QUEUE_CAP = 510;              // entries; beyond it every coefficient of the quad is resolved (pathological input)
-constexpr int WAVE_LDS_DWORDS = TILE_BYTES / 4 + 256;   // + count word + 510 16-bit entries: 6656 B, 6 waves/SIMD fit in 160 KB
+#ifndef JPEZY_QUEUE_DWORDS
+#define JPEZY_QUEUE_DWORDS 192   // 5632 + 768 = 6400 B per wave: 12800 B per workgroup = 10 LDS granules of 1280 B, 12 workgroups (6 waves/SIMD) per CU
+#endif
+constexpr int QUEUE_CAP = 2 * (JPEZY_QUEUE_DWORDS - 1);   // entries; beyond it every coefficient of the quad is resolved (pathological input)
+constexpr int WAVE_LDS_DWORDS = TILE_BYTES / 4 + JPEZY_QUEUE_DWORDS;   // + count word + 16-bit entries
 
 __device__ __forceinline__ unsigned fast_div(unsigned n, unsigned magic, unsigned shift)
 {
@@ -244,17 +247,26 @@ __device__ __forceinline__ int resolve_coef(const uint32_t* w, bool part, int y,
     return dct / Q;
 }
 
+// Quantised DC of a block from the exact table (DeviceTables::dcq): sum8 = this lane's column sum of eight samples
+// after the row pass -- on the j == 0 lane that is the block's integer sample sum (exact in FP32).  Issued right after
+// the column reads, long before the value is needed, so the L2 latency never sits on a wave's critical path; written
+// with fdct8f's own association so that the adds are shared with it.
+__device__ __forceinline__ int dc_lookup(const float* x, const signed char* dcq)
+{
+    const float s0 = x[0] + x[7], s1 = x[1] + x[6], s2 = x[2] + x[5], s3 = x[3] + x[4];
+    const float sum8 = (s0 + s3) + (s1 + s2);
+    // index = sum + 8192, formed in FP32 (exact) and clamped there (non-DC lanes carry arbitrary values); an
+    // unsigned index keeps the lookup a scalar-base + 32-bit-offset load
+    const unsigned si = (unsigned)(__builtin_fminf(__builtin_fmaxf(sum8, -8192.f), 8192.f) + 8192.f);
+    return dcq[si];
+}
+
 // quantise 8 coefficients of one block column.  Returns the smallest distance |t - rint(t)| over the column (the DC
 // lane skips i == 0): below DELTA1 some coefficient MAY need level 2 -- the caller then looks coefficient by coefficient
 // (a distance below DELTA1 around rint(t) == 0 is not a truncation boundary and is sorted out there, off the hot path).
-// dcq: this table's DC lookup (exact, see DeviceTables::dcq) -- F[0] of the j == 0 lane is the block's integer sum.
-__device__ __forceinline__ float quant8f(const float* F, const float* ks, bool dc_lane, const signed char* dcq, int* q)
+// dc: the block's quantised DC (dc_lookup below) -- only the j == 0 lane uses it.
+__device__ __forceinline__ float quant8f(const float* F, const float* ks, bool dc_lane, int dc, int* q)
 {
-    // issue the DC lookup first: its latency hides behind the other seven coefficients
-    // index = block sum + 8192, formed in FP32 (exact) and clamped there (non-DC lanes carry arbitrary values); an
-    // unsigned index keeps the lookup a scalar-base + 32-bit-offset load
-    const unsigned si = (unsigned)(__builtin_fminf(__builtin_fmaxf(F[0], -8192.f), 8192.f) + 8192.f);
-    const int dc = dcq[si];
     float d[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -270,12 +282,12 @@ __device__ __forceinline__ float quant8f(const float* F, const float* ks, bool d
 
 // base: LDS address of this lane's FIRST block; blk_off: byte offset of the block to write (an immediate after inlining)
 // delta1: this lane's level-1 guard band (DeviceTables::delta1, a function of the table and of the column j)
-__device__ __forceinline__ void quant_block_column(const float* F, const float* ks, float delta1, int j, const signed char* dcq,
+__device__ __forceinline__ void quant_block_column(const float* F, const float* ks, float delta1, int j, int dc,
                                                    bool live, char* base, uint32_t zz_lo, uint32_t zz_hi, int blk_off, int blk,
                                                    unsigned* queue, bool force)
 {
     int q[8];
-    const float dmin = quant8f(F, ks, j == 0, dcq, q);
+    const float dmin = quant8f(F, ks, j == 0, dc, q);
     const bool cand = force || dmin < delta1;
     // rare on noisy content; flat content (exact zeros) enters and finds nothing to queue.  (Lanes that are not live
     // repeat the quad's last MCU, so leaving them in the vote changes nothing and keeps it a bare v_cmp + s_cmp.)
@@ -297,7 +309,8 @@ __device__ __forceinline__ void quant_block_column(const float* F, const float* 
     // zz_lo/zz_hi: byte i = LDS byte offset of natural coefficient (i, j) inside a block (2 * zig-zag index < 128);
     // packed so that the eight addresses cost two registers (one SDWA add per store instead)
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int ii = 1; ii <= 8; ++ii) {      // i = 0 last: it waits for the DC lookup
+        const int i = ii & 7;
         const uint32_t off = ((i < 4 ? zz_lo : zz_hi) >> (8 * (i & 3))) & 0xFFu;
         *reinterpret_cast<int16_t*>(base + off + blk_off) = (int16_t)q[i];
     }
@@ -312,12 +325,18 @@ __global__ __launch_bounds__(64 * WPB, JPEZY_F32_WAVES) void fdct_quant_f32_kern
     // WPB waves per workgroup; the wave index is made an SGPR so that everything derived from it (quad position, plane
     // and coefficient base addresses, the LDS slice) is computed once on the scalar unit
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    // One quad per wave, one launch of exactly as many waves as quads.  (A grid-stride loop over a grid sized to the
+    // resident workgroups was measured: same 4096^2 time -- the kernel's tail comes from XCD-to-XCD variation, which a
+    // static partition cannot balance either -- and 8 more VGPRs.)
     const unsigned qidx = blockIdx.x * (unsigned)WPB + (unsigned)wave;          // quad index inside the frame
     if (qidx >= (unsigned)(p.mcu_rows * p.quads_per_row)) return;     // wave-uniform
     const int frame = (int)blockIdx.y;
     const int mcu_y = (int)fast_div(qidx, p.qpr_magic, p.qpr_shift);
     const int quad_x = (int)qidx - mcu_y * p.quads_per_row;
 
+#ifdef JPEZY_TRACE
+    const unsigned long long tr_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
     uint32_t* lds = lds_all[wave];
     float* ldsf = reinterpret_cast<float*>(lds);
     unsigned* queue = lds + TILE_BYTES / 4;                            // [0] = count, then 16-bit entries
@@ -361,6 +380,10 @@ __global__ __launch_bounds__(64 * WPB, JPEZY_F32_WAVES) void fdct_quant_f32_kern
         }
     }
 
+#ifdef JPEZY_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long tr_t1 = __builtin_amdgcn_s_memrealtime();
+#endif
     // ---- 2. luma + row pass of the left and right block, into the transpose tile.  The integer samples stay in
     //         registers as packed fp16 pairs (ph: luma 16, pc: chroma 8) for the rare levels 2 and 3. ----
     uint32_t ph[8], pc[4] = { 0, 0, 0, 0 };
@@ -446,16 +469,17 @@ __global__ __launch_bounds__(64 * WPB, JPEZY_F32_WAVES) void fdct_quant_f32_kern
 #pragma unroll
         for (int i = 0; i < 8; ++i) ks[i] = lcol->ks[i];
         const float dl = lcol->delta1;
+        const int dc_top = dc_lookup(col, dcq_l), dc_bot = dc_lookup(col + 8, dcq_l);
         {
             float F[8];
             fdct8f(col, F);
-            quant_block_column(F, ks, dl, j, dcq_l, live, sbase, zz_lo, zz_hi, 0, m * BPM + bx, queue, FORCE != 0);
+            quant_block_column(F, ks, dl, j, dc_top, live, sbase, zz_lo, zz_hi, 0, m * BPM + bx, queue, FORCE != 0);
         }
         __builtin_amdgcn_sched_barrier(0);
         {
             float F[8];
             fdct8f(col + 8, F);
-            quant_block_column(F, ks, dl, j, dcq_l, live, sbase, zz_lo, zz_hi, 2 * STG_BLK, m * BPM + 2 + bx, queue, FORCE != 0);
+            quant_block_column(F, ks, dl, j, dc_bot, live, sbase, zz_lo, zz_hi, 2 * STG_BLK, m * BPM + 2 + bx, queue, FORCE != 0);
         }
     }
 
@@ -477,17 +501,19 @@ __global__ __launch_bounds__(64 * WPB, JPEZY_F32_WAVES) void fdct_quant_f32_kern
         wave_sync();
 
         float Fc[8];
+        int dc_c;
         {
             float col[8];
             const float* src = ldsf + m * C_MCU + (cq >> 3) * C_COMP + j;
 #pragma unroll
             for (int rr = 0; rr < 8; ++rr) col[rr] = src[rr * C_PITCH];
+            dc_c = dc_lookup(col, dcq_c);
             fdct8f(col, Fc);
         }
         float ks[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) ks[i] = lcol[8].ks[i];
-        quant_block_column(Fc, ks, lcol[8].delta1, j, dcq_c, live, sbase, zz_lo, zz_hi, 4 * STG_BLK, m * BPM + 4 + bx, queue, FORCE != 0);
+        quant_block_column(Fc, ks, lcol[8].delta1, j, dc_c, live, sbase, zz_lo, zz_hi, 4 * STG_BLK, m * BPM + 4 + bx, queue, FORCE != 0);
     }
     wave_sync();
 
@@ -521,11 +547,14 @@ __global__ __launch_bounds__(64 * WPB, JPEZY_F32_WAVES) void fdct_quant_f32_kern
                 if (lane == 0) *reinterpret_cast<int16_t*>(stage + blk * STG_BLK + 2 * (int)c_zzinv[nat]) = (int16_t)qv;
                 ++done;
             }
-            if (lane == 0 && done) atomicAdd(p.fallback_count + ((blockIdx.x * (unsigned)WPB + wave) & (COUNTER_SHARDS - 1)), (unsigned long long)done);
+            if (lane == 0 && done) atomicAdd(p.fallback_count + (qidx & (COUNTER_SHARDS - 1)), (unsigned long long)done);
             wave_sync();
         }
     }
 
+#ifdef JPEZY_TRACE
+    const unsigned long long tr_t2 = __builtin_amdgcn_s_memrealtime();
+#endif
     // ---- 6. coalesced store of the quad's coefficients ----
     {
         const int valid_chunks = min(4, p.mcu_cols - quad_x * 4) * BPM * 8;         // 16-byte chunks
@@ -535,9 +564,30 @@ __global__ __launch_bounds__(64 * WPB, JPEZY_F32_WAVES) void fdct_quant_f32_kern
 #pragma unroll
         for (int k = 0; k < BPM * 128 * 4 / 1024; ++k) {
             const int c = k * 64 + lane;
-            if (c < valid_chunks) g4[c] = *reinterpret_cast<const uint4*>(stage + (c >> 3) * STG_BLK + (c & 7) * 16);
+            if (c < valid_chunks) {
+                // streamed out, never re-read by this kernel: a non-temporal store leaves less dirty data in the L2s
+                // for the end-of-kernel write-back (measured: 2 us per 4096^2 frame)
+                const uint4 v = *reinterpret_cast<const uint4*>(stage + (c >> 3) * STG_BLK + (c & 7) * 16);
+                typedef unsigned v4u __attribute__((ext_vector_type(4)));
+                __builtin_nontemporal_store(v4u{v.x, v.y, v.z, v.w}, reinterpret_cast<v4u*>(g4 + c));
+            }
         }
     }
+#ifdef JPEZY_TRACE
+    if (frame == 0 && qidx < 65536u) {
+#if JPEZY_TRACE > 1
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        const unsigned long long tr_t3 = __builtin_amdgcn_s_memrealtime();
+        const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+        if (lane == 0) {
+            p.trace[qidx * 4 + 0] = tr_t0;
+            p.trace[qidx * 4 + 1] = ((tr_t1 - tr_t0) << 32) | (tr_t2 - tr_t0);
+            p.trace[qidx * 4 + 2] = tr_t3 - tr_t0;
+            p.trace[qidx * 4 + 3] = ((unsigned long long)xcc << 32) | hw;
+        }
+    }
+#endif
 }
 
 }  // namespace f32

@@ -9,8 +9,6 @@ namespace jpezy_dev {
 // Fixed-point scale of the quantiser guard band: a coefficient is v/Q * 2^QFRAC_BITS truncated to int32.
 // |v/Q| <= 1024/10 with the Annex-K tables, so 2^24 keeps |n| < 2^31.
 constexpr int QFRAC_BITS = 24;
-// IDCT samples: (sum/4+128) * 2^SFRAC_BITS; samples outside +-2^(30-SFRAC_BITS) take the exact path.
-constexpr int SFRAC_BITS = 18;
 
 // Per (table, block column j) record of the f32 encode kernel: one 64-byte line per lane, three loads off one address.
 struct F32Column {
@@ -80,6 +78,7 @@ struct DecParams {
     int coef_limit;           // 32768 / largest quantiser: raw coefficients above it send the wave to the exact path
     unsigned long long* fallback_count;
     int W, H, mcu_cols, mcu_rows, quads_per_row, n_frames;
+    unsigned qpr_magic, qpr_shift;   // fast_div by quads_per_row (set by the launcher)
 };
 
 // (magic, shift) such that n / d == (((n - mulhi(n, magic)) >> 1) + mulhi(n, magic)) >> shift for all 32-bit n;

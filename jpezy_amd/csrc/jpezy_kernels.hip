@@ -30,6 +30,15 @@ namespace jpezy_dev {
 __constant__ double c_cos[64] = JPEZY_COS_INIT;            // [u*8+x] = cos((2x+1)u*pi/16)
 __constant__ unsigned char c_zzinv[64] = JPEZY_ZZ_INV_INIT;  // natural index -> zig-zag position
 
+__device__ __forceinline__ unsigned fast_div(unsigned n, unsigned magic, unsigned shift)   // see fast_div_setup
+{
+    const unsigned q = __umulhi(n, magic);
+    return magic ? (((n - q) >> 1) + q) >> shift : n;
+}
+
+// wave-uniform "some lane": one v_cmp into an SGPR pair + s_cmp (HIP's __any goes through a 0/1 VGPR)
+__device__ __forceinline__ bool wave_any(bool x) { return __builtin_amdgcn_ballot_w64(x) != 0ull; }
+
 // Outputs are streamed out and never re-read by the kernel: a non-temporal store leaves less dirty data in the eight
 // L2s for the end-of-kernel write-back (measured on the f32 encode kernel: 2 us per 4096^2 frame).
 #ifndef JPEZY_NO_NT
@@ -452,16 +461,39 @@ __device__ __forceinline__ int exact_idct_sample_sparse(const int2* __restrict__
     return (int)(sum / 4 + 128);
 }
 
-// fixed-point sample + guard flag from the fast row sum
-__device__ __forceinline__ int sample_fx(double sum, bool& flag)
+// Sample of the reference, int(sum / 4 + 128) (ref :667), from the fast row sum, plus the guard key of the fast path:
+// e = fract(v) - 1/2 in FP32, so that v is within eps of an integer  <=>  |e| > 1/2 - eps.  v_cvt_i32_f64 truncates
+// toward zero like the reference's int() and saturates; a wild v has fract(v) == 0, i.e. |e| == 1/2: flagged.
+// The fast sum is within 2e-10 of the reference's sum, the conversion of fract(v) to FP32 adds 3e-8, and
+// SAMPLE_EPS = 2^-18 is far above both.  Eight keys are reduced with v_max3; the per-sample flag bits are only formed
+// when the reduction says that some lane of the wave has a sample in the band.
+constexpr float SAMPLE_EPS = 0x1p-18f;
+constexpr float SAMPLE_TH = 0.5f - SAMPLE_EPS;
+__device__ __forceinline__ int sample_of(double sum, float& e)
 {
-    constexpr int MASK = (1 << SFRAC_BITS) - 1;
-    const double t = FMA(sum, (double)(1 << (SFRAC_BITS - 2)), (double)(128 << SFRAC_BITS));   // (sum/4+128)*2^18
-    // v_cvt_i32_f64 saturates (and maps NaN to 0): an out-of-range sample yields INT_MAX / INT_MIN / 0, all of which
-    // satisfy the boundary test below, so wild values take the exact path without a separate range check
-    const int n = (int)t;
-    flag = (unsigned)((n + 1) & MASK) <= 2u;
-    return (n + ((n >> 31) & MASK)) >> SFRAC_BITS;
+    const double v = FMA(sum, 0.25, 128.0);          // == fl(sum / 4 + 128): the scaling is exact
+    e = (float)__builtin_amdgcn_fract(v) - 0.5f;
+    return (int)v;
+}
+__device__ __forceinline__ float absmax8(const float* e)
+{
+    return __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(e[0]), __builtin_fabsf(e[1])),
+                                           __builtin_fmaxf(__builtin_fabsf(e[2]), __builtin_fabsf(e[3]))),
+                           __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(e[4]), __builtin_fabsf(e[5])),
+                                           __builtin_fmaxf(__builtin_fabsf(e[6]), __builtin_fabsf(e[7]))));
+}
+// flag bits (bit k: sample k is inside the guard band) of eight samples; dc_only: the block's samples are exact by
+// construction (step 2 of the kernel) and exempt.  The bits are only spelled out when some lane needs them.
+__device__ __forceinline__ unsigned guard_bits8(const float* e, bool dc_only)
+{
+    const float em = dc_only ? 0.f : absmax8(e);
+    unsigned bits = 0;
+    if (wave_any(em > SAMPLE_TH)) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) bits |= (__builtin_fabsf(e[k]) > SAMPLE_TH ? 1u : 0u) << k;
+        if (dc_only) bits = 0;
+    }
+    return bits;
 }
 
 __device__ __forceinline__ uint32_t clamp_byte(double v)   // revise_value, ref :672-676
@@ -476,14 +508,14 @@ __global__ __launch_bounds__(64 * WPB, 5) void dequant_idct_kernel(DecParams p)
     __shared__ __attribute__((aligned(16))) uint32_t lds_all[WPB][DEC_LDS_DWORDS];
     constexpr int BPM = 6;
 
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;   // WPB waves per workgroup
-    const long quad = (long)blockIdx.x * WPB + wave;
-    const long quads_per_frame = (long)p.mcu_rows * p.quads_per_row;
-    if (quad >= quads_per_frame * p.n_frames) return;
-    const int frame = (int)(quad / quads_per_frame);
-    const int qrem = (int)(quad - (long)frame * quads_per_frame);
-    const int mcu_y = qrem / p.quads_per_row;
-    const int quad_x = qrem - mcu_y * p.quads_per_row;
+    // WPB waves per workgroup; grid: x = quads of one frame / WPB, y = frame.  The wave index is made an SGPR so that the
+    // quad position and every base address are computed once on the scalar unit.
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const unsigned qrem = blockIdx.x * (unsigned)WPB + (unsigned)wave;
+    if (qrem >= (unsigned)(p.mcu_rows * p.quads_per_row)) return;      // wave-uniform
+    const int frame = (int)blockIdx.y;
+    const int mcu_y = (int)fast_div(qrem, p.qpr_magic, p.qpr_shift);
+    const int quad_x = (int)qrem - mcu_y * p.quads_per_row;
 
     uint32_t* lds = lds_all[wave];
     if (lane == 0) lds[DEC_TILE_DWORDS] = 0;                    // exact-path block mask
@@ -570,7 +602,7 @@ __global__ __launch_bounds__(64 * WPB, 5) void dequant_idct_kernel(DecParams p)
     const bool dc_only_cb = ((unsigned)ac_chr & colbits) == 0, dc_only_cr = ((unsigned)(ac_chr >> 32) & colbits) == 0;
     // fast path is only trusted for sane magnitudes: |coef| <= coef_limit = 32768 / max quantiser keeps every
     // dequantised input below 2^15 (error bound); wave-uniform decision
-    const bool force = FORCE_EXACT || __any(max(cmx, -cmn) > p.coef_limit);
+    const bool force = FORCE_EXACT || wave_any(max(cmx, -cmn) > p.coef_limit);
     wave_sync();   // staging consumed (the exact path re-reads coefficients from global memory)
 
     // ---- 3. transpose in two halves: the lanes holding the LEFT block columns (cq < 8) publish them, every lane
@@ -594,16 +626,13 @@ __global__ __launch_bounds__(64 * WPB, 5) void dequant_idct_kernel(DecParams p)
 #pragma unroll
             for (int k = 0; k < 4; ++k) { const double2 t = src[k]; in[2 * k] = t.x; in[2 * k + 1] = t.y; }
             idct8(in, out);
+            float e[8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                bool f;
-                Y[half * 8 + k] = sample_fx(out[k], f);
-                yflags |= (f ? 1u : 0u) << (half * 8 + k);
-            }
+            for (int k = 0; k < 8; ++k) Y[half * 8 + k] = sample_of(out[k], e[k]);
+            yflags |= guard_bits8(e, half ? dc_only_r : dc_only_l) << (half * 8);
         }
         wave_sync();   // the half tile was read; it is rewritten next
     }
-    yflags &= ~((dc_only_l ? 0x00FFu : 0u) | (dc_only_r ? 0xFF00u : 0u));   // exact by construction, see step 2
     if (force) yflags = 0xFFFFu;
     int Cb[8], Cr[8];
     unsigned cflags = 0;
@@ -625,15 +654,15 @@ __global__ __launch_bounds__(64 * WPB, 5) void dequant_idct_kernel(DecParams p)
         }
         idct8(in, out);
         idct8(in + 8, out + 8);
+        {
+            float e[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            bool f;
-            Cb[k] = sample_fx(out[k], f);
-            cflags |= (f ? 1u : 0u) << k;
-            Cr[k] = sample_fx(out[8 + k], f);
-            cflags |= (f ? 1u : 0u) << (8 + k);
+            for (int k = 0; k < 8; ++k) Cb[k] = sample_of(out[k], e[k]);
+            cflags = guard_bits8(e, dc_only_cb);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) Cr[k] = sample_of(out[8 + k], e[k]);
+            cflags |= guard_bits8(e, dc_only_cr) << 8;
         }
-        cflags &= ~((dc_only_cb ? 0x00FFu : 0u) | (dc_only_cr ? 0xFF00u : 0u));
         if (force) cflags = 0xFFFFu;
     }
     if (!live) { yflags = 0; cflags = 0; }
@@ -710,7 +739,7 @@ __global__ __launch_bounds__(64 * WPB, 5) void dequant_idct_kernel(DecParams p)
                 }
                 wave_sync();
             }
-            if (done) atomicAdd(p.fallback_count + ((blockIdx.x * (unsigned)WPB + wave) & (COUNTER_SHARDS - 1)), (unsigned long long)done);
+            if (done) atomicAdd(p.fallback_count + (qrem & (COUNTER_SHARDS - 1)), (unsigned long long)done);
         }
     }
 
@@ -798,11 +827,14 @@ static void dec_launch2(const DecParams& p, bool force, dim3 grid, hipStream_t s
         hipLaunchKernelGGL((dequant_idct_kernel<GRAY, ALIGNED, false>), grid, dim3(64 * WPB), 0, s, p);
 }
 
-hipError_t launch_dequant_idct(const DecParams& p, bool gray, bool force_exact, hipStream_t stream)
+hipError_t launch_dequant_idct(const DecParams& p0, bool gray, bool force_exact, hipStream_t stream)
 {
-    const long quads = (long)p.n_frames * p.mcu_rows * p.quads_per_row;
-    if (quads <= 0) return hipSuccess;
-    const dim3 grid((unsigned)((quads + WPB - 1) / WPB));
+    const long quads = (long)p0.mcu_rows * p0.quads_per_row;
+    if (quads <= 0 || p0.n_frames <= 0) return hipSuccess;
+    if (p0.n_frames > 65535) return hipErrorInvalidValue;              // grid.y limit; callers chunk larger batches
+    DecParams p = p0;
+    fast_div_setup((unsigned)p.quads_per_row, &p.qpr_magic, &p.qpr_shift);
+    const dim3 grid((unsigned)((quads + WPB - 1) / WPB), (unsigned)p.n_frames);
     const bool al = is_aligned16(p, p.r, p.g, p.b);
     if (gray) { if (al) dec_launch2<true, true>(p, force_exact, grid, stream); else dec_launch2<true, false>(p, force_exact, grid, stream); }
     else      { if (al) dec_launch2<false, true>(p, force_exact, grid, stream); else dec_launch2<false, false>(p, force_exact, grid, stream); }

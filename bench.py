@@ -161,6 +161,25 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed, ev_ms = float(t[0]), float(t[1])
 
+    # besides the vendor peak, report a device-copy bandwidth measured on this box with the same byte count
+    # and the same ring (one plain copy kernel per step: half the bytes read, half written)
+    copy_gbs = None
+    if rank == 0:
+        half = step_bytes // 2
+        src_bufs = torch.empty((ring, half), dtype=torch.uint8, device=dev)
+        dst_bufs = torch.empty((ring, half), dtype=torch.uint8, device=dev)
+        for i in range(5):
+            dst_bufs[i % ring].copy_(src_bufs[i % ring])
+        c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 50
+        c0.record(stream)
+        for i in range(reps):
+            dst_bufs[i % ring].copy_(src_bufs[i % ring])
+        c1.record(stream)
+        torch.cuda.synchronize(dev)
+        copy_gbs = 2 * half * reps / (c0.elapsed_time(c1) * 1e-3) / 1e9
+        del src_bufs, dst_bufs
+
     gather = None
     if world > 1 and not args.no_gather:
         # north_star: gather the coefficient buffers over xGMI -- jpezy_amd.sharding.gather_coefficients,
@@ -220,7 +239,8 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "kernel": ("f32::fdct_quant_f32_kernel" if args.variant in (None, 1) else "fdct_quant_kernel")
                          if direction == "encode" else "dequant_idct_kernel",
-                         "algorithmic_bytes_per_launch": step_bytes, "avg_launch_ms_hip_events": round(kern_ms, 5)},
+                         "algorithmic_bytes_per_launch": step_bytes, "avg_launch_ms_hip_events": round(kern_ms, 5),
+                         "device_copy_GBs_measured": round(copy_gbs, 1), "frac_of_device_copy": round(achieved / copy_gbs, 4)},
             "exact_fallbacks_per_step": round(nfallback / max(1, args.steps), 2),
         }
         if gather:

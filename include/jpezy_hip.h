@@ -141,6 +141,24 @@ size_t jpezy_jpeg_bound(int W, int H);   /* a cap that always suffices */
 int jpezy_write_jpeg_batch(const int16_t* coeffs, int W, int H, int gray, int n_frames, const char* comment,
                            uint8_t* out, size_t cap, long* sizes, int threads);
 
+/*
+ * The same tail on the GPU ("entropy coding off the critical path"): coefficients already in device
+ * memory (the output of jpezy_fdct_quant_dev), bytes identical to jpezy_write_jpeg.  pre_DC (encoder/jpezy_encoder.hpp:
+ * 180-181) becomes a read of the previous block's DC and the bit cursor a prefix sum of the blocks' code lengths; the
+ * 0xFF00 stuffing of the reference's bofstream is a second prefix sum.  out/sizes are host memory: frame f writes at
+ * most cap bytes at out + f*cap and sizes[f] receives its length or a negative status.  Synchronous.
+ */
+long jpezy_write_jpeg_gpu(jpezy_ctx* ctx, const int16_t* d_coeffs, int W, int H, int gray, const char* comment,
+                          uint8_t* out, size_t cap);
+int jpezy_write_jpeg_gpu_batch(jpezy_ctx* ctx, const int16_t* d_coeffs, int W, int H, int gray, int n_frames,
+                               const char* comment, uint8_t* out, size_t cap, long* sizes);
+/*
+ * encoder::encode end to end (encoder/jpezy_encoder.hpp:38-77) with both stages on the GPU: host planar r,g,b in,
+ * host .jpg bytes out; returns the byte count (the value encoder::encode returns) or a negative status.
+ */
+long jpezy_encode_jpeg(jpezy_ctx* ctx, const uint8_t* r, const uint8_t* g, const uint8_t* b, int W, int H, int gray,
+                       const char* comment, uint8_t* out, size_t cap);
+
 typedef struct jpezy_frame_info {
     int width, height, ncomp, precision;
     int H[3], V[3], Tq[3];

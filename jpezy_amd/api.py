@@ -60,6 +60,9 @@ ABI = [
     ("jpezy_write_jpeg", C.c_long, [_vp, C.c_int, C.c_int, C.c_int, C.c_char_p, _vp, C.c_size_t]),
     ("jpezy_jpeg_bound", C.c_size_t, [C.c_int, C.c_int]),
     ("jpezy_write_jpeg_batch", C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, _vp, C.c_size_t, C.POINTER(C.c_long), C.c_int]),
+    ("jpezy_write_jpeg_gpu", C.c_long, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_char_p, _vp, C.c_size_t]),
+    ("jpezy_write_jpeg_gpu_batch", C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, _vp, C.c_size_t, C.POINTER(C.c_long)]),
+    ("jpezy_encode_jpeg", C.c_long, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_char_p, _vp, C.c_size_t]),
     ("jpezy_read_jpeg", C.c_int, [_vp, C.c_size_t, C.POINTER(FrameInfo), _vp, C.c_size_t]),
 ]
 
@@ -200,6 +203,34 @@ class Context:
         stride = plane_stride if plane_stride is not None else W * H
         _check(load_library().jpezy_fdct_quant_dev(self._h, d_r.data_ptr(), d_g.data_ptr(), d_b.data_ptr(), stride, W, H,
                                                    int(gray), n_frames, d_coeffs.data_ptr(), stream))
+
+    # ---- entropy coding on the GPU: same bytes as write_jpeg ----
+    def write_jpeg_gpu(self, d_coeffs, W, H, gray=False, comment=None, n_frames=1):
+        """Device coefficients (torch int16 tensor, the output of fdct_quant_dev; its producing stream must be
+        synchronised) -> list of .jpg bytes, Huffman coding + bit packing + byte stuffing on the GPU."""
+        lib = load_library()
+        if comment is None:
+            comment = b"Encoded by JPEZY" if gray else b"Encoded by jpezy"
+        cap = lib.jpezy_jpeg_bound(W, H)
+        buf = np.empty(cap * n_frames, dtype=np.uint8)
+        sizes = (C.c_long * n_frames)()
+        rc = lib.jpezy_write_jpeg_gpu_batch(self._h, d_coeffs.data_ptr(), W, H, int(gray), n_frames, comment, _np_ptr(buf), cap, sizes)
+        _check(rc)
+        return [buf[f * cap: f * cap + sizes[f]].tobytes() for f in range(n_frames)]
+
+    def encode_jpeg(self, r, g, b, W, H, gray=False, comment=None):
+        """Host planes -> .jpg bytes, both stages on the GPU (encoder::encode end to end)."""
+        lib = load_library()
+        r, g, b = (np.ascontiguousarray(p, dtype=np.uint8).reshape(-1) for p in (r, g, b))
+        if not (r.size == g.size == b.size == W * H):
+            raise JpezyError("plane size does not match W*H")
+        if comment is None:
+            comment = b"Encoded by JPEZY" if gray else b"Encoded by jpezy"
+        cap = lib.jpezy_jpeg_bound(W, H)
+        buf = np.empty(cap, dtype=np.uint8)
+        n = lib.jpezy_encode_jpeg(self._h, _np_ptr(r), _np_ptr(g), _np_ptr(b), W, H, int(gray), comment, _np_ptr(buf), cap)
+        _check(n)
+        return buf[:n].tobytes()
 
     def dequant_idct_dev(self, d_coeffs, W, H, d_r, d_g, d_b, qt=None, comp_tq=(0, 1, 1), gray=False, n_frames=1,
                          plane_stride=None, stream=None):

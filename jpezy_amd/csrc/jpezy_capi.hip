@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <algorithm>
 #include <atomic>
 #include <string>
 #include <thread>
@@ -14,6 +15,7 @@
 #include "../../include/jpezy_constants.h"
 #include "../../include/jpezy_hip.h"
 #include "jpezy_device.h"
+#include "jpezy_entropy.h"
 #include "jpezy_host_codec.h"
 
 using namespace jpezy_dev;
@@ -80,6 +82,11 @@ struct jpezy_ctx {
     unsigned long long* d_trace = nullptr;
 #endif
     DevBuf in[3], out, scratch;    // staging for the host-buffer entry points; scratch: samples of the generic decoder
+    // GPU entropy coder (jpezy_entropy.hip): code tables + scratch
+    jpezy_dev::entropy::CodeTables* d_codes = nullptr;
+    DevBuf e_bits, e_off, e_tmp, e_small, e_U, e_cnt, e_ffoff, e_out, e_coef;
+    uint8_t* e_pinned = nullptr;   // pinned host staging of the stuffed streams
+    size_t e_pinned_cap = 0;
 };
 
 extern "C" {
@@ -198,6 +205,9 @@ void jpezy_ctx_destroy(jpezy_ctx* c)
     for (auto& b : c->in) b.release();
     c->out.release();
     c->scratch.release();
+    if (c->d_codes) (void)hipFree(c->d_codes);
+    if (c->e_pinned) (void)hipHostFree(c->e_pinned);
+    for (DevBuf* b : { &c->e_bits, &c->e_off, &c->e_tmp, &c->e_small, &c->e_U, &c->e_cnt, &c->e_ffoff, &c->e_out, &c->e_coef }) b->release();
     delete c;
 }
 
@@ -273,10 +283,18 @@ int jpezy_fdct_quant_dev(jpezy_ctx* c, const uint8_t* d_r, const uint8_t* d_g, c
     p.quads_per_row = (p.mcu_cols + 3) / 4;
     p.n_frames = n_frames;
     fast_div_setup((unsigned)p.quads_per_row, &p.qpr_magic, &p.qpr_shift);
-    if (c->variant == 1)
-        HIP_TRY(launch_fdct_quant_f32(p, gray != 0, c->force_exact, s));
-    else
-        HIP_TRY(launch_fdct_quant(p, gray != 0, c->force_exact != 0, s));
+    // the f32 kernel puts the frame index in grid.y (at most 65535): larger batches go out in chunks
+    constexpr int kMaxFramesPerLaunch = 65535;
+    for (int f0 = 0; f0 < n_frames; f0 += kMaxFramesPerLaunch) {
+        EncParams q = p;
+        q.n_frames = n_frames - f0 < kMaxFramesPerLaunch ? n_frames - f0 : kMaxFramesPerLaunch;
+        q.r += (size_t)f0 * plane_stride; q.g += (size_t)f0 * plane_stride; q.b += (size_t)f0 * plane_stride;
+        q.coeffs += (size_t)f0 * p.coeffs_per_frame;
+        if (c->variant == 1)
+            HIP_TRY(launch_fdct_quant_f32(q, gray != 0, c->force_exact, s));
+        else
+            HIP_TRY(launch_fdct_quant(q, gray != 0, c->force_exact != 0, s));
+    }
     return JPEZY_OK;
 }
 
@@ -368,7 +386,14 @@ int jpezy_dequant_idct_dev(jpezy_ctx* c, const int16_t* d_coeffs, const uint16_t
     p.mcu_rows = jpezy_mcu_rows(H);
     p.quads_per_row = (p.mcu_cols + 3) / 4;
     p.n_frames = n_frames;
-    HIP_TRY(launch_dequant_idct(p, gray != 0, c->force_exact != 0, s));
+    constexpr int kMaxFramesPerLaunch = 65535;           // grid.y
+    for (int f0 = 0; f0 < n_frames; f0 += kMaxFramesPerLaunch) {
+        DecParams q = p;
+        q.n_frames = n_frames - f0 < kMaxFramesPerLaunch ? n_frames - f0 : kMaxFramesPerLaunch;
+        q.coeffs += (size_t)f0 * p.coeffs_per_frame;
+        q.r += (size_t)f0 * plane_stride; q.g += (size_t)f0 * plane_stride; q.b += (size_t)f0 * plane_stride;
+        HIP_TRY(launch_dequant_idct(q, gray != 0, c->force_exact != 0, s));
+    }
     return JPEZY_OK;
 }
 
@@ -481,6 +506,173 @@ int jpezy_write_jpeg_batch(const int16_t* coeffs, int W, int H, int gray, int n_
     work();
     for (auto& t : pool) t.join();
     return failed.load() ? set_err(JPEZY_E_FORMAT, "write_jpeg_batch: at least one frame failed (see sizes[])") : JPEZY_OK;
+}
+
+// ---- GPU entropy coding: same bytes as jpezy_write_jpeg, coefficients already on the device ----
+namespace {
+
+int ensure_code_tables(jpezy_ctx* c)
+{
+    if (c->d_codes) return JPEZY_OK;
+    uint16_t code[4][256];
+    uint8_t len[4][256];
+    jpezy_host::enc_code_tables(code, len);
+    static jpezy_dev::entropy::CodeTables h;
+    std::memset(&h, 0, sizeof h);
+    for (int t = 0; t < 2; ++t) {      // DHT order: YDc, CDc, YAc, CAc
+        for (int k = 0; k < 12; ++k) h.dc[t][k] = ((uint32_t)code[t][k] << 8) | len[t][k];
+        for (int k = 0; k < 256; ++k) h.ac[t][k] = ((uint32_t)code[2 + t][k] << 8) | len[2 + t][k];
+    }
+    HIP_TRY(hipMalloc((void**)&c->d_codes, sizeof h));
+    HIP_TRY(hipMemcpy(c->d_codes, &h, sizeof h, hipMemcpyHostToDevice));
+    return JPEZY_OK;
+}
+
+// one chunk of frames, all resident in the scratch buffers
+int entropy_chunk(jpezy_ctx* c, const int16_t* d_coeffs, int W, int H, int gray, int F, const char* comment, uint8_t* out,
+                  size_t cap, long* sizes, bool* any_failed)
+{
+    namespace E = jpezy_dev::entropy;
+    hipStream_t s = c->stream;
+    const size_t nmcu = (size_t)jpezy_mcu_cols(W) * jpezy_mcu_rows(H);
+    const size_t nblk = nmcu * 6, N = nblk * (size_t)F;
+    E::Job job;
+    job.coeffs = d_coeffs;
+    job.coeffs_per_frame = jpezy_coeff_count(W, H, gray);
+    job.tables = c->d_codes;
+    job.blocks_per_frame = (unsigned)nblk;
+    job.bpm = gray ? 4 : 6;
+    job.n_frames = F;
+
+    if (int rc = c->e_bits.reserve(N * sizeof(uint32_t))) return rc;
+    if (int rc = c->e_off.reserve((N + 1) * sizeof(unsigned long long))) return rc;
+    if (int rc = c->e_tmp.reserve(E::scan_tmp_elems(N) * sizeof(unsigned long long))) return rc;
+    // small arrays: [F] status u32 | [F] bit totals | [F] stream bytes | [F] 0xFF totals
+    const size_t small_words = (size_t)F * 8;
+    if (int rc = c->e_small.reserve(small_words * sizeof(unsigned long long))) return rc;
+    unsigned* d_status = (unsigned*)c->e_small.p;
+    unsigned long long* d_tot = (unsigned long long*)c->e_small.p + F;
+    unsigned long long* d_bytes = d_tot + F;
+    unsigned long long* d_fftot = d_bytes + F;
+
+    // 1. code lengths, bit offsets
+    HIP_TRY(hipMemsetAsync(d_status, 0, sizeof(unsigned) * F, s));
+    HIP_TRY(E::launch_block_bits(job, (uint32_t*)c->e_bits.p, d_status, s));
+    HIP_TRY(E::launch_scan_u32((const uint32_t*)c->e_bits.p, (unsigned long long*)c->e_off.p, N, (unsigned long long*)c->e_tmp.p, s));
+    HIP_TRY(E::launch_frame_totals((const unsigned long long*)c->e_off.p, nblk, F, d_tot, s));
+    std::vector<unsigned long long> tot(F), nbytes(F), fftot(F);
+    std::vector<unsigned> status(F);
+    HIP_TRY(hipMemcpyAsync(tot.data(), d_tot, sizeof(unsigned long long) * F, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(status.data(), d_status, sizeof(unsigned) * F, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+
+    // 2. unstuffed streams, one per frame, at a common stride
+    unsigned long long max_bytes = 0;
+    for (int f = 0; f < F; ++f) {
+        nbytes[f] = (tot[f] + 7) / 8;                 // the last byte is padded with zero bits (U is zeroed)
+        if (nbytes[f] > max_bytes) max_bytes = nbytes[f];
+    }
+    const size_t chunk = E::chunk_bytes();
+    const size_t u_stride = ((size_t)max_bytes + 8 + chunk - 1) / chunk * chunk;
+    if (int rc = c->e_U.reserve(u_stride * F)) return rc;
+    HIP_TRY(hipMemsetAsync(c->e_U.p, 0, u_stride * F, s));
+    HIP_TRY(hipMemcpyAsync(d_bytes, nbytes.data(), sizeof(unsigned long long) * F, hipMemcpyHostToDevice, s));
+    HIP_TRY(E::launch_emit(job, (const unsigned long long*)c->e_off.p, (uint32_t*)c->e_U.p, u_stride / 4, s));
+
+    // 3. byte stuffing
+    const size_t nchunks = u_stride / chunk * F;
+    if (int rc = c->e_cnt.reserve(nchunks * sizeof(uint32_t))) return rc;
+    if (int rc = c->e_ffoff.reserve((nchunks + 1) * sizeof(unsigned long long))) return rc;
+    if (int rc = c->e_tmp.reserve(E::scan_tmp_elems(nchunks > N ? nchunks : N) * sizeof(unsigned long long))) return rc;
+    HIP_TRY(E::launch_ff_count((const uint32_t*)c->e_U.p, u_stride / 4, d_bytes, F, (uint32_t*)c->e_cnt.p, s));
+    HIP_TRY(E::launch_scan_u32((const uint32_t*)c->e_cnt.p, (unsigned long long*)c->e_ffoff.p, nchunks, (unsigned long long*)c->e_tmp.p, s));
+    HIP_TRY(E::launch_frame_totals((const unsigned long long*)c->e_ffoff.p, u_stride / chunk, F, d_fftot, s));
+    HIP_TRY(hipMemcpyAsync(fftot.data(), d_fftot, sizeof(unsigned long long) * F, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    unsigned long long max_out = 0;
+    for (int f = 0; f < F; ++f)
+        if (nbytes[f] + fftot[f] > max_out) max_out = nbytes[f] + fftot[f];
+    const size_t o_stride = ((size_t)max_out + 2 + 63) / 64 * 64;
+    if (int rc = c->e_out.reserve(o_stride * F)) return rc;
+    HIP_TRY(E::launch_stuff((const uint32_t*)c->e_U.p, u_stride / 4, d_bytes, F, (const unsigned long long*)c->e_ffoff.p,
+                            (uint8_t*)c->e_out.p, o_stride, s));
+
+    // 4. header + entropy-coded segment + EOI into the caller's buffers.  One device-to-host copy of all streams into a
+    //    pinned staging buffer (per-frame copies into pageable memory cost more than the kernels for small frames).
+    if (c->e_pinned_cap < o_stride * F) {
+        if (c->e_pinned) (void)hipHostFree(c->e_pinned);
+        c->e_pinned = nullptr;
+        c->e_pinned_cap = 0;
+        HIP_TRY(hipHostMalloc((void**)&c->e_pinned, o_stride * F, hipHostMallocDefault));
+        c->e_pinned_cap = o_stride * F;
+    }
+    HIP_TRY(hipMemcpyAsync(c->e_pinned, c->e_out.p, o_stride * F, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    for (int f = 0; f < F; ++f) {
+        uint8_t* dst = out + (size_t)f * cap;
+        if (status[f]) { sizes[f] = JPEZY_E_FORMAT; *any_failed = true; continue; }
+        const size_t hdr = jpezy_host::write_header(W, H, comment, dst, cap);
+        const size_t body = (size_t)(nbytes[f] + fftot[f]);
+        if (!hdr || hdr + body + 2 > cap) { sizes[f] = JPEZY_E_NOSPACE; *any_failed = true; continue; }
+        std::memcpy(dst + hdr, c->e_pinned + (size_t)f * o_stride, body);
+        dst[hdr + body] = 0xFF;
+        dst[hdr + body + 1] = 0xD9;
+        sizes[f] = (long)(hdr + body + 2);
+    }
+    return JPEZY_OK;
+}
+
+}  // namespace
+
+int jpezy_write_jpeg_gpu_batch(jpezy_ctx* c, const int16_t* d_coeffs, int W, int H, int gray, int n_frames, const char* comment,
+                               uint8_t* out, size_t cap, long* sizes)
+{
+    if (int rc = check_dims(c, W, H, n_frames)) return rc;
+    if (!d_coeffs || !out || !sizes) return set_err(JPEZY_E_BADARG, "write_jpeg_gpu: null pointer");
+    HIP_TRY(hipSetDevice(c->device));
+    if (int rc = ensure_code_tables(c)) return rc;
+    const size_t nblk = (size_t)jpezy_mcu_cols(W) * jpezy_mcu_rows(H) * 6;
+    // chunk the batch so that the worst-case unstuffed streams (208 bytes per block) stay below ~1 GiB
+    const size_t worst = nblk * 208 + 4096;
+    int per = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_frames, ((size_t)1 << 30) / worst));
+    bool any_failed = false;
+    const size_t cpf = jpezy_coeff_count(W, H, gray);
+    for (int f0 = 0; f0 < n_frames; f0 += per) {
+        const int F = std::min(per, n_frames - f0);
+        if (int rc = entropy_chunk(c, d_coeffs + (size_t)f0 * cpf, W, H, gray, F, comment, out + (size_t)f0 * cap, cap, sizes + f0, &any_failed))
+            return rc;
+    }
+    return any_failed ? set_err(JPEZY_E_FORMAT, "write_jpeg_gpu: at least one frame failed (see sizes[])") : JPEZY_OK;
+}
+
+long jpezy_write_jpeg_gpu(jpezy_ctx* c, const int16_t* d_coeffs, int W, int H, int gray, const char* comment, uint8_t* out, size_t cap)
+{
+    long size = 0;
+    const int rc = jpezy_write_jpeg_gpu_batch(c, d_coeffs, W, H, gray, 1, comment, out, cap, &size);
+    if (rc != JPEZY_OK && size >= 0) return rc;
+    if (size == JPEZY_E_FORMAT) set_err(JPEZY_E_FORMAT, "write_jpeg_gpu: coefficient outside the Annex-K code tables");
+    if (size == JPEZY_E_NOSPACE) set_err(JPEZY_E_NOSPACE, "write_jpeg_gpu: output buffer too small");
+    return size;
+}
+
+// planar RGB on the host -> .jpg bytes on the host, both stages on the GPU (what encoder::encode does end to end)
+long jpezy_encode_jpeg(jpezy_ctx* c, const uint8_t* r, const uint8_t* g, const uint8_t* b, int W, int H, int gray, const char* comment,
+                       uint8_t* out, size_t cap)
+{
+    if (int rc = check_dims(c, W, H, 1)) return rc;
+    if (!r || !g || !b || !out) return set_err(JPEZY_E_BADARG, "encode_jpeg: null pointer");
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t plane = (size_t)W * H, stride = (plane + 15) & ~(size_t)15;
+    const uint8_t* src[3] = { r, g, b };
+    for (int k = 0; k < 3; ++k) {
+        if (int rc = c->in[k].reserve(stride)) return rc;
+        HIP_TRY(hipMemcpyAsync(c->in[k].p, src[k], plane, hipMemcpyHostToDevice, c->stream));
+    }
+    if (int rc = c->e_coef.reserve(jpezy_coeff_count(W, H, gray) * sizeof(int16_t))) return rc;
+    if (int rc = jpezy_fdct_quant_dev(c, (const uint8_t*)c->in[0].p, (const uint8_t*)c->in[1].p, (const uint8_t*)c->in[2].p, stride, W, H,
+                                      gray, 1, (int16_t*)c->e_coef.p, c->stream))
+        return rc;
+    return jpezy_write_jpeg_gpu(c, (const int16_t*)c->e_coef.p, W, H, gray, comment, out, cap);
 }
 
 int jpezy_read_jpeg(const uint8_t* data, size_t len, jpezy_frame_info* info, int16_t* coeffs, size_t coeff_cap)

@@ -1,0 +1,39 @@
+// jpezy_entropy.h -- GPU Huffman coder + bit packer + byte stuffer (internal; see jpezy_entropy.hip)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace jpezy_dev {
+namespace entropy {
+
+// entry = (code << 8) | length in bits;  dc[t][category 0..11], ac[t][(run << 4) | size]   (t: 0 luma, 1 chroma)
+struct CodeTables {
+    uint32_t dc[2][16];
+    uint32_t ac[2][256];
+};
+
+struct Job {
+    const int16_t* coeffs;        // device, [frame][mcu][bpm][64] zig-zag
+    size_t coeffs_per_frame;      // int16 elements
+    const CodeTables* tables;     // device
+    unsigned blocks_per_frame;    // coded blocks: 6 per MCU (gray: the two chroma blocks are coded as zero blocks)
+    int bpm;                      // stored blocks per MCU: 6 colour, 4 gray
+    int n_frames;
+};
+
+size_t scan_tmp_elems(size_t n);  // uint64 scratch elements launch_scan_u32 needs for n inputs
+size_t chunk_bytes();             // granularity of the stuffing pass: U strides must be multiples of it
+
+hipError_t launch_block_bits(const Job& job, uint32_t* bits, unsigned* status, hipStream_t s);
+// out[0..n) exclusive prefix sums, out[n] the total
+hipError_t launch_scan_u32(const uint32_t* in, unsigned long long* out, size_t n, unsigned long long* tmp, hipStream_t s);
+hipError_t launch_frame_totals(const unsigned long long* off, size_t per, int n_frames, unsigned long long* dst, hipStream_t s);
+hipError_t launch_emit(const Job& job, const unsigned long long* bitoff, uint32_t* U, size_t u_stride_words, hipStream_t s);
+hipError_t launch_ff_count(const uint32_t* U, size_t u_stride_words, const unsigned long long* frame_bytes, int n_frames,
+                           uint32_t* counts, hipStream_t s);
+hipError_t launch_stuff(const uint32_t* U, size_t u_stride_words, const unsigned long long* frame_bytes, int n_frames,
+                        const unsigned long long* ff_before, uint8_t* out, size_t out_stride, hipStream_t s);
+
+}  // namespace entropy
+}  // namespace jpezy_dev

@@ -1,0 +1,418 @@
+// jpezy_entropy.hip -- the encoder's serial tail on the GPU: Annex-K Huffman coding of the
+// zig-zagged coefficients, bit packing, 0xFF00 byte stuffing.  Same bytes as jpezy_host::write_jpeg / the reference's
+// encoder::encode_huffman + bofstream (ref encoder/jpezy_encoder.hpp:174-242): MSB-first bits, DC predictors per
+// component never reset, EOB only when a block ends in zeros, ZRL for runs over 15, zero pad bits before EOI.
+//
+// What is serial in the reference is the bit cursor and pre_DC[3].  Neither is a true dependency:
+//   * pre_DC of a block is the DC of the previous block of the same component, which is simply read;
+//   * the bit cursor is an exclusive prefix sum of the blocks' code lengths.
+// Pipeline for a chunk of frames (all launches on one stream, two host syncs to learn sizes):
+//   1. block_bits_kernel   one lane per coded block: length in bits of its codes        (reads 3 B/px... of coefficients)
+//   2. scan                exclusive prefix sum over all blocks -> bit offset of every block (uint64)
+//   3. emit_kernel         one lane per block: codes again, written at the block's bit offset into the unstuffed
+//                          stream U (32-bit big-endian words; a block's first and last word are shared with its
+//                          neighbours and merged with atomicOr, U is zeroed first)
+//   4. ff_count_kernel     0xFF bytes per 64-byte chunk of U;  5. scan;  6. stuff_kernel copies U to the output
+//                          inserting 0x00 after every 0xFF.
+// The JFIF header and EOI are written by the host wrapper (jpezy_capi.hip).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "jpezy_entropy.h"
+
+namespace jpezy_dev {
+namespace entropy {
+
+// code tables: entry = (code << 8) | length; dc[t][category], ac[t][(run << 4) | size]   (t: 0 luma, 1 chroma)
+struct LdsTables {
+    uint32_t dc[2][16];
+    uint32_t ac[2][256];
+};
+
+__device__ __forceinline__ void load_tables(LdsTables& L, const CodeTables* T)
+{
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(T);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(&L);
+    for (unsigned i = threadIdx.x; i < sizeof(LdsTables) / 4; i += blockDim.x) dst[i] = src[i];
+    __syncthreads();
+}
+
+// MSB-first writer into 32-bit big-endian words of a zeroed buffer
+struct BitWriter {
+    unsigned long long acc;
+    int nacc;
+    uint32_t* wp;
+    bool first;
+    __device__ __forceinline__ void init(uint32_t* base, unsigned long long bitoff)
+    {
+        wp = base + (bitoff >> 5);
+        nacc = (int)(bitoff & 31);
+        acc = 0;
+        first = true;
+    }
+    __device__ __forceinline__ void put(uint32_t bits, int n)   // n <= 26
+    {
+        acc = (acc << n) | bits;
+        nacc += n;
+        if (nacc >= 32) {
+            nacc -= 32;
+            const uint32_t w = __builtin_bswap32((uint32_t)(acc >> nacc));
+            if (first) { atomicOr(wp, w); first = false; } else *wp = w;
+            ++wp;
+        }
+    }
+    __device__ __forceinline__ void finish()
+    {
+        if (nacc > 0) atomicOr(wp, __builtin_bswap32((uint32_t)(acc << (32 - nacc))));
+    }
+};
+
+struct NoWriter {
+    __device__ __forceinline__ void put(uint32_t, int) {}
+};
+
+// codes of one block (ref :174-225).  z: 64 zig-zag coefficients (nullptr: an all-zero block), pred: DC of the previous
+// block of the component.  Returns the length in bits; err is set for values outside the Annex-K tables (the
+// reference throws / the host writer returns JPEZY_E_FORMAT).
+template <class W>
+__device__ __forceinline__ unsigned code_block(const int16_t* z, int pred, const uint32_t* dc, const uint32_t* ac, W& w,
+                                               bool& err)
+{
+    unsigned len = 0;
+    uint4 c0 = make_uint4(0, 0, 0, 0);
+    if (z) c0 = *reinterpret_cast<const uint4*>(z);
+    {
+        const int dcv = (int)(short)(c0.x & 0xFFFFu);
+        const int diff = dcv - pred;
+        const unsigned a = (unsigned)(diff < 0 ? -diff : diff);
+        const int di = a ? 32 - __builtin_clz(a) : 0;
+        if (di > 11) { err = true; return 0; }
+        const uint32_t e = dc[di];
+        w.put(e >> 8, (int)(e & 0xFF));
+        len += e & 0xFF;
+        if (di) {
+            w.put((uint32_t)(diff + (diff >> 31)) & ((1u << di) - 1u), di);
+            len += di;
+        }
+    }
+    int run = 0;
+    if (z) {
+#pragma unroll 1
+        for (int k = 0; k < 8; ++k) {
+            const uint4 c = k ? reinterpret_cast<const uint4*>(z)[k] : c0;
+            const uint32_t wd[4] = { c.x, c.y, c.z, c.w };
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (k == 0 && j == 0) continue;
+                const int v = (int)(short)((wd[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu);
+                if (v == 0) {
+                    ++run;
+                } else {
+                    const unsigned a = (unsigned)(v < 0 ? -v : v);
+                    const int s = 32 - __builtin_clz(a);
+                    if (s > 10) { err = true; return 0; }
+                    if (run > 15) {
+                        const uint32_t zrl = ac[0xF0];
+                        for (int r = run >> 4; r > 0; --r) { w.put(zrl >> 8, (int)(zrl & 0xFF)); len += zrl & 0xFF; }
+                        run &= 15;
+                    }
+                    const uint32_t e = ac[(run << 4) | s];
+                    // code and value bits in one append: at most 16 + 10 bits
+                    const int n = (int)(e & 0xFF) + s;
+                    w.put(((e >> 8) << s) | ((uint32_t)(v + (v >> 31)) & ((1u << s) - 1u)), n);
+                    len += n;
+                    run = 0;
+                }
+            }
+        }
+    } else {
+        run = 63;
+    }
+    if (run) {
+        const uint32_t e = ac[0x00];
+        w.put(e >> 8, (int)(e & 0xFF));
+        len += e & 0xFF;
+    }
+    return len;
+}
+
+// Workgroup tile: the coefficients of the 256 coded blocks of a workgroup are contiguous in memory (also across
+// frames, and in gray mode, where 6 coded blocks per MCU map to 4 stored ones); they are copied to LDS with coalesced
+// 16-byte loads and every lane then walks its own block there (144-byte pitch: conflict-free ds_read_b128).
+constexpr int WG = 256, TILE_PITCH = 144;
+
+struct BlockRef {
+    const int16_t* z;     // in LDS, or nullptr for an all-zero block
+    int pred;             // DC of the previous block of the component (ref :180-181: pre_DC[cs], zero-initialised)
+    int table;            // 0 luma, 1 chroma
+};
+
+// stored-block index (over all frames) of coded block g; -1 for the zero chroma blocks of gray mode
+__device__ __forceinline__ long long stored_index(const Job& job, size_t g, unsigned& mcu, unsigned& i)
+{
+    const size_t frame = g / job.blocks_per_frame;
+    const unsigned b = (unsigned)(g - frame * job.blocks_per_frame);
+    mcu = b / 6u;
+    i = b - mcu * 6u;
+    if (i >= 4 && job.bpm == 4) return -1;
+    return (long long)(frame * (job.coeffs_per_frame / 64) + (size_t)mcu * job.bpm + i);
+}
+
+__device__ __forceinline__ BlockRef stage_and_locate(const Job& job, char* tile, size_t g, size_t n_total)
+{
+    // first / last stored block this workgroup needs
+    const size_t g0 = (size_t)blockIdx.x * WG, g1 = (g0 + WG < n_total ? g0 + WG : n_total) - 1;
+    unsigned m0, i0, m1, i1;
+    long long s0 = stored_index(job, g0, m0, i0), s1 = stored_index(job, g1, m1, i1);
+    if (s0 < 0) s0 = (long long)((g0 / job.blocks_per_frame) * (job.coeffs_per_frame / 64) + (size_t)(m0 + 1) * job.bpm);   // next MCU's Y0
+    if (s1 < 0) s1 = (long long)((g1 / job.blocks_per_frame) * (job.coeffs_per_frame / 64) + (size_t)m1 * job.bpm + 3);     // this MCU's Y3
+    const long long nchunks = (s1 - s0 + 1) * 8;                       // 16-byte chunks
+    const uint4* src = reinterpret_cast<const uint4*>(job.coeffs + (size_t)s0 * 64);
+    for (long long c = threadIdx.x; c < nchunks; c += WG)
+        *reinterpret_cast<uint4*>(tile + (c >> 3) * TILE_PITCH + (c & 7) * 16) = src[c];
+    __syncthreads();
+
+    BlockRef r;
+    r.z = nullptr; r.pred = 0; r.table = 0;
+    if (g >= n_total) return r;
+    unsigned mcu, i;
+    const long long si = stored_index(job, g, mcu, i);
+    r.table = i < 4 ? 0 : 1;
+    if (si < 0) return r;
+    r.z = reinterpret_cast<const int16_t*>(tile + (si - s0) * TILE_PITCH);
+    // predictor: previous block of the same component in the frame's scan order, read from global memory (it may
+    // belong to the previous workgroup)
+    const int16_t* zg = job.coeffs + (size_t)si * 64;
+    if (i >= 1 && i <= 3) r.pred = zg[-64];                                // previous Y block of the same MCU
+    else if (mcu == 0) r.pred = 0;
+    else r.pred = i == 0 ? zg[-(job.bpm - 3) * 64] : zg[-job.bpm * 64];    // Y3 / same chroma block of the previous MCU
+    return r;
+}
+
+__global__ __launch_bounds__(WG) void block_bits_kernel(Job job, uint32_t* bits, unsigned* status)
+{
+    __shared__ LdsTables L;
+    __shared__ __attribute__((aligned(16))) char tile[WG * TILE_PITCH];
+    load_tables(L, job.tables);
+    const size_t n_total = (size_t)job.blocks_per_frame * job.n_frames;
+    const size_t g = (size_t)blockIdx.x * WG + threadIdx.x;
+    const BlockRef r = stage_and_locate(job, tile, g, n_total);
+    if (g >= n_total) return;
+    NoWriter w;
+    bool err = false;
+    const unsigned n = code_block(r.z, r.pred, L.dc[r.table], L.ac[r.table], w, err);
+    if (err) atomicOr(status + g / job.blocks_per_frame, 1u);
+    bits[g] = n;
+}
+
+__global__ __launch_bounds__(WG) void emit_kernel(Job job, const unsigned long long* bitoff, uint32_t* U, size_t u_stride_words)
+{
+    __shared__ LdsTables L;
+    __shared__ __attribute__((aligned(16))) char tile[WG * TILE_PITCH];
+    load_tables(L, job.tables);
+    const size_t n_total = (size_t)job.blocks_per_frame * job.n_frames;
+    const size_t g = (size_t)blockIdx.x * WG + threadIdx.x;
+    const BlockRef r = stage_and_locate(job, tile, g, n_total);
+    if (g >= n_total) return;
+    const size_t frame = g / job.blocks_per_frame;
+    BitWriter w;
+    w.init(U + frame * u_stride_words, bitoff[g] - bitoff[frame * job.blocks_per_frame]);
+    bool err = false;
+    (void)code_block(r.z, r.pred, L.dc[r.table], L.ac[r.table], w, err);
+    w.finish();
+}
+
+// ---- exclusive prefix sums: 2048 elements per workgroup, recursive over the workgroup totals ----
+constexpr int SCAN_T = 256, SCAN_E = 8, SCAN_N = SCAN_T * SCAN_E;
+
+template <typename TIn>
+__global__ __launch_bounds__(SCAN_T) void scan_local_kernel(const TIn* in, unsigned long long* out, unsigned long long* totals,
+                                                           size_t n)
+{
+    __shared__ unsigned long long wsum[SCAN_T / 64];
+    const size_t base = (size_t)blockIdx.x * SCAN_N + (size_t)threadIdx.x * SCAN_E;
+    unsigned long long v[SCAN_E], s = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_E; ++k) {
+        v[k] = base + k < n ? (unsigned long long)in[base + k] : 0ull;
+        s += v[k];
+    }
+    // inclusive scan of the per-thread sums: within the wave by shuffles, across the four waves through LDS
+    unsigned long long inc = s;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned long long o = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += o;
+    }
+    if (lane == 63) wsum[wv] = inc;
+    __syncthreads();
+    unsigned long long woff = 0;
+    for (int k = 0; k < wv; ++k) woff += wsum[k];
+    unsigned long long run = woff + inc - s;
+#pragma unroll
+    for (int k = 0; k < SCAN_E; ++k) {
+        if (base + k < n) out[base + k] = run;
+        run += v[k];
+    }
+    if (threadIdx.x == SCAN_T - 1) totals[blockIdx.x] = run;
+}
+
+__global__ __launch_bounds__(SCAN_T) void scan_add_kernel(unsigned long long* out, const unsigned long long* offs, size_t n,
+                                                         unsigned long long* total_slot)
+{
+    const size_t base = (size_t)blockIdx.x * SCAN_N + (size_t)threadIdx.x * SCAN_E;
+    const unsigned long long o = offs[blockIdx.x];
+#pragma unroll
+    for (int k = 0; k < SCAN_E; ++k)
+        if (base + k < n) out[base + k] += o;
+    (void)total_slot;
+}
+
+// out[0..n) = exclusive prefix sums of in[0..n), out[n] = total.  tmp: scratch of scan_tmp_elems(n) uint64.
+size_t scan_tmp_elems(size_t n)
+{
+    size_t t = 0;
+    while (n > 1) {
+        n = (n + SCAN_N - 1) / SCAN_N;
+        t += n + 1 + n;      // scanned totals (n+1) and raw totals (n)
+        if (n == 1) break;
+    }
+    return t + 4;
+}
+
+template <typename TIn>
+static hipError_t scan_exclusive(const TIn* in, unsigned long long* out, size_t n, unsigned long long* tmp, hipStream_t s)
+{
+    if (n == 0) return hipMemsetAsync(out, 0, sizeof(unsigned long long), s);
+    const size_t nb = (n + SCAN_N - 1) / SCAN_N;
+    unsigned long long* raw = tmp;             // [nb] workgroup totals
+    unsigned long long* scanned = tmp + nb;    // [nb + 1]
+    hipLaunchKernelGGL((scan_local_kernel<TIn>), dim3((unsigned)nb), dim3(SCAN_T), 0, s, in, out, raw, n);
+    if (nb == 1) {
+        // total of the single workgroup is the grand total
+        return hipMemcpyAsync(out + n, raw, sizeof(unsigned long long), hipMemcpyDeviceToDevice, s);
+    }
+    hipError_t e = scan_exclusive<unsigned long long>(raw, scanned, nb, scanned + nb + 1, s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(scan_add_kernel, dim3((unsigned)nb), dim3(SCAN_T), 0, s, out, scanned, n, (unsigned long long*)nullptr);
+    return hipMemcpyAsync(out + n, scanned + nb, sizeof(unsigned long long), hipMemcpyDeviceToDevice, s);
+}
+
+// frame totals: dst[f] = off[(f+1)*per] - off[f*per]
+__global__ void frame_totals_kernel(const unsigned long long* off, size_t per, int n_frames, unsigned long long* dst)
+{
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f < n_frames) dst[f] = off[(size_t)(f + 1) * per] - off[(size_t)f * per];
+}
+
+// ---- byte stuffing ----
+constexpr int CHUNK = 64;   // bytes of U per thread
+
+__device__ __forceinline__ unsigned count_ff(uint32_t x)
+{
+    const uint32_t z = ~x;                                             // 0xFF bytes of x are zero bytes of z
+    uint32_t y = (z & 0x7F7F7F7Fu) + 0x7F7F7F7Fu;
+    y = ~(y | z | 0x7F7F7F7Fu);                                         // 0x80 exactly in the zero bytes of z
+    return (unsigned)__builtin_popcount(y);
+}
+
+__global__ __launch_bounds__(256) void ff_count_kernel(const uint32_t* U, size_t u_stride_words, const unsigned long long* frame_bytes,
+                                                      int n_frames, uint32_t* counts)
+{
+    const size_t chunks_per_frame = u_stride_words * 4 / CHUNK;
+    const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= chunks_per_frame * n_frames) return;
+    const size_t frame = g / chunks_per_frame, c = g - frame * chunks_per_frame;
+    unsigned n = 0;
+    if ((unsigned long long)c * CHUNK < frame_bytes[frame]) {          // bytes past the end of the stream are zero
+        const uint4* p = reinterpret_cast<const uint4*>(U + frame * u_stride_words) + c * (CHUNK / 16);
+#pragma unroll
+        for (int k = 0; k < CHUNK / 16; ++k) {
+            const uint4 v = p[k];
+            n += count_ff(v.x) + count_ff(v.y) + count_ff(v.z) + count_ff(v.w);
+        }
+    }
+    counts[g] = n;
+}
+
+__global__ __launch_bounds__(256) void stuff_kernel(const uint32_t* U, size_t u_stride_words, const unsigned long long* frame_bytes,
+                                                   int n_frames, const unsigned long long* ff_before, uint8_t* out, size_t out_stride)
+{
+    const size_t chunks_per_frame = u_stride_words * 4 / CHUNK;
+    const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= chunks_per_frame * n_frames) return;
+    const size_t frame = g / chunks_per_frame, c = g - frame * chunks_per_frame;
+    const unsigned long long nbytes = frame_bytes[frame];
+    if ((unsigned long long)c * CHUNK >= nbytes) return;
+    const unsigned long long before = ff_before[g] - ff_before[frame * chunks_per_frame];
+    uint8_t* dst = out + frame * out_stride + c * CHUNK + before;
+    const uint8_t* src = reinterpret_cast<const uint8_t*>(U + frame * u_stride_words) + c * CHUNK;
+    const int n = (int)((nbytes - (unsigned long long)c * CHUNK) < (unsigned long long)CHUNK ? (nbytes - (unsigned long long)c * CHUNK) : CHUNK);
+#pragma unroll 1
+    for (int k = 0; k < CHUNK / 16; ++k) {
+        const uint4 v = reinterpret_cast<const uint4*>(src)[k];
+        const uint32_t wd[4] = { v.x, v.y, v.z, v.w };
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            if (k * 16 + j < n) {
+                const uint8_t b = (uint8_t)(wd[j >> 2] >> ((j & 3) * 8));
+                *dst++ = b;
+                if (b == 0xFF) *dst++ = 0x00;
+            }
+        }
+    }
+}
+
+// ---- host-side driver ----
+hipError_t launch_block_bits(const Job& job, uint32_t* bits, unsigned* status, hipStream_t s)
+{
+    const size_t n = (size_t)job.blocks_per_frame * job.n_frames;
+    if (!n) return hipSuccess;
+    hipLaunchKernelGGL(block_bits_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, job, bits, status);
+    return hipGetLastError();
+}
+
+hipError_t launch_scan_u32(const uint32_t* in, unsigned long long* out, size_t n, unsigned long long* tmp, hipStream_t s)
+{
+    hipError_t e = scan_exclusive<uint32_t>(in, out, n, tmp, s);
+    return e != hipSuccess ? e : hipGetLastError();
+}
+
+hipError_t launch_frame_totals(const unsigned long long* off, size_t per, int n_frames, unsigned long long* dst, hipStream_t s)
+{
+    hipLaunchKernelGGL(frame_totals_kernel, dim3((unsigned)((n_frames + 63) / 64)), dim3(64), 0, s, off, per, n_frames, dst);
+    return hipGetLastError();
+}
+
+hipError_t launch_emit(const Job& job, const unsigned long long* bitoff, uint32_t* U, size_t u_stride_words, hipStream_t s)
+{
+    const size_t n = (size_t)job.blocks_per_frame * job.n_frames;
+    if (!n) return hipSuccess;
+    hipLaunchKernelGGL(emit_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, job, bitoff, U, u_stride_words);
+    return hipGetLastError();
+}
+
+hipError_t launch_ff_count(const uint32_t* U, size_t u_stride_words, const unsigned long long* frame_bytes, int n_frames,
+                           uint32_t* counts, hipStream_t s)
+{
+    const size_t n = u_stride_words * 4 / CHUNK * n_frames;
+    if (!n) return hipSuccess;
+    hipLaunchKernelGGL(ff_count_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, U, u_stride_words, frame_bytes, n_frames, counts);
+    return hipGetLastError();
+}
+
+hipError_t launch_stuff(const uint32_t* U, size_t u_stride_words, const unsigned long long* frame_bytes, int n_frames,
+                        const unsigned long long* ff_before, uint8_t* out, size_t out_stride, hipStream_t s)
+{
+    const size_t n = u_stride_words * 4 / CHUNK * n_frames;
+    if (!n) return hipSuccess;
+    hipLaunchKernelGGL(stuff_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, U, u_stride_words, frame_bytes, n_frames, ff_before, out,
+                       out_stride);
+    return hipGetLastError();
+}
+
+size_t chunk_bytes() { return CHUNK; }
+
+}  // namespace entropy
+}  // namespace jpezy_dev

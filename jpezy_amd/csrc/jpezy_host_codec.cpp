@@ -179,6 +179,22 @@ void put_header(BitSink& o, int W, int H, const char* comment)
 
 }  // namespace
 
+size_t write_header(int W, int H, const char* comment, uint8_t* out, size_t cap)
+{
+    BitSink o(out, cap);
+    put_header(o, W, H, comment);
+    return o.ok() ? o.size() : 0;
+}
+
+void enc_code_tables(uint16_t code[4][256], uint8_t len[4][256])
+{
+    const EncTables& T = enc_tables();
+    for (int k = 0; k < 4; ++k) {
+        std::memcpy(code[k], T.t[k].code, sizeof T.t[k].code);
+        std::memcpy(len[k], T.t[k].len, sizeof T.t[k].len);
+    }
+}
+
 size_t jpeg_bound(int W, int H)
 {
     const size_t nmcu = (size_t)((W + 15) / 16) * (size_t)((H + 15) / 16);

@@ -15,6 +15,10 @@ namespace jpezy_host {
 long write_jpeg(const int16_t* coeffs, int W, int H, bool gray, const char* comment, uint8_t* out, size_t cap,
                 std::string* err);
 size_t jpeg_bound(int W, int H);
+// the bytes before the entropy-coded segment (SOI .. SOS, 644 with the default comment); 0 if cap is too small
+size_t write_header(int W, int H, const char* comment, uint8_t* out, size_t cap);
+// canonical (code, length) per symbol of the four Annex-K tables in DHT order YDc, CDc, YAc, CAc (for the GPU coder)
+void enc_code_tables(uint16_t code[4][256], uint8_t len[4][256]);
 
 // ref decoder/jpezy_decoder.hpp:171-502, 583-642
 int read_jpeg(const uint8_t* data, size_t len, jpezy_frame_info* info, int16_t* coeffs, size_t coeff_cap,

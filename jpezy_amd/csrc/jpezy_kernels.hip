@@ -502,8 +502,11 @@ __device__ __forceinline__ uint32_t clamp_byte(double v)   // revise_value, ref 
     return (uint32_t)min(max(iv, 0), 255);
 }
 
+#ifndef JPEZY_DEC_WAVES
+#define JPEZY_DEC_WAVES 5
+#endif
 template <bool GRAY, bool ALIGNED, bool FORCE_EXACT>
-__global__ __launch_bounds__(64 * WPB, 5) void dequant_idct_kernel(DecParams p)
+__global__ __launch_bounds__(64 * WPB, JPEZY_DEC_WAVES) void dequant_idct_kernel(DecParams p)
 {
     __shared__ __attribute__((aligned(16))) uint32_t lds_all[WPB][DEC_LDS_DWORDS];
     constexpr int BPM = 6;

@@ -297,8 +297,8 @@ def default_context(device=0):
 
 class Encoder:
     """Mirror of jpezy::encoder<T> (ref encoder/jpezy_encoder.hpp:22-77): holds copies of the planes;
-    encode() runs the compute stage on the GPU and the Huffman/JFIF tail on the host, writes the file and
-    returns the number of bytes written."""
+    encode() runs the compute stage and the Huffman stage on the GPU (Context.encode_jpeg; the JFIF header and EOI
+    come from the host), writes the file and returns the number of bytes written."""
 
     block_size = 8
 
@@ -312,7 +312,8 @@ class Encoder:
         return ctx.fdct_quant(self.r, self.g, self.b, self.width, self.height, gray=gray)
 
     def encode_bytes(self, gray=False):
-        return write_jpeg(self.coefficients(gray), self.width, self.height, gray)
+        ctx = self.ctx or default_context()
+        return ctx.encode_jpeg(self.r, self.g, self.b, self.width, self.height, gray=gray)
 
     def encode(self, output_file, gray=False):
         data = self.encode_bytes(gray)

@@ -1,9 +1,11 @@
 // jpezy_encoder.hpp -- jpezy::encoder<T>, same surface as the reference's src/encoder/jpezy_encoder.hpp:22-77.
-// encode<MODE_TAG>() splits the reference's per-MCU loop (:58-67) in two: the batched compute stage
-// (make_YCC + DCT + quantization + zig-zag for ALL MCUs) runs on the MI355X through the C-ABI
-// (jpezy_fdct_quant), then the serial Huffman/JFIF tail (encode_huffman :174-225, jpezy_writer) runs on the
-// host (jpezy_write_jpeg).  Legal because encode_huffman's only cross-block state is pre_DC[3] and the bit
-// cursor.  Output bytes are identical to the reference arithmetic.
+// encode<MODE_TAG>() splits the reference's per-MCU loop (:58-67) in two stages, both on the MI355X through one
+// C-ABI call (jpezy_encode_jpeg): the batched compute stage (make_YCC + DCT + quantization + zig-zag for ALL MCUs),
+// then the entropy stage (encode_huffman :174-225 + the bit packer) -- legal because encode_huffman's only
+// cross-block state is pre_DC[3], which is the previous block's DC, and the bit cursor, which is a prefix sum of
+// code lengths.  The JFIF header and EOI are written by the host.  Output bytes are identical
+// to the reference arithmetic.  Define JPEZY_HOST_ENTROPY to keep the serial tail on the host
+// (jpezy_fdct_quant + jpezy_write_jpeg): same bytes.
 #ifndef JPEZY_AMD_HOST_ENCODER_HPP
 #define JPEZY_AMD_HOST_ENCODER_HPP
 #include <cstdio>
@@ -33,7 +35,6 @@ struct encoder {
             throw std::runtime_error("encode");
         std::FILE* fp = std::fopen(output_file, "wb");
         if (!fp) throw std::runtime_error("write_header");          // jpezy_writer::write_header (:22-23)
-        std::vector<std::int16_t> coeffs(jpezy_coeff_count(W, H, gray));
         std::vector<std::uint8_t> out(jpezy_jpeg_bound(W, H));
         long n = 0;
         {
@@ -42,10 +43,18 @@ struct encoder {
         try {
             raii_messenger mes("Encoding ...");
             jpezy_ctx* ctx = detail::device_context();
+#ifdef JPEZY_HOST_ENTROPY
+            std::vector<std::int16_t> coeffs(jpezy_coeff_count(W, H, gray));
             if (jpezy_fdct_quant(ctx, reinterpret_cast<const std::uint8_t*>(r.data()), reinterpret_cast<const std::uint8_t*>(g.data()),
                                  reinterpret_cast<const std::uint8_t*>(b.data()), W, H, gray, 1, coeffs.data()) != JPEZY_OK)
                 throw std::runtime_error(std::string("jpezy_fdct_quant: ") + jpezy_hip_last_error());
             n = jpezy_write_jpeg(coeffs.data(), W, H, gray, pr.template get<property::At::Comment>().c_str(), out.data(), out.size());
+#else
+            n = jpezy_encode_jpeg(ctx, reinterpret_cast<const std::uint8_t*>(r.data()), reinterpret_cast<const std::uint8_t*>(g.data()),
+                                  reinterpret_cast<const std::uint8_t*>(b.data()), W, H, gray,
+                                  pr.template get<property::At::Comment>().c_str(), out.data(), out.size());
+            if (n < 0 && n != JPEZY_E_FORMAT) throw std::runtime_error(std::string("jpezy_encode_jpeg: ") + jpezy_hip_last_error());
+#endif
             if (n < 0) throw std::runtime_error("encode_huffman");   // ref :186-187, 207-208
         } catch (...) {
             std::fclose(fp);

@@ -469,9 +469,12 @@ __device__ __forceinline__ int exact_idct_sample_sparse(const int2* __restrict__
 // when the reduction says that some lane of the wave has a sample in the band.
 constexpr float SAMPLE_EPS = 0x1p-18f;
 constexpr float SAMPLE_TH = 0.5f - SAMPLE_EPS;
-__device__ __forceinline__ int sample_of(double sum, float& e)
+// sum512 = row sum + 512: the level shift enters the row pass as one addition to its DC input (bias_row below), so
+// that a sample costs one multiplication here.  fl(s + 512) / 4 == fl(s / 4 + 128) because scaling by 4 is exact; a
+// DC-only block therefore still reproduces the reference bit for bit (its row sum reaches this point unrounded).
+__device__ __forceinline__ int sample_of(double sum512, float& e)
 {
-    const double v = FMA(sum, 0.25, 128.0);          // == fl(sum / 4 + 128): the scaling is exact
+    const double v = sum512 * 0.25;
     e = (float)__builtin_amdgcn_fract(v) - 0.5f;
     return (int)v;
 }
@@ -494,6 +497,19 @@ __device__ __forceinline__ unsigned guard_bits8(const float* e, bool dc_only)
         if (dc_only) bits = 0;
     }
     return bits;
+}
+
+// revise_value (ref :672-676) of four values and their packing into one word: saturate to int16 pairs
+// (v_cvt_pk_i16_i32), saturate those to bytes (v_sat_pk_u8_i16), join the halves (v_perm_b32): 5 instructions for 4 values.
+__device__ __forceinline__ uint32_t clamp_pack4(const int* v)
+{
+    typedef short short2_t __attribute__((ext_vector_type(2)));
+    const uint32_t p01 = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16(v[0], v[1]));
+    const uint32_t p23 = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16(v[2], v[3]));
+    uint32_t b01, b23;
+    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(b01) : "v"(p01));
+    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(b23) : "v"(p23));
+    return __builtin_amdgcn_perm(b23, b01, 0x05040100u);     // bytes 0,1 of b01 then bytes 0,1 of b23
 }
 
 __device__ __forceinline__ uint32_t clamp_byte(double v)   // revise_value, ref :672-676
@@ -628,6 +644,7 @@ __global__ __launch_bounds__(64 * WPB, JPEZY_DEC_WAVES) void dequant_idct_kernel
             const double2* src = reinterpret_cast<const double2*>(lds + m * DH_MCU + row * DH_PITCH);
 #pragma unroll
             for (int k = 0; k < 4; ++k) { const double2 t = src[k]; in[2 * k] = t.x; in[2 * k + 1] = t.y; }
+            in[0] += 512.0;          // level shift 128 * 4, see sample_of
             idct8(in, out);
             float e[8];
 #pragma unroll
@@ -655,6 +672,8 @@ __global__ __launch_bounds__(64 * WPB, JPEZY_DEC_WAVES) void dequant_idct_kernel
             in[2 * k] = a.x; in[2 * k + 1] = a.y;
             in[8 + 2 * k] = b.x; in[8 + 2 * k + 1] = b.y;
         }
+        in[0] += 512.0;
+        in[8] += 512.0;
         idct8(in, out);
         idct8(in + 8, out + 8);
         {
@@ -747,26 +766,31 @@ __global__ __launch_bounds__(64 * WPB, JPEZY_DEC_WAVES) void dequant_idct_kernel
     }
 
     // ---- 5. YCbCr -> RGB in the reference's exact order (ref :567-578), clamp, pack, store ----
-    uint32_t Rw[4] = { 0, 0, 0, 0 }, Gw[4] = { 0, 0, 0, 0 }, Bw[4] = { 0, 0, 0, 0 };
+    uint32_t Rw[4], Gw[4], Bw[4];
     if (!GRAY) {
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            const double up = (double)Cb[c] - 128.0, vp = (double)Cr[c] - 128.0;
-            const double pr_ = vp * 1.4020, pg1 = up * 0.3441, pg2 = vp * 0.7139, pb_ = up * 1.7718;
+        for (int q = 0; q < 4; ++q) {              // four pixels = two chroma samples -> one word of each plane
+            int ri[4], gi[4], bi[4];
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int k = 2 * c + h;
-                const double yp = (double)Y[k];
-                Rw[k >> 2] |= clamp_byte(yp + pr_) << ((k & 3) * 8);
-                Gw[k >> 2] |= clamp_byte(yp - pg1 - pg2) << ((k & 3) * 8);
-                Bw[k >> 2] |= clamp_byte(yp + pb_) << ((k & 3) * 8);
+            for (int cc = 0; cc < 2; ++cc) {
+                const int c = 2 * q + cc;
+                const double up = (double)Cb[c] - 128.0, vp = (double)Cr[c] - 128.0;
+                const double pr_ = vp * 1.4020, pg1 = up * 0.3441, pg2 = vp * 0.7139, pb_ = up * 1.7718;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const double yp = (double)Y[2 * c + h];
+                    ri[2 * cc + h] = (int)(yp + pr_);            // truncates; revise_value clamps below (ref :672-676)
+                    gi[2 * cc + h] = (int)(yp - pg1 - pg2);
+                    bi[2 * cc + h] = (int)(yp + pb_);
+                }
             }
+            Rw[q] = clamp_pack4(ri);
+            Gw[q] = clamp_pack4(gi);
+            Bw[q] = clamp_pack4(bi);
         }
     } else {
 #pragma unroll
-        for (int k = 0; k < 16; ++k) Rw[k >> 2] |= (uint32_t)min(max(Y[k], 0), 255) << ((k & 3) * 8);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) Gw[k] = Bw[k] = Rw[k];
+        for (int q = 0; q < 4; ++q) Rw[q] = Gw[q] = Bw[q] = clamp_pack4(Y + 4 * q);
     }
     const int py = mcu_y * 16 + row;
     if (live && py < H) {

@@ -82,6 +82,9 @@ def main():
     ap.add_argument("--variant", type=int, default=None, help="encode kernel variant (0 FP64 butterflies, 1 FP32 first level)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-gather", action="store_true", help="skip the separate RCCL gather measurement (N>1)")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="development aid: run the N>1 control flow with every rank on GPU 0 and the gloo backend "
+                         "(RCCL refuses two ranks on one device); the numbers mean nothing")
     args = ap.parse_args()
 
     import torch
@@ -97,11 +100,19 @@ def main():
         raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback for the hot path)")
+    if args.rehearse_on_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    red_dev = dev                       # where the small reduction tensors live
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.rehearse_on_one_gpu:
+            dist.init_process_group("gloo")
+            red_dev = torch.device("cpu")
+            args.no_gather = True
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     W, H, gray, fps, direction, desc = WORKLOADS[args.workload]
     ctx = J.Context(local_rank)
@@ -156,7 +167,7 @@ def main():
     ev_ms = ev0.elapsed_time(ev1)
     nfallback = ctx.fallback_count()
 
-    t = torch.tensor([elapsed, ev_ms], dtype=torch.float64, device=dev)
+    t = torch.tensor([elapsed, ev_ms], dtype=torch.float64, device=red_dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed, ev_ms = float(t[0]), float(t[1])

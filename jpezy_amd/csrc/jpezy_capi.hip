@@ -138,7 +138,9 @@ jpezy_ctx* jpezy_ctx_create(int device)
         for (int j = 0; j < 8; ++j)
             for (int i = 0; i < 8; ++i) {
                 const double cu = j ? 1.0 : S, cv = i ? 1.0 : S;
-                h.f32col[t][j].ks[i] = (float)(cu * cv / (4.0 * kQt[t][i * 8 + j]));
+                // the f32 kernel's 8-point transform leaves output 4 without its factor cos(pi/4); it is applied here
+                const double k4 = 0x1.6a09e667f3bcdp-1;      // cos(pi/4), correctly rounded
+                h.f32col[t][j].ks[i] = (float)(cu * cv / (4.0 * kQt[t][i * 8 + j]) * (i == 4 ? k4 : 1.0) * (j == 4 ? k4 : 1.0));
             }
     }
     for (int t = 0; t < 2; ++t)

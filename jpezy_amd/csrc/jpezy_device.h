@@ -12,7 +12,7 @@ constexpr int QFRAC_BITS = 24;
 
 // Per (table, block column j) record of the f32 encode kernel: one 64-byte line per lane, three loads off one address.
 struct F32Column {
-    float ks[8];              // ks[i] = cu(j) * cv(i) / (4 * Q_t[i*8+j])
+    float ks[8];              // ks[i] = cu(j) * cv(i) / (4 * Q_t[i*8+j]) * cos(pi/4)^[i == 4] * cos(pi/4)^[j == 4]
     // level-1 guard band: 1.25 x max over i of the worst-case FP32 error of t[i][j] = F[i][j] * ks[i]
     // (jpezy_capi.hip; tests/test_f32_error_bound.py re-derives it)
     float delta1;

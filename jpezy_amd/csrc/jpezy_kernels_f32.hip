@@ -73,14 +73,16 @@ __device__ __forceinline__ void wave_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// X[u] = sum_x x[x] * cos((2x+1)u*pi/16); X[0] is the plain sum (exact for integers below 2^24)
+// X[u] = sum_x x[x] * cos((2x+1)u*pi/16), except X[4], which is left WITHOUT its factor cos(pi/4): both passes'
+// factors are folded into the quantiser scale ks (F32Column::ks carries cos(pi/4) per index 4).  X[0] is the plain
+// sum (exact for integers below 2^24).
 __device__ __forceinline__ void fdct8f(const float* x, float* X)
 {
     const float s0 = x[0] + x[7], s1 = x[1] + x[6], s2 = x[2] + x[5], s3 = x[3] + x[4];
     const float d0 = x[0] - x[7], d1 = x[1] - x[6], d2 = x[2] - x[5], d3 = x[3] - x[4];
     const float e0 = s0 + s3, e1 = s1 + s2, e2 = s0 - s3, e3 = s1 - s2;
     X[0] = e0 + e1;
-    X[4] = (e0 - e1) * K4;
+    X[4] = e0 - e1;
     X[2] = FMAF(e3, K6, e2 * K2);
     X[6] = FMAF(-e3, K2, e2 * K6);
     X[1] = FMAF(d3, K7, FMAF(d2, K5, FMAF(d1, K3, d0 * K1)));
@@ -128,6 +130,24 @@ __device__ __forceinline__ float luma_px(uint32_t wr, uint32_t wg, uint32_t wb, 
     e = __builtin_fabsf(t - Yt) - 0.5f;
     return Yt;
 }
+// two pixels at once: the three FMAs of the estimate as v_pk_fma_f32 (2.2 ns for two results against 2 x 1.4)
+typedef float float2_t __attribute__((ext_vector_type(2)));
+template <int B0, int B1>
+__device__ __forceinline__ void luma_px2(uint32_t wr, uint32_t wg, uint32_t wb, float& y0, float& y1, float& e0, float& e1)
+{
+#ifdef JPEZY_NO_PK
+    y0 = luma_px<B0>(wr, wg, wb, e0);
+    y1 = luma_px<B1>(wr, wg, wb, e1);
+#else
+    const float2_t r = { ubyte<B0>(wr), ubyte<B1>(wr) }, g = { ubyte<B0>(wg), ubyte<B1>(wg) }, b = { ubyte<B0>(wb), ubyte<B1>(wb) };
+    const float2_t c1 = { 0.299f, 0.299f }, c2 = { 0.587f, 0.587f }, c3 = { 0.114f, 0.114f }, c0 = { -128.f, -128.f };
+    const float2_t t = __builtin_elementwise_fma(c3, b, __builtin_elementwise_fma(c2, g, __builtin_elementwise_fma(c1, r, c0)));
+    y0 = __builtin_truncf(t.x);
+    y1 = __builtin_truncf(t.y);
+    e0 = __builtin_fabsf(t.x - y0) - 0.5f;
+    e1 = __builtin_fabsf(t.y - y1) - 0.5f;
+#endif
+}
 template <int B>
 __device__ __forceinline__ float luma_px_ref(uint32_t wr, uint32_t wg, uint32_t wb)
 {
@@ -145,15 +165,11 @@ __device__ __forceinline__ float absmax8(const float* e)
 __device__ __forceinline__ void luma8(const uint32_t* wr, const uint32_t* wg, const uint32_t* wb, float* y)
 {
     float e[8];
-    y[0] = luma_px<0>(wr[0], wg[0], wb[0], e[0]);
-    y[1] = luma_px<1>(wr[0], wg[0], wb[0], e[1]);
-    y[2] = luma_px<2>(wr[0], wg[0], wb[0], e[2]);
-    y[3] = luma_px<3>(wr[0], wg[0], wb[0], e[3]);
+    luma_px2<0, 1>(wr[0], wg[0], wb[0], y[0], y[1], e[0], e[1]);
+    luma_px2<2, 3>(wr[0], wg[0], wb[0], y[2], y[3], e[2], e[3]);
     __builtin_amdgcn_sched_barrier(0);   // 4 pixels at a time: more in flight only costs registers
-    y[4] = luma_px<0>(wr[1], wg[1], wb[1], e[4]);
-    y[5] = luma_px<1>(wr[1], wg[1], wb[1], e[5]);
-    y[6] = luma_px<2>(wr[1], wg[1], wb[1], e[6]);
-    y[7] = luma_px<3>(wr[1], wg[1], wb[1], e[7]);
+    luma_px2<0, 1>(wr[1], wg[1], wb[1], y[4], y[5], e[4], e[5]);
+    luma_px2<2, 3>(wr[1], wg[1], wb[1], y[6], y[7], e[6], e[7]);
     constexpr float TH = 0.5f - LUMA_EPS;
     if (wave_any(absmax8(e) > TH)) {   // one pixel in 1000: the reference's FP64 rounding decides
         bool f;
@@ -177,21 +193,29 @@ __device__ __forceinline__ float chroma_px(uint32_t wr, uint32_t wg, uint32_t wb
     e = __builtin_fabsf(t - Ct) - 0.5f;
     return Ct;
 }
+template <int B0, int B1>
+__device__ __forceinline__ void chroma_px2(uint32_t wr0, uint32_t wg0, uint32_t wb0, uint32_t wr1, uint32_t wg1, uint32_t wb1, float k1,
+                                           float k2, float k3, float& c0, float& c1, float& e0, float& e1)
+{
+#ifdef JPEZY_NO_PK
+    c0 = chroma_px<B0>(wr0, wg0, wb0, k1, k2, k3, e0);
+    c1 = chroma_px<B1>(wr1, wg1, wb1, k1, k2, k3, e1);
+#else
+    const float2_t r = { ubyte<B0>(wr0), ubyte<B1>(wr1) }, g = { ubyte<B0>(wg0), ubyte<B1>(wg1) }, b = { ubyte<B0>(wb0), ubyte<B1>(wb1) };
+    const float2_t q1 = { k1, k1 }, q2 = { k2, k2 }, q3 = { k3, k3 };
+    const float2_t t = __builtin_elementwise_fma(q3, b, __builtin_elementwise_fma(q2, g, q1 * r));
+    c0 = __builtin_truncf(t.x);
+    c1 = __builtin_truncf(t.y);
+    e0 = __builtin_fabsf(t.x - c0) - 0.5f;
+    e1 = __builtin_fabsf(t.y - c1) - 0.5f;
+#endif
+}
 template <int B>
 __device__ __forceinline__ float chroma_px_ref(uint32_t wr, uint32_t wg, uint32_t wb, bool odd)
 {
     const double r = (double)ubyte<B>(wr), g = (double)ubyte<B>(wg), b = (double)ubyte<B>(wb);
     return (float)(odd ? ref_cr(r, g, b) : ref_cb(r, g, b));
 }
-
-typedef __fp16 half2_t __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ uint32_t pack_h2(float a, float b)   // small integers: exact in fp16
-{
-    return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(a, b));
-}
-__device__ __forceinline__ double unpack_lo(uint32_t w) { return (double)(float)__builtin_bit_cast(half2_t, w).x; }
-__device__ __forceinline__ double unpack_hi(uint32_t w) { return (double)(float)__builtin_bit_cast(half2_t, w).y; }
 
 __device__ __forceinline__ double readlane_f64(double v, int src)   // src wave-uniform
 {
@@ -202,10 +226,10 @@ __device__ __forceinline__ double readlane_f64(double v, int src)   // src wave-
 }
 
 // Levels 2 and 3 for ONE coefficient (i, j) of one block, by the 8 lanes that hold the block's 8 rows of samples
-// (w[0..3]: this lane's 8 samples as packed fp16 pairs; part: this lane holds row y of the block; first/stride:
+// (w[0..7]: this lane's 8 samples, integers held as floats; part: this lane holds row y of the block; first/stride:
 // lane of row 0 and lane distance between rows -- all but w, part, y wave-uniform).  ref jpezy_encoder.hpp:146-172.
 template <int FORCE>
-__device__ __forceinline__ int resolve_coef(const uint32_t* w, bool part, int y, int first, int stride, int i, int j,
+__device__ __forceinline__ int resolve_coef(const float* w, bool part, int y, int first, int stride, int i, int j,
                                             int Q, double qinv)
 {
     double t[8];
@@ -213,10 +237,8 @@ __device__ __forceinline__ int resolve_coef(const uint32_t* w, bool part, int y,
         const double cy = c_cos[i * 8 + y];
         const double* cj = c_cos + j * 8;
         // the reference's term (pic * cos[j][x]) * cos[i][y], plain multiplications
-        t[0] = unpack_lo(w[0]) * cj[0] * cy; t[1] = unpack_hi(w[0]) * cj[1] * cy;
-        t[2] = unpack_lo(w[1]) * cj[2] * cy; t[3] = unpack_hi(w[1]) * cj[3] * cy;
-        t[4] = unpack_lo(w[2]) * cj[4] * cy; t[5] = unpack_hi(w[2]) * cj[5] * cy;
-        t[6] = unpack_lo(w[3]) * cj[6] * cy; t[7] = unpack_hi(w[3]) * cj[7] * cy;
+#pragma unroll
+        for (int x = 0; x < 8; ++x) t[x] = (double)w[x] * cj[x] * cy;
     }
     const double cu = j ? 1.0 : JPEZY_S, cv = i ? 1.0 : JPEZY_S;
     // (i, j) in {0,4}x{0,4}: every cosine is +-cos(pi/4) or 1, the exact value of v is a multiple of 1/8 and t a multiple
@@ -385,28 +407,24 @@ __global__ __launch_bounds__(64 * WPB, JPEZY_F32_WAVES) void fdct_quant_f32_kern
     const unsigned long long tr_t1 = __builtin_amdgcn_s_memrealtime();
 #endif
     // ---- 2. luma + row pass of the left and right block, into the transpose tile.  The integer samples stay in
-    //         registers as packed fp16 pairs (ph: luma 16, pc: chroma 8) for the rare levels 2 and 3. ----
-    uint32_t ph[8], pc[4] = { 0, 0, 0, 0 };
+    //         registers as floats (ys: luma 16, cs: chroma 8) for the chroma row pass and the rare levels 2 and 3. ----
+    float ys[16], cs[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
     {
         float4* dst = reinterpret_cast<float4*>(ldsf + m * Y_MCU + row * Y_PITCH);
-        float yv[8], X[8];
-        luma8(R, G, B, yv);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) ph[k] = pack_h2(yv[2 * k], yv[2 * k + 1]);
-        fdct8f(yv, X);
+        float X[8];
+        luma8(R, G, B, ys);
+        fdct8f(ys, X);
         dst[0] = make_float4(X[0], X[1], X[2], X[3]);
         dst[1] = make_float4(X[4], X[5], X[6], X[7]);
-        luma8(R + 2, G + 2, B + 2, yv);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) ph[4 + k] = pack_h2(yv[2 * k], yv[2 * k + 1]);
-        fdct8f(yv, X);
+        luma8(R + 2, G + 2, B + 2, ys + 8);
+        fdct8f(ys + 8, X);
         dst[2] = make_float4(X[0], X[1], X[2], X[3]);
         dst[3] = make_float4(X[4], X[5], X[6], X[7]);
     }
     __builtin_amdgcn_sched_barrier(0);   // keep the phases apart: the scheduler otherwise overlaps them and needs >80 VGPRs
     // ---- 2b. chroma samples (top-left pixel of every 2x2, ref :134-142): the odd-row lane takes its even neighbour's
-    //         pixels (DPP row_shr:4) and computes Cr, the even-row lane Cb.  Only the packed samples survive, so the
-    //         raw pixel registers die here. ----
+    //         pixels (DPP row_shr:4) and computes Cr, the even-row lane Cb.  Only the samples survive, so the raw
+    //         pixel registers die here. ----
     if (!GRAY) {
         const bool odd = (row & 1) != 0;
         uint32_t R2[4], G2[4], B2[4];
@@ -419,15 +437,11 @@ __global__ __launch_bounds__(64 * WPB, JPEZY_F32_WAVES) void fdct_quant_f32_kern
         // (Cb, Cr) = (-.1687 R - .3313 G + .5 B), (.5 R - .4187 G - .0813 B)   (ref :249-256)
         const float k1 = odd ? 0.5f : -0.1687f, k2 = odd ? -0.4187f : -0.3313f, k3 = odd ? -0.0813f : 0.5f;
         float cv[8], e[8];
-        cv[0] = chroma_px<0>(R2[0], G2[0], B2[0], k1, k2, k3, e[0]);
-        cv[1] = chroma_px<2>(R2[0], G2[0], B2[0], k1, k2, k3, e[1]);
-        cv[2] = chroma_px<0>(R2[1], G2[1], B2[1], k1, k2, k3, e[2]);
-        cv[3] = chroma_px<2>(R2[1], G2[1], B2[1], k1, k2, k3, e[3]);
+        chroma_px2<0, 2>(R2[0], G2[0], B2[0], R2[0], G2[0], B2[0], k1, k2, k3, cv[0], cv[1], e[0], e[1]);
+        chroma_px2<0, 2>(R2[1], G2[1], B2[1], R2[1], G2[1], B2[1], k1, k2, k3, cv[2], cv[3], e[2], e[3]);
         __builtin_amdgcn_sched_barrier(0);
-        cv[4] = chroma_px<0>(R2[2], G2[2], B2[2], k1, k2, k3, e[4]);
-        cv[5] = chroma_px<2>(R2[2], G2[2], B2[2], k1, k2, k3, e[5]);
-        cv[6] = chroma_px<0>(R2[3], G2[3], B2[3], k1, k2, k3, e[6]);
-        cv[7] = chroma_px<2>(R2[3], G2[3], B2[3], k1, k2, k3, e[7]);
+        chroma_px2<0, 2>(R2[2], G2[2], B2[2], R2[2], G2[2], B2[2], k1, k2, k3, cv[4], cv[5], e[4], e[5]);
+        chroma_px2<0, 2>(R2[3], G2[3], B2[3], R2[3], G2[3], B2[3], k1, k2, k3, cv[6], cv[7], e[6], e[7]);
         constexpr float TH = 0.5f - CHROMA_EPS;
         if (wave_any(absmax8(e) > TH)) {
             bool f;
@@ -441,7 +455,7 @@ __global__ __launch_bounds__(64 * WPB, JPEZY_F32_WAVES) void fdct_quant_f32_kern
             f = __builtin_fabsf(e[7]) > TH; if (wave_any(f)) { if (f) cv[7] = chroma_px_ref<2>(R2[3], G2[3], B2[3], odd); }
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) pc[k] = pack_h2(cv[2 * k], cv[2 * k + 1]);
+        for (int k = 0; k < 8; ++k) cs[k] = cv[k];
     }
     __builtin_amdgcn_sched_barrier(0);
     wave_sync();
@@ -487,14 +501,8 @@ __global__ __launch_bounds__(64 * WPB, JPEZY_F32_WAVES) void fdct_quant_f32_kern
     // ---- 5. chroma row pass, transpose, column pass ----
     if (!GRAY) {
         const bool odd = (row & 1) != 0;
-        float cv[8], cX[8];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const half2_t h = __builtin_bit_cast(half2_t, pc[k]);
-            cv[2 * k] = (float)h.x;
-            cv[2 * k + 1] = (float)h.y;
-        }
-        fdct8f(cv, cX);
+        float cX[8];
+        fdct8f(cs, cX);
         float4* dst = reinterpret_cast<float4*>(ldsf + m * C_MCU + (odd ? C_COMP : 0) + (row >> 1) * C_PITCH);
         dst[0] = make_float4(cX[0], cX[1], cX[2], cX[3]);
         dst[1] = make_float4(cX[4], cX[5], cX[6], cX[7]);
@@ -533,16 +541,16 @@ __global__ __launch_bounds__(64 * WPB, JPEZY_F32_WAVES) void fdct_quant_f32_kern
                 if (em >= valid_mcus) continue;
                 const int ei = nat >> 3, ej = nat & 7;
                 const int comp = eb < 4 ? 0 : eb - 3, tbl = comp ? 1 : 0;
-                // the 8 lanes that hold the block's rows: luma block (by,bx): rows by*8+y, words ph[4bx..]; chroma:
-                // Cb on even-row lanes, Cr on odd-row lanes, words pc[]
+                // the 8 lanes that hold the block's rows: luma block (by,bx): rows by*8+y, samples ys[8bx..]; chroma:
+                // Cb on even-row lanes, Cr on odd-row lanes, samples cs[]
                 const int by = (eb >> 1) & 1, bx = eb & 1;
                 const int first = comp ? (comp == 2 ? 4 : 0) + em : by * 32 + em;
                 const int stride = comp ? 8 : 4;
                 const bool part = (m == em) && (comp ? ((row & 1) == (comp == 2)) : ((row >> 3) == by));
                 const int yrow = comp ? (row >> 1) : (row & 7);
-                uint32_t w[4];
+                float w[8];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) w[k] = comp ? pc[k] : (bx ? ph[4 + k] : ph[k]);
+                for (int k = 0; k < 8; ++k) w[k] = comp ? cs[k] : (bx ? ys[8 + k] : ys[k]);
                 const int qv = resolve_coef<FORCE>(w, part, yrow, first, stride, ei, ej, tab->qt[tbl][nat], tab->qinv[tbl][nat]);
                 if (lane == 0) *reinterpret_cast<int16_t*>(stage + blk * STG_BLK + 2 * (int)c_zzinv[nat]) = (int16_t)qv;
                 ++done;

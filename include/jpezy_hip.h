@@ -112,7 +112,9 @@ int jpezy_dequant_idct_generic(jpezy_ctx* ctx, const int16_t* coeffs, const uint
 
 /* Test hook: route EVERY coefficient / sample through the kernels' exact-order fallback (the path a
  * guard-band hit takes).  0 = normal, 1 = reference-order path, 2 = (encode variant 1 only) the FP64 second
- * level, which may still defer to the reference-order path.  Exists so the rare branches have parity tests. */
+ * level, which may still defer to the reference-order path, 3 = (encode variant 1 only) the per-lane evaluator a
+ * quad falls back to when it has more guard-band hits than its queue holds.  Exists so the rare branches have
+ * parity tests. */
 void jpezy_ctx_set_force_exact(jpezy_ctx* ctx, int on);
 /* Encode kernel variant: 0 = FP64 butterflies (round-1 kernel), 1 = FP32 first level + FP64 second level +
  * reference-order third level.  Both produce identical coefficients; they differ in speed only. */

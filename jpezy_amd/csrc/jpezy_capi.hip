@@ -76,7 +76,8 @@ struct jpezy_ctx {
     uint16_t dq_cache[3][64];
     int coef_limit = 0;
     bool dq_valid = false;
-    int force_exact = 0;           // 0 normal, 1 everything through the reference-order path, 2 (f32 variant) through level 2
+    int force_exact = 0;           // 0 normal, 1 everything through the reference-order path, 2 (f32 variant) through level 2,
+                                   // 3 (f32 variant) through the per-lane evaluator of the queue-overflow case
     int variant = 1;               // encode kernel: 0 = FP64 butterflies, 1 = FP32 first level (default: faster)
 #ifdef JPEZY_TRACE
     unsigned long long* d_trace = nullptr;
@@ -226,7 +227,7 @@ void* jpezy_ctx_stream(const jpezy_ctx* c) { return c ? (void*)c->stream : nullp
 
 void jpezy_ctx_set_force_exact(jpezy_ctx* c, int on)
 {
-    if (c) c->force_exact = on < 0 ? 0 : on > 2 ? 2 : on;
+    if (c) c->force_exact = on < 0 ? 0 : on > 3 ? 3 : on;
 }
 
 int jpezy_ctx_set_variant(jpezy_ctx* c, int variant)

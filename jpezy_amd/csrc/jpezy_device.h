@@ -94,7 +94,8 @@ inline void fast_div_setup(unsigned d, unsigned* magic, unsigned* shift)
 
 hipError_t launch_fdct_quant(const EncParams& p, bool gray, bool force_exact, hipStream_t stream);
 // variant 1: FP32 first level, FP64 second level, reference-order third level.  force: 0 normal, 1 every
-// coefficient through the reference-order chain, 2 every coefficient through the FP64 second level.
+// coefficient through the reference-order chain, 2 every coefficient through the FP64 second level, 3 every quad
+// through the per-lane evaluator of the queue-overflow case.
 hipError_t launch_fdct_quant_f32(const EncParams& p, bool gray, int force, hipStream_t stream);
 hipError_t launch_dequant_idct(const DecParams& p, bool gray, bool force_exact, hipStream_t stream);
 

@@ -525,10 +525,66 @@ __global__ __launch_bounds__(64 * WPB, JPEZY_F32_WAVES) void fdct_quant_f32_kern
     }
     wave_sync();
 
-    // ---- 5b. levels 2 and 3 for the queued coefficients (FORCE / queue overflow: every coefficient of the quad) ----
-    {
-        const unsigned nq = queue[0];
-        const bool all = FORCE != 0 || nq > (unsigned)QUEUE_CAP;
+    // ---- 5b. levels 2 and 3 for the queued coefficients (FORCE 1/2: every coefficient of the quad) ----
+    const unsigned nq = queue[0];
+    if (FORCE == 3 || (FORCE == 0 && nq > (unsigned)QUEUE_CAP)) {
+        // More guard-band hits than the queue holds (adversarial patterns; FORCE 3 exercises it): every lane evaluates
+        // the 24 coefficients of its three block columns in the reference's order by itself.  The integer samples go
+        // to LDS as bytes (1.5 KB in the dead chroma tile); a lane walks its block row by row, keeps the eight running
+        // sums of its column (i = 0..7) and adds (pic * cos[j][x]) * cos[i][y] for x = 0..7 to each -- for every i
+        // exactly the reference's sequence (ref :146-166).  ~3,500 FP64 operations per lane, 7 us per wave, against
+        // ~1 ms for the cooperative path on all 1536 coefficients.
+        signed char* smp = reinterpret_cast<signed char*>(lds);
+        {
+            uint32_t w4[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                w4[k] = ((uint32_t)(int)ys[4 * k] & 0xFFu) | (((uint32_t)(int)ys[4 * k + 1] & 0xFFu) << 8) |
+                        (((uint32_t)(int)ys[4 * k + 2] & 0xFFu) << 16) | (((uint32_t)(int)ys[4 * k + 3] & 0xFFu) << 24);
+            const int by = row >> 3, y = row & 7;
+            uint32_t* d0 = reinterpret_cast<uint32_t*>(smp + ((m * 4 + by * 2) * 64 + y * 8));
+            d0[0] = w4[0]; d0[1] = w4[1];
+            d0[16] = w4[2]; d0[17] = w4[3];                      // the right block, 64 bytes further
+            if (!GRAY) {
+#pragma unroll
+                for (int k = 0; k < 2; ++k)
+                    w4[k] = ((uint32_t)(int)cs[4 * k] & 0xFFu) | (((uint32_t)(int)cs[4 * k + 1] & 0xFFu) << 8) |
+                            (((uint32_t)(int)cs[4 * k + 2] & 0xFFu) << 16) | (((uint32_t)(int)cs[4 * k + 3] & 0xFFu) << 24);
+                uint32_t* dc = reinterpret_cast<uint32_t*>(smp + 1024 + ((m * 2 + (row & 1)) * 64 + (row >> 1) * 8));
+                dc[0] = w4[0]; dc[1] = w4[1];
+            }
+        }
+        wave_sync();
+        const double cu = j ? 1.0 : JPEZY_S;
+#pragma unroll 1
+        for (int bc = 0; bc < (GRAY ? 2 : 3); ++bc) {
+            // block column bc of this lane: 0 top luma block, 1 bottom luma block, 2 chroma block (Cb / Cr by cq >> 3)
+            const int blk = m * BPM + (bc < 2 ? bc * 2 + bx : 4 + bx);
+            const signed char* src = bc < 2 ? smp + (m * 4 + bc * 2 + bx) * 64 : smp + 1024 + (m * 2 + bx) * 64;
+            const int tbl = bc < 2 ? 0 : 1;
+            double S[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+#pragma unroll 1
+            for (int y = 0; y < 8; ++y) {
+                // x is not unrolled: this path must not raise the kernel's register count (it is never the hot one)
+#pragma unroll 1
+                for (int x = 0; x < 8; ++x) {
+                    const double px = (double)(int)src[y * 8 + x] * c_cos[j * 8 + x];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) S[i] += px * c_cos[i * 8 + y];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const double cv = i ? 1.0 : JPEZY_S;
+                const int dct = (int)(S[i] * cu * cv / 4);
+                const int qv = dct / tab->qt[tbl][i * 8 + j];
+                *reinterpret_cast<int16_t*>(stage + blk * STG_BLK + 2 * (int)c_zzinv[i * 8 + j]) = (int16_t)qv;
+            }
+        }
+        if (lane == 0) atomicAdd(p.fallback_count + (qidx & (COUNTER_SHARDS - 1)), (unsigned long long)(4 * BPM * 64));
+        wave_sync();
+    } else {
+        const bool all = FORCE != 0;
         const unsigned total = all ? (unsigned)(4 * BPM * 64) : nq;
         if (total) {
             const int valid_mcus = min(4, p.mcu_cols - quad_x * 4);
@@ -607,6 +663,8 @@ static void enc_f32_launch2(const EncParams& p, int force, dim3 grid, hipStream_
         hipLaunchKernelGGL((f32::fdct_quant_f32_kernel<GRAY, ALIGNED, 1>), grid, dim3(64 * WPB), 0, s, p);
     else if (force == 2)
         hipLaunchKernelGGL((f32::fdct_quant_f32_kernel<GRAY, ALIGNED, 2>), grid, dim3(64 * WPB), 0, s, p);
+    else if (force == 3)
+        hipLaunchKernelGGL((f32::fdct_quant_f32_kernel<GRAY, ALIGNED, 3>), grid, dim3(64 * WPB), 0, s, p);
     else
         hipLaunchKernelGGL((f32::fdct_quant_f32_kernel<GRAY, ALIGNED, 0>), grid, dim3(64 * WPB), 0, s, p);
 }

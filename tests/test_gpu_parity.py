@@ -38,7 +38,7 @@ def ctx(J, request):
 def test_golden_fixtures(J, ctx, golden_dir, name):
     z = np.load(golden_dir / f"{name}.npz")
     W, H = int(z["W"]), int(z["H"])
-    for force in (0, 1, 2):
+    for force in (0, 1, 2, 3):
         ctx.set_force_exact(force)
         co = ctx.fdct_quant(z["r"], z["g"], z["b"], W, H, gray=False)
         cog = ctx.fdct_quant(z["r"], z["g"], z["b"], W, H, gray=True)
@@ -103,6 +103,28 @@ def test_exact_fallback_branch_alone(J, ctx, oracle):
     assert n_dec == W * H + 2 * (W // 2) * (H // 2) * 2   # luma samples + chroma samples (each chroma row is held by 2 lanes)
     for a, e in zip(dec, oracle.decode_planes(want, oracle.make_info(W, H))):
         assert np.array_equal(a, e)
+
+
+def test_queue_overflow_evaluator(J, ctx, oracle):
+    """force_exact 3 (encode variant 1): every quad takes the per-lane evaluator that a quad with more guard-band hits
+    than its queue holds falls back to -- random, structured and ragged inputs, colour and gray, same bits."""
+    ctx.set_force_exact(3)
+    try:
+        for (W, H) in ((16, 16), (80, 48), (33, 17), (208, 120), (720, 486)):
+            r, g, b = oracle.synth_rgb(W, H, frame=7 * W + H)
+            for gray in (False, True):
+                want = oracle.encode_coeffs(r, g, b, W, H, gray)
+                ctx.fallback_count()
+                got = ctx.fdct_quant(r, g, b, W, H, gray=gray)
+                assert np.array_equal(got, want), (W, H, gray)
+                if ctx.variant == 1:
+                    quads = want.shape[0] * ((want.shape[1] + 3) // 4)
+                    assert ctx.fallback_count() == quads * 4 * want.shape[2] * 64
+        yy, xx = np.mgrid[0:64, 0:256]
+        p = np.where((xx + yy) % 2 == 0, 255, 0).astype(np.uint8).reshape(-1)
+        assert np.array_equal(ctx.fdct_quant(p, p, p, 256, 64), oracle.encode_coeffs(p, p, p, 256, 64, False))
+    finally:
+        ctx.set_force_exact(0)
 
 
 def test_structured_inputs_that_sit_on_truncation_boundaries(J, ctx, oracle):

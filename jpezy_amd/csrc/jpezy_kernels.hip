@@ -708,10 +708,14 @@ __global__ __launch_bounds__(64 * WPB, JPEZY_DEC_WAVES) void dequant_idct_kernel
             if (myflags & 0x00FF0000u) myblocks |= 1u << (m * BPM + 4);
             if (myflags & 0xFF000000u) myblocks |= 1u << (m * BPM + 5);
         }
-        wave_sync();                                               // all tile reads are done
-        if (myblocks) atomicOr(need_blocks, myblocks);
-        wave_sync();
-        const unsigned all_todo = __builtin_amdgcn_readfirstlane((int)need_blocks[0]);
+        // common case: no lane of the wave has a flagged sample -- one vote, no LDS traffic
+        unsigned all_todo = 0;
+        if (wave_any(myblocks != 0)) {
+            wave_sync();                                           // all tile reads are done
+            if (myblocks) atomicOr(need_blocks, myblocks);
+            wave_sync();
+            all_todo = __builtin_amdgcn_readfirstlane((int)need_blocks[0]);
+        }
         if (all_todo) {
             constexpr unsigned LUMA_BLOCKS = 0x0F | (0x0F << 6) | (0x0F << 12) | (0x0F << 18);   // blocks 0-3 of the 4 MCUs
             unsigned done = 0;

@@ -551,13 +551,20 @@ __global__ __launch_bounds__(64 * WPB, JPEZY_DEC_WAVES) void dequant_idct_kernel
         const int valid_bytes = valid_mcus * BPM * 128;
         const uint4* g4 = reinterpret_cast<const uint4*>(gbase);
         uint4* s4 = reinterpret_cast<uint4*>(lds);
+        // all three loads are issued before the first one is waited for (one memory latency per wave, not three)
+        uint4 v[3];
+        if (valid_mcus == 4) {                       // wave-uniform; every quad but the last of a ragged row
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const int c = k * 64 + lane;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (c * 16 < valid_bytes) v = g4[c];
-            s4[c] = v;
+            for (int k = 0; k < 3; ++k) v[k] = g4[k * 64 + lane];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                v[k] = make_uint4(0, 0, 0, 0);
+                if ((k * 64 + lane) * 16 < valid_bytes) v[k] = g4[k * 64 + lane];
+            }
         }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) s4[k * 64 + lane] = v[k];
     }
     wave_sync();
 

@@ -810,9 +810,17 @@ __global__ __launch_bounds__(64 * WPB, JPEZY_DEC_WAVES) void dequant_idct_kernel
         uint8_t* obp = p.b + (size_t)frame * p.plane_stride + (size_t)py * W;
         if (ALIGNED) {
             const size_t off = (size_t)mcu_x * 16;
+#ifdef JPEZY_DEC_NT
             nt_store16(reinterpret_cast<uint4*>(orp + off), make_uint4(Rw[0], Rw[1], Rw[2], Rw[3]));
             nt_store16(reinterpret_cast<uint4*>(ogp + off), make_uint4(Gw[0], Gw[1], Gw[2], Gw[3]));
             nt_store16(reinterpret_cast<uint4*>(obp + off), make_uint4(Bw[0], Bw[1], Bw[2], Bw[3]));
+#else
+            // plain stores: a quad covers only 64 bytes of a pixel row, the neighbouring wave writes the other half of
+            // the 128-byte line -- the L2 merges them; non-temporal stores go out as partial lines (WRITE_SIZE +40 %)
+            *reinterpret_cast<uint4*>(orp + off) = make_uint4(Rw[0], Rw[1], Rw[2], Rw[3]);
+            *reinterpret_cast<uint4*>(ogp + off) = make_uint4(Gw[0], Gw[1], Gw[2], Gw[3]);
+            *reinterpret_cast<uint4*>(obp + off) = make_uint4(Bw[0], Bw[1], Bw[2], Bw[3]);
+#endif
         } else {
 #pragma unroll
             for (int k = 0; k < 16; ++k) {

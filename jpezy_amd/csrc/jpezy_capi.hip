@@ -351,7 +351,8 @@ static int upload_dequant(jpezy_ctx* c, const uint16_t qt[4][64], const uint8_t 
         for (int u = 0; u < 8; ++u)
             for (int v = 0; v < 8; ++v) {
                 const double cu = u ? 1.0 : S, cv = v ? 1.0 : S;
-                h_scale[k][u][v] = cu * cv * (double)sel[k][v * 8 + u];
+                // the reference's final / 4 (ref :667) is folded in here: an exact scaling of every intermediate value
+                h_scale[k][u][v] = cu * cv * (double)sel[k][v * 8 + u] * 0.25;
                 h_qt[k][v * 8 + u] = sel[k][v * 8 + u];
             }
     HIP_TRY(hipMemcpy(c->d_dqscale, h_scale, sizeof h_scale, hipMemcpyHostToDevice));

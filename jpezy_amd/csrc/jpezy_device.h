@@ -73,7 +73,7 @@ struct DecParams {
     uint8_t* g;
     uint8_t* b;
     size_t plane_stride;
-    const double* dqscale;    // [3 comps][8 (u=lane col)][8 (v)] : cu*cv*Q[v*8+u]   (dequant folded in)
+    const double* dqscale;    // [3 comps][8 (u=lane col)][8 (v)] : cu*cv*Q[v*8+u] / 4   (dequant and the final / 4 folded in)
     const int* dqt;           // [3 comps][64] natural order quant values (exact path)
     int coef_limit;           // 32768 / largest quantiser: raw coefficients above it send the wave to the exact path
     unsigned long long* fallback_count;

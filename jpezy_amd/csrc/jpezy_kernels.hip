@@ -469,12 +469,12 @@ __device__ __forceinline__ int exact_idct_sample_sparse(const int2* __restrict__
 // when the reduction says that some lane of the wave has a sample in the band.
 constexpr float SAMPLE_EPS = 0x1p-18f;
 constexpr float SAMPLE_TH = 0.5f - SAMPLE_EPS;
-// sum512 = row sum + 512: the level shift enters the row pass as one addition to its DC input (bias_row below), so
-// that a sample costs one multiplication here.  fl(s + 512) / 4 == fl(s / 4 + 128) because scaling by 4 is exact; a
-// DC-only block therefore still reproduces the reference bit for bit (its row sum reaches this point unrounded).
-__device__ __forceinline__ int sample_of(double sum512, float& e)
+// v = row sum / 4 + 128 arrives ready-made: the / 4 is folded into the dequantiser constants (an exact scaling of every
+// intermediate value) and the level shift enters the row pass as one addition to its DC input.  fl(s/4 + 128) is what
+// the reference forms (ref :667); a DC-only block still reproduces it bit for bit (its term reaches the addition
+// unrounded, scaled by an exact 1/4).
+__device__ __forceinline__ int sample_of(double v, float& e)
 {
-    const double v = sum512 * 0.25;
     e = (float)__builtin_amdgcn_fract(v) - 0.5f;
     return (int)v;
 }
@@ -594,13 +594,13 @@ __global__ __launch_bounds__(64 * WPB, JPEZY_DEC_WAVES) void dequant_idct_kernel
         int c[8], acor;
 #pragma unroll
         for (int v = 0; v < 8; ++v) { c[v] = bt[zp[v]]; in[v] = (double)c[v] * dq[v]; cmx = max(cmx, c[v]); cmn = min(cmn, c[v]); }
-        if (u == 0) in[0] = cucv_dc * (double)(c[0] * p.dqt[0]);
+        if (u == 0) in[0] = cucv_dc * (double)(c[0] * p.dqt[0]) * 0.25;
         acor = (u ? c[0] : 0) | c[1] | c[2] | c[3] | c[4] | c[5] | c[6] | c[7];
         ac_top = __ballot(acor != 0);
         idct8(in, gtop);
 #pragma unroll
         for (int v = 0; v < 8; ++v) { c[v] = bb[zp[v]]; in[v] = (double)c[v] * dq[v]; cmx = max(cmx, c[v]); cmn = min(cmn, c[v]); }
-        if (u == 0) in[0] = cucv_dc * (double)(c[0] * p.dqt[0]);
+        if (u == 0) in[0] = cucv_dc * (double)(c[0] * p.dqt[0]) * 0.25;
         acor = (u ? c[0] : 0) | c[1] | c[2] | c[3] | c[4] | c[5] | c[6] | c[7];
         ac_bot = __ballot(acor != 0);
         idct8(in, gbot);
@@ -614,7 +614,7 @@ __global__ __launch_bounds__(64 * WPB, JPEZY_DEC_WAVES) void dequant_idct_kernel
                 cmx = max(cmx, c[v]);
                 cmn = min(cmn, c[v]);
             }
-            if (u == 0) in[0] = cucv_dc * (double)(c[0] * p.dqt[comp * 64]);
+            if (u == 0) in[0] = cucv_dc * (double)(c[0] * p.dqt[comp * 64]) * 0.25;
             acor = (u ? c[0] : 0) | c[1] | c[2] | c[3] | c[4] | c[5] | c[6] | c[7];
             ac_chr = __ballot(acor != 0);
             idct8(in, gc);
@@ -651,7 +651,7 @@ __global__ __launch_bounds__(64 * WPB, JPEZY_DEC_WAVES) void dequant_idct_kernel
             const double2* src = reinterpret_cast<const double2*>(lds + m * DH_MCU + row * DH_PITCH);
 #pragma unroll
             for (int k = 0; k < 4; ++k) { const double2 t = src[k]; in[2 * k] = t.x; in[2 * k + 1] = t.y; }
-            in[0] += 512.0;          // level shift 128 * 4, see sample_of
+            in[0] += 128.0;          // level shift, see sample_of
             idct8(in, out);
             float e[8];
 #pragma unroll
@@ -679,8 +679,8 @@ __global__ __launch_bounds__(64 * WPB, JPEZY_DEC_WAVES) void dequant_idct_kernel
             in[2 * k] = a.x; in[2 * k + 1] = a.y;
             in[8 + 2 * k] = b.x; in[8 + 2 * k + 1] = b.y;
         }
-        in[0] += 512.0;
-        in[8] += 512.0;
+        in[0] += 128.0;
+        in[8] += 128.0;
         idct8(in, out);
         idct8(in + 8, out + 8);
         {

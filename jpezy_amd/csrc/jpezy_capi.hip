@@ -123,7 +123,8 @@ jpezy_ctx* jpezy_ctx_create(int device)
     }
     jpezy_ctx* c = new jpezy_ctx;
     c->device = device;
-    static DeviceTables h;             // 33 KB: keep it off the stack
+    std::vector<DeviceTables> hbuf(1); // 33 KB: off the stack, and private to this call (contexts may be created concurrently)
+    DeviceTables& h = hbuf[0];
     const double S = JPEZY_INV_SQRT2;
     for (int t = 0; t < 2; ++t) {
         for (int j = 0; j < 8; ++j)
@@ -521,7 +522,7 @@ int ensure_code_tables(jpezy_ctx* c)
     uint16_t code[4][256];
     uint8_t len[4][256];
     jpezy_host::enc_code_tables(code, len);
-    static jpezy_dev::entropy::CodeTables h;
+    jpezy_dev::entropy::CodeTables h;
     std::memset(&h, 0, sizeof h);
     for (int t = 0; t < 2; ++t) {      // DHT order: YDc, CDc, YAc, CAc
         for (int k = 0; k < 12; ++k) h.dc[t][k] = ((uint32_t)code[t][k] << 8) | len[t][k];

@@ -360,3 +360,38 @@ def test_generic_decode_of_libjpeg_files(J, ctx, oracle, kw):
         fused = ctx.dequant_idct(co, Wd, Hd, qt=info.qt, comp_tq=tuple(info.Tq[i] for i in range(3)))
         for a, e in zip(fused, oracle.decode_planes(oco, oinfo, False)):
             assert np.array_equal(a, e)
+
+
+def test_two_contexts_from_two_threads(J, oracle):
+    """ABI contract (include/jpezy_hip.h): a context is used by one thread at a time, distinct contexts may run
+    concurrently -- two host threads create their own context and encode/decode different frames at the same time."""
+    import threading
+    W, H = 320, 240
+    results, errors = {}, []
+
+    def work(k):
+        try:
+            c = J.Context(0)
+            r, g, b = oracle.synth_rgb(W, H, frame=100 + k)
+            for _ in range(5):
+                co = c.fdct_quant(r, g, b, W, H)
+                dec = c.dequant_idct(co, W, H)
+                jpg = c.encode_jpeg(r, g, b, W, H)
+            results[k] = (co, dec, jpg, (r, g, b))
+            c.close()
+        except Exception as e:          # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for k in range(2):
+        co, dec, jpg, (r, g, b) = results[k]
+        want = oracle.encode_coeffs(r, g, b, W, H, False)
+        assert np.array_equal(co, want)
+        assert jpg == oracle.encode_jpeg(r, g, b, W, H, False)
+        for a, e in zip(dec, oracle.decode_planes(want, oracle.make_info(W, H))):
+            assert np.array_equal(a, e)

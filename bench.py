@@ -87,6 +87,9 @@ def main():
     ap.add_argument("--no-graph", action="store_true",
                     help="launch the timed steps one by one instead of replaying them as one captured hipGraph "
                          "(the graph saves ~1.5 us of launch gap per 30 us step; same kernels, same work)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="development aid: initialise torch.distributed (nccl = RCCL) even with one rank, so that the "
+                         "barrier / all_reduce / all_gather calls of the N>1 path run on a single-GPU box")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="development aid: run the N>1 control flow with every rank on GPU 0 and the gloo backend "
                          "(RCCL refuses two ranks on one device); the numbers mean nothing")
@@ -110,8 +113,12 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     red_dev = dev                       # where the small reduction tensors live
-    if world > 1:
+    multi = world > 1 or args.force_dist       # the distributed calls are made
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if args.rehearse_on_one_gpu:
             dist.init_process_group("gloo")
             red_dev = torch.device("cpu")
@@ -157,7 +164,7 @@ def main():
     ctx.fallback_count()           # reset the counter
 
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize(dev)
     graph = None
@@ -175,6 +182,7 @@ def main():
         torch.cuda.synchronize(dev)
         graph.replay()
         torch.cuda.synchronize(dev)
+        ctx.fallback_count()       # reset: only the timed replay is counted
     t0 = time.perf_counter()
     ev0.record(stream)
     if graph is not None:
@@ -184,14 +192,14 @@ def main():
             step(i)
     ev1.record(stream)
     torch.cuda.synchronize(dev)
-    if world > 1:
+    if multi:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     ev_ms = ev0.elapsed_time(ev1)
     nfallback = ctx.fallback_count()
 
     t = torch.tensor([elapsed, ev_ms], dtype=torch.float64, device=red_dev)
-    if world > 1:
+    if multi:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed, ev_ms = float(t[0]), float(t[1])
 
@@ -215,7 +223,7 @@ def main():
         del src_bufs, dst_bufs
 
     gather = None
-    if world > 1 and not args.no_gather:
+    if multi and not args.no_gather:
         # north_star: gather the coefficient buffers over xGMI -- jpezy_amd.sharding.gather_coefficients,
         # one all_gather of this rank's step output (fps frames per rank).
         from jpezy_amd import sharding
@@ -285,7 +293,7 @@ def main():
         print(json.dumps(out), flush=True)
 
     ctx.close()
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 

@@ -155,6 +155,15 @@ long jpezy_write_jpeg_gpu(jpezy_ctx* ctx, const int16_t* d_coeffs, int W, int H,
 int jpezy_write_jpeg_gpu_batch(jpezy_ctx* ctx, const int16_t* d_coeffs, int W, int H, int gray, int n_frames,
                                const char* comment, uint8_t* out, size_t cap, long* sizes);
 /*
+ * Device-resident, asynchronous form of the same: everything is enqueued on `stream` (HIP semantics, NULL = default
+ * stream; the coefficients must have been produced on it or be complete), nothing is copied to the host, no host
+ * synchronisation.  Frame f's complete file (header, entropy-coded segment, EOI) is written at d_out + f*out_stride
+ * and d_sizes[f] (device memory) receives its length, JPEZY_E_FORMAT or JPEZY_E_NOSPACE (out_stride too small; nothing
+ * is written past it).  Scratch is sized for the worst case of 208 bytes per block.
+ */
+int jpezy_write_jpeg_gpu_dev(jpezy_ctx* ctx, const int16_t* d_coeffs, int W, int H, int gray, int n_frames,
+                             const char* comment, uint8_t* d_out, size_t out_stride, long long* d_sizes, void* stream);
+/*
  * encoder::encode end to end (encoder/jpezy_encoder.hpp:38-77) with both stages on the GPU: host planar r,g,b in,
  * host .jpg bytes out; returns the byte count (the value encoder::encode returns) or a negative status.
  */

@@ -62,6 +62,7 @@ ABI = [
     ("jpezy_write_jpeg_batch", C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, _vp, C.c_size_t, C.POINTER(C.c_long), C.c_int]),
     ("jpezy_write_jpeg_gpu", C.c_long, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_char_p, _vp, C.c_size_t]),
     ("jpezy_write_jpeg_gpu_batch", C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, _vp, C.c_size_t, C.POINTER(C.c_long)]),
+    ("jpezy_write_jpeg_gpu_dev", C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, _vp, C.c_size_t, _vp, _vp]),
     ("jpezy_encode_jpeg", C.c_long, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_char_p, _vp, C.c_size_t]),
     ("jpezy_read_jpeg", C.c_int, [_vp, C.c_size_t, C.POINTER(FrameInfo), _vp, C.c_size_t]),
 ]
@@ -217,6 +218,18 @@ class Context:
         rc = lib.jpezy_write_jpeg_gpu_batch(self._h, d_coeffs.data_ptr(), W, H, int(gray), n_frames, comment, _np_ptr(buf), cap, sizes)
         _check(rc)
         return [buf[f * cap: f * cap + sizes[f]].tobytes() for f in range(n_frames)]
+
+    def write_jpeg_gpu_dev(self, d_coeffs, W, H, d_out, d_sizes, gray=False, comment=None, n_frames=1, stream=None):
+        """Asynchronous, device-resident: d_out is a torch uint8 tensor [n_frames, out_stride], d_sizes int64 [n_frames];
+        every frame's complete .jpg is left in d_out[f, :d_sizes[f]]."""
+        import torch
+        if stream is None:
+            stream = torch.cuda.current_stream(d_coeffs.device).cuda_stream
+        if comment is None:
+            comment = b"Encoded by JPEZY" if gray else b"Encoded by jpezy"
+        stride = d_out.numel() // n_frames
+        _check(load_library().jpezy_write_jpeg_gpu_dev(self._h, d_coeffs.data_ptr(), W, H, int(gray), n_frames, comment,
+                                                       d_out.data_ptr(), stride, d_sizes.data_ptr(), stream))
 
     def encode_jpeg(self, r, g, b, W, H, gray=False, comment=None):
         """Host planes -> .jpg bytes, both stages on the GPU (encoder::encode end to end)."""

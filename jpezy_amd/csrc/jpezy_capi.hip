@@ -88,6 +88,9 @@ struct jpezy_ctx {
     DevBuf e_bits, e_off, e_tmp, e_small, e_U, e_cnt, e_ffoff, e_out, e_coef;
     uint8_t* e_pinned = nullptr;   // pinned host staging of the stuffed streams
     size_t e_pinned_cap = 0;
+    DevBuf e_hdr;                  // JFIF header bytes of the device-resident variant (cached per W, H, comment)
+    uint8_t e_hdr_host[1024];
+    size_t e_hdr_len = 0;
 };
 
 extern "C" {
@@ -211,7 +214,7 @@ void jpezy_ctx_destroy(jpezy_ctx* c)
     c->scratch.release();
     if (c->d_codes) (void)hipFree(c->d_codes);
     if (c->e_pinned) (void)hipHostFree(c->e_pinned);
-    for (DevBuf* b : { &c->e_bits, &c->e_off, &c->e_tmp, &c->e_small, &c->e_U, &c->e_cnt, &c->e_ffoff, &c->e_out, &c->e_coef }) b->release();
+    for (DevBuf* b : { &c->e_bits, &c->e_off, &c->e_tmp, &c->e_small, &c->e_U, &c->e_cnt, &c->e_ffoff, &c->e_out, &c->e_coef, &c->e_hdr }) b->release();
     delete c;
 }
 
@@ -628,6 +631,70 @@ int entropy_chunk(jpezy_ctx* c, const int16_t* d_coeffs, int W, int H, int gray,
 }
 
 }  // namespace
+
+// Device-resident, asynchronous variant: everything is enqueued on `stream`, nothing is copied to the host.
+int jpezy_write_jpeg_gpu_dev(jpezy_ctx* c, const int16_t* d_coeffs, int W, int H, int gray, int n_frames, const char* comment,
+                             uint8_t* d_out, size_t out_stride, long long* d_sizes, void* stream)
+{
+    namespace E = jpezy_dev::entropy;
+    if (int rc = check_dims(c, W, H, n_frames)) return rc;
+    if (!d_coeffs || !d_out || !d_sizes) return set_err(JPEZY_E_BADARG, "write_jpeg_gpu_dev: null pointer");
+    HIP_TRY(hipSetDevice(c->device));
+    if (int rc = ensure_code_tables(c)) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    // header bytes: cached on the device per (W, H, comment) -- uploaded outside any capture on first use
+    uint8_t hdr[1024];
+    const size_t hdr_len = jpezy_host::write_header(W, H, comment, hdr, sizeof hdr);
+    if (!hdr_len) return set_err(JPEZY_E_BADARG, "write_jpeg_gpu_dev: comment too long");
+    if (c->e_hdr_len != hdr_len || std::memcmp(c->e_hdr_host, hdr, hdr_len)) {
+        if (int rc = c->e_hdr.reserve(sizeof hdr)) return rc;
+        HIP_TRY(hipStreamSynchronize(s));                    // an earlier launch may still read the old header
+        HIP_TRY(hipMemcpy(c->e_hdr.p, hdr, hdr_len, hipMemcpyHostToDevice));
+        std::memcpy(c->e_hdr_host, hdr, hdr_len);
+        c->e_hdr_len = hdr_len;
+    }
+    const size_t nmcu = (size_t)jpezy_mcu_cols(W) * jpezy_mcu_rows(H);
+    const size_t nblk = nmcu * 6;
+    const size_t chunk = E::chunk_bytes();
+    // worst case per block: 64 x (16-bit code + 10 value bits) = 208 bytes
+    const size_t u_stride = (nblk * 208 + 8 + chunk - 1) / chunk * chunk;
+    const int per = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_frames, ((size_t)1 << 30) / u_stride));
+    const size_t cpf = jpezy_coeff_count(W, H, gray);
+    for (int f0 = 0; f0 < n_frames; f0 += per) {
+        const int F = std::min(per, n_frames - f0);
+        const size_t N = nblk * (size_t)F, nchunks = u_stride / chunk * F;
+        E::Job job;
+        job.coeffs = d_coeffs + (size_t)f0 * cpf;
+        job.coeffs_per_frame = cpf;
+        job.tables = c->d_codes;
+        job.blocks_per_frame = (unsigned)nblk;
+        job.bpm = gray ? 4 : 6;
+        job.n_frames = F;
+        if (int rc = c->e_bits.reserve(N * sizeof(uint32_t))) return rc;
+        if (int rc = c->e_off.reserve((N + 1) * sizeof(unsigned long long))) return rc;
+        if (int rc = c->e_tmp.reserve(E::scan_tmp_elems(nchunks > N ? nchunks : N) * sizeof(unsigned long long))) return rc;
+        if (int rc = c->e_small.reserve((size_t)F * 8 * sizeof(unsigned long long))) return rc;
+        if (int rc = c->e_U.reserve(u_stride * F)) return rc;
+        if (int rc = c->e_cnt.reserve(nchunks * sizeof(uint32_t))) return rc;
+        if (int rc = c->e_ffoff.reserve((nchunks + 1) * sizeof(unsigned long long))) return rc;
+        unsigned* d_status = (unsigned*)c->e_small.p;
+        unsigned long long* d_bytes = (unsigned long long*)c->e_small.p + F;
+        uint8_t* out = d_out + (size_t)f0 * out_stride;
+        HIP_TRY(hipMemsetAsync(d_status, 0, sizeof(unsigned) * F, s));
+        HIP_TRY(hipMemsetAsync(c->e_U.p, 0, u_stride * F, s));
+        HIP_TRY(E::launch_block_bits(job, (uint32_t*)c->e_bits.p, d_status, s));
+        HIP_TRY(E::launch_scan_u32((const uint32_t*)c->e_bits.p, (unsigned long long*)c->e_off.p, N, (unsigned long long*)c->e_tmp.p, s));
+        HIP_TRY(E::launch_frame_bytes((const unsigned long long*)c->e_off.p, nblk, F, d_bytes, s));
+        HIP_TRY(E::launch_emit(job, (const unsigned long long*)c->e_off.p, (uint32_t*)c->e_U.p, u_stride / 4, s));
+        HIP_TRY(E::launch_ff_count((const uint32_t*)c->e_U.p, u_stride / 4, d_bytes, F, (uint32_t*)c->e_cnt.p, s));
+        HIP_TRY(E::launch_scan_u32((const uint32_t*)c->e_cnt.p, (unsigned long long*)c->e_ffoff.p, nchunks, (unsigned long long*)c->e_tmp.p, s));
+        HIP_TRY(E::launch_plan_and_header(d_bytes, (const unsigned long long*)c->e_ffoff.p, u_stride / chunk, d_status, F,
+                                          (const uint8_t*)c->e_hdr.p, hdr_len, out, out_stride, d_sizes + f0, s));
+        HIP_TRY(E::launch_stuff((const uint32_t*)c->e_U.p, u_stride / 4, d_bytes, F, (const unsigned long long*)c->e_ffoff.p, out + hdr_len,
+                                out_stride, s));
+    }
+    return JPEZY_OK;
+}
 
 int jpezy_write_jpeg_gpu_batch(jpezy_ctx* c, const int16_t* d_coeffs, int W, int H, int gray, int n_frames, const char* comment,
                                uint8_t* out, size_t cap, long* sizes)

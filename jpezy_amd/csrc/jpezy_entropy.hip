@@ -414,5 +414,55 @@ hipError_t launch_stuff(const uint32_t* U, size_t u_stride_words, const unsigned
 
 size_t chunk_bytes() { return CHUNK; }
 
+// ---- fully device-side variant: sizes stay on the device, no host sync ----
+// bytes[f] = ceil(bits of frame f / 8)
+__global__ void frame_bytes_kernel(const unsigned long long* off, size_t per, int n_frames, unsigned long long* bytes)
+{
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f < n_frames) bytes[f] = (off[(size_t)(f + 1) * per] - off[(size_t)f * per] + 7) / 8;
+}
+
+// one thread per frame, after the 0xFF scan: decide whether the frame fits, write its size and its EOI marker, and
+// disable the copy kernels for frames that failed (bytes[f] = 0)
+__global__ void plan_kernel(unsigned long long* bytes, const unsigned long long* ffoff, size_t chunks_per_frame, const unsigned* status,
+                            int n_frames, size_t hdr_len, uint8_t* out, size_t out_stride, long long* sizes)
+{
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= n_frames) return;
+    const unsigned long long body = bytes[f] + (ffoff[(size_t)(f + 1) * chunks_per_frame] - ffoff[(size_t)f * chunks_per_frame]);
+    const unsigned long long total = hdr_len + body + 2;
+    if (status[f]) { sizes[f] = -5; bytes[f] = 0; return; }              // JPEZY_E_FORMAT
+    if (total > out_stride) { sizes[f] = -6; bytes[f] = 0; return; }     // JPEZY_E_NOSPACE
+    uint8_t* dst = out + (size_t)f * out_stride;
+    dst[hdr_len + body] = 0xFF;
+    dst[hdr_len + body + 1] = 0xD9;
+    sizes[f] = (long long)total;
+}
+
+__global__ void header_copy_kernel(const uint8_t* hdr, size_t hdr_len, const unsigned long long* bytes, int n_frames, uint8_t* out,
+                                   size_t out_stride)
+{
+    const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t f = g / hdr_len, i = g - f * hdr_len;
+    if (f < (size_t)n_frames && bytes[f]) out[f * out_stride + i] = hdr[i];
+}
+
+hipError_t launch_frame_bytes(const unsigned long long* off, size_t per, int n_frames, unsigned long long* bytes, hipStream_t s)
+{
+    hipLaunchKernelGGL(frame_bytes_kernel, dim3((unsigned)((n_frames + 63) / 64)), dim3(64), 0, s, off, per, n_frames, bytes);
+    return hipGetLastError();
+}
+
+hipError_t launch_plan_and_header(unsigned long long* bytes, const unsigned long long* ffoff, size_t chunks_per_frame, const unsigned* status,
+                                  int n_frames, const uint8_t* hdr, size_t hdr_len, uint8_t* out, size_t out_stride, long long* sizes,
+                                  hipStream_t s)
+{
+    hipLaunchKernelGGL(plan_kernel, dim3((unsigned)((n_frames + 63) / 64)), dim3(64), 0, s, bytes, ffoff, chunks_per_frame, status, n_frames,
+                       hdr_len, out, out_stride, sizes);
+    const size_t n = hdr_len * (size_t)n_frames;
+    hipLaunchKernelGGL(header_copy_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, hdr, hdr_len, bytes, n_frames, out, out_stride);
+    return hipGetLastError();
+}
+
 }  // namespace entropy
 }  // namespace jpezy_dev

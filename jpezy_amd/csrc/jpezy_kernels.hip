@@ -503,7 +503,6 @@ __device__ __forceinline__ unsigned guard_bits8(const float* e, bool dc_only)
 // (v_cvt_pk_i16_i32), saturate those to bytes (v_sat_pk_u8_i16), join the halves (v_perm_b32): 5 instructions for 4 values.
 __device__ __forceinline__ uint32_t clamp_pack4(const int* v)
 {
-    typedef short short2_t __attribute__((ext_vector_type(2)));
     const uint32_t p01 = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16(v[0], v[1]));
     const uint32_t p23 = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16(v[2], v[3]));
     uint32_t b01, b23;

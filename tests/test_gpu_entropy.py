@@ -123,3 +123,54 @@ def test_full_4096_frame(J, ctx, oracle):
     got = ctx.write_jpeg_gpu(_dev(co), W, H)[0]
     assert len(got) == len(want) and hashlib.sha256(got).digest() == hashlib.sha256(want).digest()
     torch.cuda.synchronize()
+
+
+def test_device_resident_async_variant(J, ctx, oracle):
+    """jpezy_write_jpeg_gpu_dev: whole files (header + entropy segment + EOI) left in device memory, sizes on the device,
+    no host sync inside; must equal the host writer byte for byte, report NOSPACE / FORMAT per frame, and be
+    capturable in a hipGraph together with the FDCT kernel."""
+    import torch
+    W, H, n = 208, 120, 4
+    frames = [oracle.synth_rgb(W, H, frame=40 + f) for f in range(n)]
+    planes = [torch.from_numpy(np.stack([fr[k] for fr in frames])).cuda() for k in range(3)]
+    co = torch.empty((n, J.coeff_count(W, H, False)), dtype=torch.int16, device="cuda")
+    stride = 65536
+    out = torch.zeros((n, stride), dtype=torch.uint8, device="cuda")
+    sizes = torch.zeros(n, dtype=torch.int64, device="cuda")
+    ctx.fdct_quant_dev(planes[0], planes[1], planes[2], W, H, co, n_frames=n)
+    ctx.write_jpeg_gpu_dev(co, W, H, out, sizes, n_frames=n)
+    torch.cuda.synchronize()
+    want = [oracle.encode_jpeg(*frames[f], W, H, False) for f in range(n)]
+    for f in range(n):
+        assert int(sizes[f]) == len(want[f])
+        assert out[f, :len(want[f])].cpu().numpy().tobytes() == want[f]
+    # the same two launches replayed from a captured graph
+    out.zero_(); sizes.zero_()
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        with torch.cuda.graph(g, stream=s):
+            ctx.fdct_quant_dev(planes[0], planes[1], planes[2], W, H, co, n_frames=n, stream=s.cuda_stream)
+            ctx.write_jpeg_gpu_dev(co, W, H, out, sizes, n_frames=n, stream=s.cuda_stream)
+    g.replay()
+    torch.cuda.synchronize()
+    for f in range(n):
+        assert out[f, :int(sizes[f])].cpu().numpy().tobytes() == want[f]
+    # a stride that is too small: NOSPACE (-6), nothing written past the stride
+    small = torch.zeros((n, 1024), dtype=torch.uint8, device="cuda")
+    ctx.write_jpeg_gpu_dev(co, W, H, small, sizes, n_frames=n)
+    torch.cuda.synchronize()
+    assert all(int(v) == -6 for v in sizes)
+    # an out-of-table coefficient in frame 2 only: FORMAT (-5) for that frame, the others still right
+    co2 = co.clone()
+    co2[2, 5] = 1024
+    ctx.write_jpeg_gpu_dev(co2, W, H, out, sizes, n_frames=n)
+    torch.cuda.synchronize()
+    assert int(sizes[2]) == -5 and [int(sizes[f]) for f in (0, 1, 3)] == [len(want[f]) for f in (0, 1, 3)]
+    # gray
+    cog = torch.from_numpy(ctx.fdct_quant(*frames[0], W, H, gray=True)).cuda()
+    ctx.write_jpeg_gpu_dev(cog, W, H, out[:1], sizes[:1], gray=True)
+    torch.cuda.synchronize()
+    wg = oracle.encode_jpeg(*frames[0], W, H, True)
+    assert out[0, :int(sizes[0])].cpu().numpy().tobytes() == wg

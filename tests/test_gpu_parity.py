@@ -395,3 +395,28 @@ def test_two_contexts_from_two_threads(J, oracle):
         assert jpg == oracle.encode_jpeg(r, g, b, W, H, False)
         for a, e in zip(dec, oracle.decode_planes(want, oracle.make_info(W, H))):
             assert np.array_equal(a, e)
+
+
+@pytest.mark.parametrize("size", [(65535, 17), (16, 65535), (65535, 1)])
+def test_maximum_dimensions(J, ctx, oracle, size):
+    """SOF0 carries 16-bit width/height (ref jpezy_writer.hpp:77-80): the largest legal extents, ragged in the other
+    direction, through encode, both entropy coders and decode."""
+    W, H = size
+    r, g, b = oracle.synth_rgb(W, H, frame=W + 3 * H)
+    want = oracle.encode_coeffs(r, g, b, W, H, False)
+    got = ctx.fdct_quant(r, g, b, W, H)
+    assert np.array_equal(got, want)
+    jpg = J.write_jpeg(got, W, H)
+    assert jpg == oracle.write_jpeg(want, W, H, False)
+    assert ctx.encode_jpeg(r, g, b, W, H) == jpg
+    info, back = J.read_jpeg(jpg)
+    assert (info.width, info.height) == (W, H) and np.array_equal(back, want)
+    for a, e in zip(ctx.dequant_idct(got, W, H), oracle.decode_planes(want, oracle.make_info(W, H))):
+        assert np.array_equal(a, e)
+
+
+def test_out_of_range_dimensions_are_rejected(J, ctx):
+    z = np.zeros(16, np.uint8)
+    for W, H in ((0, 16), (16, 0), (65536, 1), (1, 65536), (-1, 4)):
+        with pytest.raises(J.JpezyError):
+            ctx.fdct_quant(z, z, z, W, H)

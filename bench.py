@@ -34,6 +34,7 @@ WORKLOADS = {
     "decode4096": (4096, 4096, False, 1, "decode", "BASELINE configs[2]: single 4096x4096 decode (dequant+IDCT+RGB)"),
     "gray8k": (7680, 4320, True, 1, "encode", "BASELINE configs[4]: 7680x4320 --gray encode"),
     "batch1080p": (1920, 1080, False, 32, "encode", "BASELINE configs[3] shard: 32 frames 1920x1080 per step"),
+    "gray8k_decode": (7680, 4320, True, 1, "decode", "BASELINE configs[4]: 7680x4320 --gray decode (r = g = b = Y)"),
 }
 
 
@@ -151,8 +152,8 @@ def main():
         ctx.dequant_idct_dev(co[k], W, H, pr[k], pg[k], pb[k], gray=gray, n_frames=fps, stream=stream.cuda_stream)
 
     if direction == "decode":
-        for k in range(ring):      # real coefficients: encode the random frames once, then time the decode
-            enc(k)
+        for k in range(ring):      # real coefficients: encode the random frames once (6-block layout), then time the decode
+            ctx.fdct_quant_dev(pr[k], pg[k], pb[k], W, H, co[k], gray=False, n_frames=fps, stream=stream.cuda_stream)
         torch.cuda.synchronize(dev)
         step = dec
     else:

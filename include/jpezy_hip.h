@@ -188,6 +188,30 @@ typedef struct jpezy_frame_info {
  */
 int jpezy_read_jpeg(const uint8_t* data, size_t len, jpezy_frame_info* info, int16_t* coeffs,
                     size_t coeff_cap);
+/*
+ * The same head with the Huffman decoding on the GPU (decode side): the header is parsed on the
+ * host, the entropy-coded segment is decoded by the self-synchronising parallel decoder of jpezy_huffdec.hip, the
+ * coefficients ([mcu][block][64] zig-zag int16, coeff_cap elements) are left in DEVICE memory, ready for
+ * jpezy_dequant_idct_dev / _generic.  Streams with restart intervals and anything irregular (invalid code, early end)
+ * are decoded by jpezy_read_jpeg's host decoder instead and uploaded, so results and error codes are always those of
+ * jpezy_read_jpeg.  d_coeffs may be NULL (header only).  Synchronous.
+ */
+int jpezy_read_jpeg_gpu(jpezy_ctx* ctx, const uint8_t* data, size_t len, jpezy_frame_info* info, int16_t* d_coeffs,
+                        size_t coeff_cap);
+/*
+ * decoder::decode end to end (decoder/jpezy_decoder.hpp:76-134): .jpg bytes in, planar r,g,b (plane_cap >= width*height
+ * bytes each) out; info receives the header fields.  jpezy's own layout (3 components sampled 2x2/1x1/1x1, 8 bit) runs
+ * Huffman decoding, dequantisation, IDCT and colour conversion on the device; every other baseline layout the
+ * reference accepts takes the host Huffman decoder and the generic kernels.  r,g,b NULL: header only.
+ */
+int jpezy_decode_jpeg(jpezy_ctx* ctx, const uint8_t* data, size_t len, int gray, jpezy_frame_info* info, uint8_t* r,
+                      uint8_t* g, uint8_t* b, size_t plane_cap);
+/* Synchronisation passes the last jpezy_read_jpeg_gpu call needed; 0 = the host decoder was used (test/diagnostic hook). */
+int jpezy_ctx_last_huffdec_passes(jpezy_ctx* ctx);
+/* Scans shorter than n bytes are decoded on the host (default 256 KiB: the GPU decoder has ~3 ms of fixed cost); 0
+ * sends every scan to the GPU decoder (tests). */
+void jpezy_ctx_set_huffdec_min_bytes(jpezy_ctx* ctx, size_t n);
+
 
 #ifdef __cplusplus
 }

@@ -65,6 +65,10 @@ ABI = [
     ("jpezy_write_jpeg_gpu_dev", C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, _vp, C.c_size_t, _vp, _vp]),
     ("jpezy_encode_jpeg", C.c_long, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_char_p, _vp, C.c_size_t]),
     ("jpezy_read_jpeg", C.c_int, [_vp, C.c_size_t, C.POINTER(FrameInfo), _vp, C.c_size_t]),
+    ("jpezy_read_jpeg_gpu", C.c_int, [_vp, _vp, C.c_size_t, C.POINTER(FrameInfo), _vp, C.c_size_t]),
+    ("jpezy_decode_jpeg", C.c_int, [_vp, _vp, C.c_size_t, C.c_int, C.POINTER(FrameInfo), _vp, _vp, _vp, C.c_size_t]),
+    ("jpezy_ctx_last_huffdec_passes", C.c_int, [_vp]),
+    ("jpezy_ctx_set_huffdec_min_bytes", None, [_vp, C.c_size_t]),
 ]
 
 
@@ -231,6 +235,36 @@ class Context:
         _check(load_library().jpezy_write_jpeg_gpu_dev(self._h, d_coeffs.data_ptr(), W, H, int(gray), n_frames, comment,
                                                        d_out.data_ptr(), stride, d_sizes.data_ptr(), stream))
 
+    def read_jpeg_gpu(self, data):
+        """.jpg bytes -> (FrameInfo, torch int16 tensor [mcu_rows, mcu_cols, blocks_per_mcu, 64] on the device): header
+        parsed on the host, Huffman decoding on the GPU (host decoder for streams with restart markers)."""
+        import torch
+        lib = load_library()
+        arr = np.frombuffer(bytes(data), dtype=np.uint8)
+        info = FrameInfo()
+        _check(lib.jpezy_read_jpeg_gpu(self._h, _np_ptr(arr), arr.size, C.byref(info), None, 0))
+        co = torch.empty((info.mcu_rows, info.mcu_cols, info.blocks_per_mcu, 64), dtype=torch.int16, device=f"cuda:{self.device}")
+        _check(lib.jpezy_read_jpeg_gpu(self._h, _np_ptr(arr), arr.size, C.byref(info), co.data_ptr(), co.numel()))
+        return info, co
+
+    def decode_jpeg(self, data, gray=False):
+        """.jpg bytes -> (FrameInfo, r, g, b) planes of width*height bytes (decoder::decode end to end)."""
+        lib = load_library()
+        arr = np.frombuffer(bytes(data), dtype=np.uint8)
+        info = FrameInfo()
+        _check(lib.jpezy_decode_jpeg(self._h, _np_ptr(arr), arr.size, int(gray), C.byref(info), None, None, None, 0))
+        n = info.width * info.height
+        r, g, b = (np.empty(n, dtype=np.uint8) for _ in range(3))
+        _check(lib.jpezy_decode_jpeg(self._h, _np_ptr(arr), arr.size, int(gray), C.byref(info), _np_ptr(r), _np_ptr(g), _np_ptr(b), n))
+        return info, r, g, b
+
+    def set_huffdec_min_bytes(self, n):
+        load_library().jpezy_ctx_set_huffdec_min_bytes(self._h, n)
+
+    def last_huffdec_passes(self):
+        """synchronisation passes of the last read_jpeg_gpu call; 0 = the host decoder was used"""
+        return load_library().jpezy_ctx_last_huffdec_passes(self._h)
+
     def encode_jpeg(self, r, g, b, W, H, gray=False, comment=None):
         """Host planes -> .jpg bytes, both stages on the GPU (encoder::encode end to end)."""
         lib = load_library()
@@ -350,13 +384,9 @@ class Decoder:
         try:
             with open(self.filename, "rb") as f:
                 data = f.read()
-            info, coeffs = read_jpeg(data)
+            ctx = self.ctx or default_context()
+            info, r, g, b = ctx.decode_jpeg(data, gray=gray)       # Huffman head, IDCT and colour conversion on the GPU
         except (OSError, JpezyError):
             return None
         self.pr = info
-        layout = [(info.H[i], info.V[i]) for i in range(info.ncomp)]
-        ctx = self.ctx or default_context()
-        if info.ncomp != 3 or layout != [(2, 2), (1, 1), (1, 1)] or info.precision != 8:
-            return ctx.dequant_idct_generic(coeffs, info, gray=gray)      # any other baseline layout: generic kernels
-        tq = tuple(info.Tq[i] for i in range(3))
-        return ctx.dequant_idct(coeffs, info.width, info.height, qt=info.qt, comp_tq=tq, gray=gray)
+        return r, g, b

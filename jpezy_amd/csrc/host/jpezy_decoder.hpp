@@ -1,7 +1,8 @@
 // jpezy_decoder.hpp -- jpezy::decoder<BuildMode>, same surface as the reference's src/decoder/jpezy_decoder.hpp:39-136.
-// decode<MODE_TAG>() keeps the serial head on the host (marker parsing + Huffman decoding, jpezy_read_jpeg) and
-// replaces decode_mcu's inverse_quantization + inverse_dct + upsampling and make_rgb (:504-578, 645-676) for
-// ALL MCUs by one MI355X launch through the C-ABI (jpezy_dequant_idct).
+// decode<MODE_TAG>() parses the markers on the host (header pass of jpezy_read_jpeg) and hands the file to
+// jpezy_decode_jpeg: decode_huffman (:583-642), inverse_quantization + inverse_dct + upsampling (:504-528, 645-670) and
+// make_rgb (:531-578) for ALL MCUs -- for jpezy_encode's own layout all on the MI355X (self-synchronising parallel
+// Huffman decoder, fused IDCT kernel), for other baseline layouts the host Huffman decoder and the generic kernels.
 #ifndef JPEZY_AMD_HOST_DECODER_HPP
 #define JPEZY_AMD_HOST_DECODER_HPP
 #include <array>
@@ -61,32 +62,19 @@ struct decoder {
         std::unique_ptr<raii_messenger> mes_dec;
         if constexpr (!is_release_mode) mes_dec = std::make_unique<raii_messenger>("decoding started...", "\t");
 
-        const bool own_layout = info.ncomp == 3 && info.precision == 8 && info.H[0] == 2 && info.V[0] == 2 && info.H[1] == 1 &&
-                                info.V[1] == 1 && info.H[2] == 1 && info.V[2] == 1;
-        const std::size_t ncoef = static_cast<std::size_t>(info.mcu_cols) * info.mcu_rows * info.blocks_per_mcu * 64;
-        std::vector<std::int16_t> coeffs(ncoef);
-        if (jpezy_read_jpeg(file.data(), file.size(), &info, coeffs.data(), coeffs.size()) != JPEZY_OK) {
-            std::cerr << "decode_mcu(): throw exception from " << jpezy_hip_last_error() << std::endl;   // :109-114
-            return {};
-        }
         // the reference sizes its planes to the padded MCU grid (:94-101); the first W*H entries are the image
-        const std::size_t W = info.width, H = info.height;
         const std::size_t rgb_s = static_cast<std::size_t>(info.mcu_rows) * info.vmax * 8 * static_cast<std::size_t>(info.mcu_cols) * info.hmax * 8;
         std::array<std::vector<byte>, 3> rgb;
         for (auto& v : rgb) v.resize(rgb_s);
-        const std::uint8_t tq[3] = { static_cast<std::uint8_t>(info.Tq[0]), static_cast<std::uint8_t>(info.Tq[1]), static_cast<std::uint8_t>(info.Tq[2]) };
         jpezy_ctx* ctx = detail::device_context();
-        int rc;
-        if (own_layout) {   // jpezy_encode's own layout: the fused kernel
-            rc = jpezy_dequant_idct(ctx, coeffs.data(), info.qt, tq, static_cast<int>(W), static_cast<int>(H), gray, 1,
-                                    reinterpret_cast<std::uint8_t*>(rgb[0].data()), reinterpret_cast<std::uint8_t*>(rgb[1].data()),
-                                    reinterpret_cast<std::uint8_t*>(rgb[2].data()));
-        } else {            // any other baseline layout decode_mcu handles (:504-528): the generic kernels
-            const std::uint8_t hs[3] = { static_cast<std::uint8_t>(info.H[0]), static_cast<std::uint8_t>(info.H[1]), static_cast<std::uint8_t>(info.H[2]) };
-            const std::uint8_t vs[3] = { static_cast<std::uint8_t>(info.V[0]), static_cast<std::uint8_t>(info.V[1]), static_cast<std::uint8_t>(info.V[2]) };
-            rc = jpezy_dequant_idct_generic(ctx, coeffs.data(), info.qt, info.ncomp, hs, vs, tq, static_cast<int>(W), static_cast<int>(H), gray,
-                                            reinterpret_cast<std::uint8_t*>(rgb[0].data()), reinterpret_cast<std::uint8_t*>(rgb[1].data()),
-                                            reinterpret_cast<std::uint8_t*>(rgb[2].data()));
+        // decode_huffman + inverse_quantization + inverse_dct + upsampling + make_rgb (:504-578, 583-670) for all MCUs: one
+        // C-ABI call; for jpezy_encode's own layout every stage runs on the device
+        const int rc = jpezy_decode_jpeg(ctx, reinterpret_cast<const std::uint8_t*>(file.data()), file.size(), gray, &info,
+                                         reinterpret_cast<std::uint8_t*>(rgb[0].data()), reinterpret_cast<std::uint8_t*>(rgb[1].data()),
+                                         reinterpret_cast<std::uint8_t*>(rgb[2].data()), rgb_s);
+        if (rc == JPEZY_E_FORMAT || rc == JPEZY_E_NOSPACE) {
+            std::cerr << "decode_mcu(): throw exception from " << jpezy_hip_last_error() << std::endl;   // :109-114
+            return {};
         }
         if (rc != JPEZY_OK) {
             std::cerr << "make_rgb(): throw exception from " << jpezy_hip_last_error() << std::endl;

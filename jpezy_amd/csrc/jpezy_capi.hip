@@ -5,6 +5,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <algorithm>
 #include <atomic>
@@ -16,6 +17,7 @@
 #include "../../include/jpezy_hip.h"
 #include "jpezy_device.h"
 #include "jpezy_entropy.h"
+#include "jpezy_huffdec.h"
 #include "jpezy_host_codec.h"
 
 using namespace jpezy_dev;
@@ -88,6 +90,9 @@ struct jpezy_ctx {
     DevBuf e_bits, e_off, e_tmp, e_small, e_U, e_cnt, e_ffoff, e_out, e_coef;
     uint8_t* e_pinned = nullptr;   // pinned host staging of the stuffed streams
     size_t e_pinned_cap = 0;
+    DevBuf h_scan, h_U, h_cnt, h_off, h_state, h_setup, h_small, h_dc;   // GPU Huffman decoder (jpezy_huffdec.hip)
+    int h_last_passes = 0;         // synchronisation passes of the last jpezy_read_jpeg_gpu (0: the host decoder was used)
+    size_t h_min_bytes = 256 << 10;   // scans shorter than this are decoded on the host (the GPU path has ~3 ms of fixed cost)
     DevBuf e_hdr;                  // JFIF header bytes of the device-resident variant (cached per W, H, comment)
     uint8_t e_hdr_host[1024];
     size_t e_hdr_len = 0;
@@ -214,7 +219,8 @@ void jpezy_ctx_destroy(jpezy_ctx* c)
     c->scratch.release();
     if (c->d_codes) (void)hipFree(c->d_codes);
     if (c->e_pinned) (void)hipHostFree(c->e_pinned);
-    for (DevBuf* b : { &c->e_bits, &c->e_off, &c->e_tmp, &c->e_small, &c->e_U, &c->e_cnt, &c->e_ffoff, &c->e_out, &c->e_coef, &c->e_hdr }) b->release();
+    for (DevBuf* b : { &c->e_bits, &c->e_off, &c->e_tmp, &c->e_small, &c->e_U, &c->e_cnt, &c->e_ffoff, &c->e_out, &c->e_coef, &c->e_hdr,
+                       &c->h_scan, &c->h_U, &c->h_cnt, &c->h_off, &c->h_state, &c->h_setup, &c->h_small, &c->h_dc }) b->release();
     delete c;
 }
 
@@ -746,6 +752,263 @@ long jpezy_encode_jpeg(jpezy_ctx* c, const uint8_t* r, const uint8_t* g, const u
         return rc;
     return jpezy_write_jpeg_gpu(c, (const int16_t*)c->e_coef.p, W, H, gray, comment, out, cap);
 }
+
+// ---- GPU Huffman decoding (decode side) ----
+namespace {
+
+void build_dev_table(jpezy_dev::huffdec::Table& t, const uint8_t bits[16], const uint8_t* vals, int n)
+{
+    std::memset(&t, 0, sizeof t);
+    std::memcpy(t.val, vals, (size_t)n);
+    int code = 0, p = 0;
+    for (int l = 1; l <= 16; ++l) {
+        t.valptr[l] = p;
+        t.mincode[l] = code;
+        for (int c = 0; c < bits[l - 1]; ++c, ++p, ++code) {
+            if (l <= 9) {
+                const int lo = code << (9 - l);
+                for (int f = 0; f < (1 << (9 - l)); ++f) t.look[lo + f] = (uint16_t)((l << 8) | vals[p]);
+            }
+        }
+        t.maxcode[l] = bits[l - 1] ? code - 1 : -1;
+        code <<= 1;
+    }
+    t.maxcode[17] = 0x7FFFFFFF;
+}
+
+// host decode + upload: the authoritative path for everything the GPU decoder does not take or is unsure about
+int read_jpeg_host_to_device(jpezy_ctx* c, const uint8_t* data, size_t len, jpezy_frame_info* info, int16_t* d_coeffs, size_t total)
+{
+    std::vector<int16_t> tmp(total);
+    std::string err;
+    const int rc = jpezy_host::read_jpeg(data, len, info, tmp.data(), tmp.size(), &err);
+    if (rc < 0) { g_err = err; return rc; }
+    HIP_TRY(hipMemcpy(d_coeffs, tmp.data(), total * sizeof(int16_t), hipMemcpyHostToDevice));
+    return JPEZY_OK;
+}
+
+}  // namespace
+
+int jpezy_read_jpeg_gpu(jpezy_ctx* c, const uint8_t* data, size_t len, jpezy_frame_info* info, int16_t* d_coeffs, size_t coeff_cap)
+{
+    namespace HD = jpezy_dev::huffdec;
+    namespace E = jpezy_dev::entropy;
+    if (!c) return set_err(JPEZY_E_BADARG, "null context");
+    jpezy_host::ScanSetup setup;
+    std::string err;
+    int rc = jpezy_host::parse_header(data, len, info, &setup, &err);
+    if (rc < 0) { g_err = err; return rc; }
+    if (!d_coeffs) return JPEZY_OK;
+    c->h_last_passes = 0;
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t nmcu = (size_t)info->mcu_cols * info->mcu_rows;
+    const int bpm = info->blocks_per_mcu;
+    const size_t total_blocks = nmcu * (size_t)bpm, total = total_blocks * 64;
+    if (coeff_cap < total) return set_err(JPEZY_E_NOSPACE, "read_jpeg_gpu: coefficient buffer too small");
+
+    // what the GPU decoder takes: no restart intervals, at most 12 blocks per MCU, every selected table present
+    bool gpu_ok = info->restart_interval == 0 && bpm <= 12 && total_blocks < 0xFFFFFFFFull && setup.scan_pos < len;
+    for (int i = 0; i < info->ncomp && gpu_ok; ++i)
+        gpu_ok = setup.Td[i] >= 0 && setup.Td[i] <= 2 && setup.present[setup.Td[i]] && setup.present[4 + setup.Td[i]];
+    if (!gpu_ok) return read_jpeg_host_to_device(c, data, len, info, d_coeffs, total);
+
+    // the entropy-coded segment ends at the first marker (0xFF followed by anything but 0x00)
+    const uint8_t* scan = data + setup.scan_pos;
+    size_t n = len - setup.scan_pos;
+    for (const uint8_t* q = scan; (q = (const uint8_t*)std::memchr(q, 0xFF, (size_t)(scan + n - q))) != nullptr; ++q) {
+        if (q + 1 >= scan + n) { n = (size_t)(q - scan); break; }
+        if (q[1] != 0x00) { n = (size_t)(q - scan); break; }
+    }
+    if (n == 0 || n < c->h_min_bytes) return read_jpeg_host_to_device(c, data, len, info, d_coeffs, total);
+
+    hipStream_t s = c->stream;
+    const size_t chunk = HD::chunk_bytes(), nc = (n + chunk - 1) / chunk;
+    const unsigned L = HD::subseq_bits();
+    const unsigned n_sub_max = (unsigned)((n * 8 + L - 1) / L);      // before the stuffing is removed; buffers are sized for it
+    unsigned n_sub = n_sub_max;
+    const size_t u_bytes = ((size_t)n_sub * L / 8 + 64 + 3) & ~(size_t)3;
+    if (int r2 = c->h_scan.reserve(n + 64)) return r2;
+    if (int r2 = c->h_U.reserve(u_bytes)) return r2;
+    if (int r2 = c->h_cnt.reserve(std::max(nc, (size_t)n_sub) * sizeof(uint32_t))) return r2;
+    if (int r2 = c->h_off.reserve((std::max(nc, (size_t)n_sub) + 1) * sizeof(unsigned long long))) return r2;
+    if (int r2 = c->h_state.reserve((size_t)n_sub * 3 * sizeof(uint32_t))) return r2;
+    if (int r2 = c->h_setup.reserve(sizeof(HD::Setup))) return r2;
+    if (int r2 = c->h_small.reserve(64)) return r2;
+    size_t max_dc = 0;
+    for (int i = 0; i < info->ncomp; ++i) max_dc = std::max(max_dc, nmcu * (size_t)(info->H[i] * info->V[i]));
+    if (int r2 = c->h_dc.reserve(std::max((2 * max_dc + 2), (size_t)n_sub) * sizeof(unsigned long long))) return r2;
+    if (int r2 = c->e_tmp.reserve(E::scan_tmp_elems(std::max(std::max(nc, (size_t)n_sub), max_dc)) * sizeof(unsigned long long))) return r2;
+
+    // tables
+    std::vector<HD::Setup> hs(1);
+    HD::Setup& S = hs[0];
+    std::memset(&S, 0, sizeof S);
+    for (int td = 0; td < 3; ++td) {
+        if (setup.present[td]) build_dev_table(S.dc[td], setup.bits[td], setup.vals[td], setup.nvals[td]);
+        if (setup.present[4 + td]) build_dev_table(S.ac[td], setup.bits[4 + td], setup.vals[4 + td], setup.nvals[4 + td]);
+    }
+    S.bpm = bpm;
+    S.total_blocks = (unsigned)total_blocks;
+    {
+        int b = 0;
+        for (int i = 0; i < info->ncomp; ++i)
+            for (int k = info->H[i] * info->V[i]; k > 0; --k) S.btd[b++] = setup.Td[i];
+    }
+    HIP_TRY(hipMemcpyAsync(c->h_setup.p, &S, sizeof S, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(c->h_scan.p, scan, n, hipMemcpyHostToDevice, s));
+
+    // 1. remove the byte stuffing
+    HIP_TRY(hipMemsetAsync(c->h_U.p, 0, u_bytes, s));
+    HIP_TRY(HD::launch_unstuff_count((const uint8_t*)c->h_scan.p, n, (uint32_t*)c->h_cnt.p, s));
+    HIP_TRY(E::launch_scan_u32((const uint32_t*)c->h_cnt.p, (unsigned long long*)c->h_off.p, nc, (unsigned long long*)c->e_tmp.p, s));
+    HIP_TRY(HD::launch_unstuff_copy((const uint8_t*)c->h_scan.p, n, (const unsigned long long*)c->h_off.p, (uint8_t*)c->h_U.p, s));
+    unsigned long long removed = 0;
+    HIP_TRY(hipMemcpyAsync(&removed, (const unsigned long long*)c->h_off.p + nc, sizeof removed, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    // only the subsequences that hold real data are decoded: behind them U is zero padding, which no decoder ever
+    // falls into step on (a periodic stream), so it would be walked lane by lane
+    n_sub = (unsigned)(((n - removed) * 8 + L - 1) / L);
+    if (n_sub == 0) return read_jpeg_host_to_device(c, data, len, info, d_coeffs, total);
+
+    // 2. synchronisation passes until no exit state changes
+    uint32_t* d_exit = (uint32_t*)c->h_state.p;
+    uint32_t* d_last = d_exit + n_sub;
+    unsigned* d_nblocks = (unsigned*)(d_last + n_sub);
+    unsigned* d_changed = (unsigned*)c->h_small.p;
+    unsigned* d_error = d_changed + 1;
+    unsigned long long* d_lastbit = (unsigned long long*)c->h_small.p + 1;
+    {
+        std::vector<uint32_t> init(n_sub, 0x80000000u);
+        HIP_TRY(hipMemcpyAsync(d_exit, init.data(), (size_t)n_sub * 4, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemsetAsync(d_last, 0xFF, (size_t)n_sub * 4, s));
+        HIP_TRY(hipMemsetAsync(d_nblocks, 0, (size_t)n_sub * 4, s));
+        HIP_TRY(hipStreamSynchronize(s));                       // init lives on this stack frame
+    }
+    // speculation: every lane decodes through its own and the next 12 subsequences from a guess; the farthest-travelled
+    // proposal for every boundary becomes the initial exit state (h_dc doubles as the proposal scratch)
+    HIP_TRY(HD::launch_speculate((const HD::Setup*)c->h_setup.p, (const uint32_t*)c->h_U.p, u_bytes / 4, n_sub,
+                                 (unsigned long long*)c->h_dc.p, d_exit, s));
+    std::vector<uint32_t> dbg_spec;
+    const bool dbg = std::getenv("JPEZY_HUFFDEC_DEBUG") != nullptr;
+    if (dbg) {
+        dbg_spec.resize(n_sub);
+        HIP_TRY(hipMemcpyAsync(dbg_spec.data(), d_exit, (size_t)n_sub * 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+    }
+    bool converged = false;
+    int passes = 0;
+    // confirmation: every lane decodes its subsequence once from its predecessor's proposed exit state.  No state moves:
+    // the proposals are the sequential decode.  A few move: refinement launches (each resolves a workgroup's 256
+    // subsequences internally).  Many move -- periodic data such as a flat image never lets a wrong decoder fall into
+    // step -- or refinement does not settle quickly: the host decoder takes over.
+    {
+        unsigned moved = 0;
+        auto pass = [&](int max_inner) -> int {
+            HIP_TRY(hipMemsetAsync(d_changed, 0, sizeof(unsigned), s));
+            HIP_TRY(HD::launch_sync((const HD::Setup*)c->h_setup.p, (const uint32_t*)c->h_U.p, u_bytes / 4, n_sub, d_exit, d_last, d_nblocks,
+                                    d_changed, max_inner, s));
+            HIP_TRY(hipMemcpyAsync(&moved, d_changed, sizeof moved, hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+            ++passes;
+            return JPEZY_OK;
+        };
+        if (int r2 = pass(1)) return r2;
+        converged = moved == 0;
+        // refinement budget: 6 launches of at most 24 propagation steps (~10 ms); isolated wrong lanes settle in one
+        if (!converged && moved <= n_sub / 2 + 16) {
+            for (int it = 0; it < 6 && !converged; ++it) {
+                if (int r2 = pass(24)) return r2;
+                converged = moved == 0;
+            }
+        }
+    }
+    if (dbg) {
+        std::vector<uint32_t> fin(n_sub);
+        HIP_TRY(hipMemcpy(fin.data(), d_exit, (size_t)n_sub * 4, hipMemcpyDeviceToHost));
+        size_t same = 0, longest = 0, run = 0;
+        for (unsigned i = 0; i < n_sub; ++i) {
+            if (fin[i] == dbg_spec[i]) { ++same; run = 0; } else { ++run; if (run > longest) longest = run; }
+        }
+        std::fprintf(stderr, "huffdec: %u subsequences, %zu speculative exit states already true, longest wrong run %zu, %d passes, converged %d\n",
+                     n_sub, same, longest, passes, (int)converged);
+    }
+    if (!converged) return read_jpeg_host_to_device(c, data, len, info, d_coeffs, total);
+
+    // 3. global block index of every lane, coefficients, DC predictors
+    HIP_TRY(hipMemcpyAsync(c->h_cnt.p, d_nblocks, (size_t)n_sub * 4, hipMemcpyDeviceToDevice, s));
+    HIP_TRY(E::launch_scan_u32((const uint32_t*)c->h_cnt.p, (unsigned long long*)c->h_off.p, n_sub, (unsigned long long*)c->e_tmp.p, s));
+    HIP_TRY(hipMemsetAsync(d_coeffs, 0, total * sizeof(int16_t), s));
+    HIP_TRY(hipMemsetAsync(d_error, 0, sizeof(unsigned), s));
+    HIP_TRY(hipMemsetAsync(d_lastbit, 0xFF, sizeof(unsigned long long), s));
+    HIP_TRY(HD::launch_emit((const HD::Setup*)c->h_setup.p, (const uint32_t*)c->h_U.p, u_bytes / 4, n_sub, d_exit,
+                            (const unsigned long long*)c->h_off.p, d_coeffs, d_error, d_lastbit, s));
+    {
+        unsigned start = 0;
+        for (int i = 0; i < info->ncomp; ++i) {
+            const unsigned count = (unsigned)(info->H[i] * info->V[i]);
+            const size_t nd = nmcu * count;
+            unsigned long long* d = (unsigned long long*)c->h_dc.p;
+            unsigned long long* before = d + nd + 1;
+            HIP_TRY(HD::launch_dc_gather(d_coeffs, (unsigned)bpm, start, count, nd, d, s));
+            HIP_TRY(E::launch_scan_u64(d, before, nd, (unsigned long long*)c->e_tmp.p, s));
+            HIP_TRY(HD::launch_dc_scatter(d_coeffs, (unsigned)bpm, start, count, nd, before, s));
+            start += count;
+        }
+    }
+    unsigned error = 0;
+    unsigned long long last_bit = 0;
+    HIP_TRY(hipMemcpyAsync(&error, d_error, sizeof error, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(&last_bit, d_lastbit, sizeof last_bit, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    // an invalid code, or a last block that is not complete inside the real data: the host decoder decides
+    if (error || last_bit > (unsigned long long)(n - removed) * 8) return read_jpeg_host_to_device(c, data, len, info, d_coeffs, total);
+    c->h_last_passes = passes;
+    return JPEZY_OK;
+}
+
+// decoder::decode end to end (ref decoder/jpezy_decoder.hpp:76-134): .jpg bytes in, planar r,g,b out
+int jpezy_decode_jpeg(jpezy_ctx* c, const uint8_t* data, size_t len, int gray, jpezy_frame_info* info, uint8_t* r, uint8_t* g, uint8_t* b,
+                      size_t plane_cap)
+{
+    if (!c || !info) return set_err(JPEZY_E_BADARG, "decode_jpeg: bad argument");
+    int rc = jpezy_read_jpeg_gpu(c, data, len, info, nullptr, 0);           // header only
+    if (rc < 0) return rc;
+    if (!r || !g || !b) return JPEZY_OK;
+    const int W = info->width, H = info->height;
+    if (int rc2 = check_dims(c, W, H, 1)) return rc2;
+    if (plane_cap < (size_t)W * H) return set_err(JPEZY_E_NOSPACE, "decode_jpeg: plane buffers too small");
+    const size_t ncoef = (size_t)info->mcu_cols * info->mcu_rows * info->blocks_per_mcu * 64;
+    const uint8_t tq[3] = { (uint8_t)info->Tq[0], (uint8_t)info->Tq[1], (uint8_t)info->Tq[2] };
+    const bool own_layout = info->ncomp == 3 && info->precision == 8 && info->H[0] == 2 && info->V[0] == 2 && info->H[1] == 1 &&
+                            info->V[1] == 1 && info->H[2] == 1 && info->V[2] == 1;
+    if (!own_layout) {   // any other baseline layout decode_mcu handles (:504-528): host Huffman head + the generic kernels
+        std::vector<int16_t> co(ncoef);
+        std::string err;
+        rc = jpezy_host::read_jpeg(data, len, info, co.data(), co.size(), &err);
+        if (rc < 0) { g_err = err; return rc; }
+        const uint8_t hs[3] = { (uint8_t)info->H[0], (uint8_t)info->H[1], (uint8_t)info->H[2] };
+        const uint8_t vs[3] = { (uint8_t)info->V[0], (uint8_t)info->V[1], (uint8_t)info->V[2] };
+        return jpezy_dequant_idct_generic(c, co.data(), info->qt, info->ncomp, hs, vs, tq, W, H, gray, r, g, b);
+    }
+    // jpezy's own layout: Huffman decoding, dequantisation, IDCT and colour conversion all on the device
+    HIP_TRY(hipSetDevice(c->device));
+    if (int rc2 = c->out.reserve(ncoef * sizeof(int16_t))) return rc2;
+    rc = jpezy_read_jpeg_gpu(c, data, len, info, (int16_t*)c->out.p, ncoef);
+    if (rc < 0) return rc;
+    const size_t plane = (size_t)W * H, stride = (plane + 15) & ~(size_t)15;
+    for (int k = 0; k < 3; ++k)
+        if (int rc2 = c->in[k].reserve(stride)) return rc2;
+    if (int rc2 = jpezy_dequant_idct_dev(c, (const int16_t*)c->out.p, info->qt, tq, stride, W, H, gray, 1, (uint8_t*)c->in[0].p,
+                                         (uint8_t*)c->in[1].p, (uint8_t*)c->in[2].p, c->stream))
+        return rc2;
+    uint8_t* dst[3] = { r, g, b };
+    for (int k = 0; k < 3; ++k) HIP_TRY(hipMemcpyAsync(dst[k], c->in[k].p, plane, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return JPEZY_OK;
+}
+
+int jpezy_ctx_last_huffdec_passes(jpezy_ctx* c) { return c ? c->h_last_passes : 0; }
+void jpezy_ctx_set_huffdec_min_bytes(jpezy_ctx* c, size_t n) { if (c) c->h_min_bytes = n; }
 
 int jpezy_read_jpeg(const uint8_t* data, size_t len, jpezy_frame_info* info, int16_t* coeffs, size_t coeff_cap)
 {

@@ -28,6 +28,7 @@ size_t chunk_bytes();             // granularity of the stuffing pass: U strides
 hipError_t launch_block_bits(const Job& job, uint32_t* bits, unsigned* status, hipStream_t s);
 // out[0..n) exclusive prefix sums, out[n] the total
 hipError_t launch_scan_u32(const uint32_t* in, unsigned long long* out, size_t n, unsigned long long* tmp, hipStream_t s);
+hipError_t launch_scan_u64(const unsigned long long* in, unsigned long long* out, size_t n, unsigned long long* tmp, hipStream_t s);
 hipError_t launch_frame_totals(const unsigned long long* off, size_t per, int n_frames, unsigned long long* dst, hipStream_t s);
 hipError_t launch_emit(const Job& job, const unsigned long long* bitoff, uint32_t* U, size_t u_stride_words, hipStream_t s);
 hipError_t launch_ff_count(const uint32_t* U, size_t u_stride_words, const unsigned long long* frame_bytes, int n_frames,

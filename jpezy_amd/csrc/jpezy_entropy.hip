@@ -379,6 +379,12 @@ hipError_t launch_scan_u32(const uint32_t* in, unsigned long long* out, size_t n
     return e != hipSuccess ? e : hipGetLastError();
 }
 
+hipError_t launch_scan_u64(const unsigned long long* in, unsigned long long* out, size_t n, unsigned long long* tmp, hipStream_t s)
+{
+    hipError_t e = scan_exclusive<unsigned long long>(in, out, n, tmp, s);
+    return e != hipSuccess ? e : hipGetLastError();
+}
+
 hipError_t launch_frame_totals(const unsigned long long* off, size_t per, int n_frames, unsigned long long* dst, hipStream_t s)
 {
     hipLaunchKernelGGL(frame_totals_kernel, dim3((unsigned)((n_frames + 63) / 64)), dim3(64), 0, s, off, per, n_frames, dst);

@@ -364,8 +364,27 @@ int next_marker(Reader& r)   // ref decoder/jpezy_decoder.hpp:486-502
 
 }  // namespace
 
+namespace {
+int read_jpeg_impl(const uint8_t* data, size_t len, jpezy_frame_info* info, int16_t* coeffs, size_t coeff_cap, std::string* err,
+                   ScanSetup* setup);
+}
+
 int read_jpeg(const uint8_t* data, size_t len, jpezy_frame_info* info, int16_t* coeffs, size_t coeff_cap,
               std::string* err)
+{
+    return read_jpeg_impl(data, len, info, coeffs, coeff_cap, err, nullptr);
+}
+
+int parse_header(const uint8_t* data, size_t len, jpezy_frame_info* info, ScanSetup* setup, std::string* err)
+{
+    if (!setup) { if (err) *err = "parse_header: bad argument"; return JPEZY_E_BADARG; }
+    std::memset(setup, 0, sizeof *setup);
+    return read_jpeg_impl(data, len, info, nullptr, 0, err, setup);
+}
+
+namespace {
+int read_jpeg_impl(const uint8_t* data, size_t len, jpezy_frame_info* info, int16_t* coeffs, size_t coeff_cap, std::string* err,
+                   ScanSetup* setup)
 {
     auto fail = [&](int code, const char* msg) { if (err) *err = msg; return code; };
     if (!data || !info) return fail(JPEZY_E_BADARG, "read_jpeg: bad argument");
@@ -420,6 +439,13 @@ int read_jpeg(const uint8_t* data, size_t len, jpezy_frame_info* info, int16_t* 
                 if (n > 256) return fail(JPEZY_E_FORMAT, "read_jpeg: invalid size table");
                 for (int i = 0; i < n; ++i) { const int b = r.byte(); if (b < 0) return fail(JPEZY_E_FORMAT, "read_jpeg: truncated DHT"); vals[i] = (uint8_t)b; }
                 build_dec(ht[(id >> 4) * 4 + (id & 15)], bits, vals, n);
+                if (setup) {
+                    const int slot = (id >> 4) * 4 + (id & 15);
+                    setup->present[slot] = 1;
+                    setup->nvals[slot] = n;
+                    std::memcpy(setup->bits[slot], bits, 16);
+                    std::memcpy(setup->vals[slot], vals, (size_t)n);
+                }
             } while (r.pos < end);
             have_ht = true;
             break;
@@ -515,6 +541,10 @@ int read_jpeg(const uint8_t* data, size_t len, jpezy_frame_info* info, int16_t* 
         if (info->H[i] <= 0 || info->V[i] <= 0) return fail(JPEZY_E_FORMAT, "read_jpeg: zero sampling factor");
         info->blocks_per_mcu += info->H[i] * info->V[i];
     }
+    if (setup) {
+        setup->scan_pos = r.pos;
+        for (int i = 0; i < 3; ++i) setup->Td[i] = Td[i];
+    }
     if (!coeffs) return JPEZY_OK;
 
     const size_t nmcu = (size_t)info->mcu_cols * info->mcu_rows;
@@ -556,5 +586,6 @@ int read_jpeg(const uint8_t* data, size_t len, jpezy_frame_info* info, int16_t* 
     }
     return JPEZY_OK;
 }
+}  // namespace
 
 }  // namespace jpezy_host

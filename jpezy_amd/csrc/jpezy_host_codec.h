@@ -20,6 +20,20 @@ size_t write_header(int W, int H, const char* comment, uint8_t* out, size_t cap)
 // canonical (code, length) per symbol of the four Annex-K tables in DHT order YDc, CDc, YAc, CAc (for the GPU coder)
 void enc_code_tables(uint16_t code[4][256], uint8_t len[4][256]);
 
+// What the entropy decoder needs besides jpezy_frame_info: where the scan data start, the raw DHT specifications
+// (slot = tc*4 + th: 0..3 DC, 4..7 AC) and the table selector of each scan component (the reference uses Td for both
+// the DC and the AC table, decoder/jpezy_decoder.hpp:630).
+struct ScanSetup {
+    size_t scan_pos;
+    int Td[3];
+    uint8_t present[8];
+    int nvals[8];
+    uint8_t bits[8][16];
+    uint8_t vals[8][256];
+};
+// header only (the marker parser of read_jpeg): fills info and setup
+int parse_header(const uint8_t* data, size_t len, jpezy_frame_info* info, ScanSetup* setup, std::string* err);
+
 // ref decoder/jpezy_decoder.hpp:171-502, 583-642
 int read_jpeg(const uint8_t* data, size_t len, jpezy_frame_info* info, int16_t* coeffs, size_t coeff_cap,
               std::string* err);

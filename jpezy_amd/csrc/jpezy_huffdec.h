@@ -1,0 +1,47 @@
+// jpezy_huffdec.h -- GPU Huffman decoder of a baseline scan without restart markers (internal; see jpezy_huffdec.hip)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace jpezy_dev {
+namespace huffdec {
+
+struct Table {
+    uint16_t look[512];   // 9-bit lookup: (code length << 8) | symbol, 0 when the code is longer than 9 bits
+    int maxcode[18];      // canonical decoding of the longer codes: largest code of each length, -1 if none
+    int valptr[17];
+    int mincode[17];
+    uint8_t val[256];
+};
+
+struct Setup {
+    Table dc[3], ac[3];       // indexed by the scan component's table selector Td (the reference uses Td for both)
+    int bpm;                  // blocks per MCU
+    int btd[12];              // Td of block b of an MCU
+    unsigned total_blocks;
+    unsigned pad[2];
+};
+
+unsigned subseq_bits();
+size_t chunk_bytes();
+
+hipError_t launch_unstuff_count(const uint8_t* S, size_t n, uint32_t* counts, hipStream_t s);
+hipError_t launch_unstuff_copy(const uint8_t* S, size_t n, const unsigned long long* removed_before, uint8_t* U, hipStream_t s);
+// speculation pass: fills exit_state with the best available guess of every subsequence's true exit state
+// (proposal: n_sub uint64 of scratch)
+hipError_t launch_speculate(const Setup* S, const uint32_t* U, size_t u_words, unsigned n_sub, unsigned long long* proposal,
+                            uint32_t* exit_state, hipStream_t s);
+// u_words: 32-bit words of U that may be read (the rest of a workgroup's window reads as zero)
+// *changed += number of lanes whose exit state moved.  max_inner: propagation steps inside a workgroup (1: every lane
+// decodes once from its predecessor's current exit state and nothing more)
+hipError_t launch_sync(const Setup* S, const uint32_t* U, size_t u_words, unsigned n_sub, uint32_t* exit_state, uint32_t* last_entry,
+                       unsigned* nblocks, unsigned* changed, int max_inner, hipStream_t s);
+hipError_t launch_emit(const Setup* S, const uint32_t* U, size_t u_words, unsigned n_sub, const uint32_t* exit_state,
+                       const unsigned long long* blocks_before, int16_t* out, unsigned* error, unsigned long long* last_bit, hipStream_t s);
+hipError_t launch_dc_gather(const int16_t* coeffs, unsigned bpm, unsigned start, unsigned count, size_t n, unsigned long long* d, hipStream_t s);
+hipError_t launch_dc_scatter(int16_t* coeffs, unsigned bpm, unsigned start, unsigned count, size_t n, const unsigned long long* before,
+                             hipStream_t s);
+
+}  // namespace huffdec
+}  // namespace jpezy_dev

@@ -1,0 +1,159 @@
+"""GPU Huffman decoder (decode side: the self-synchronising parallel decoder of jpezy_huffdec.hip)
+against the host decoder: identical coefficients for jpezy's own files (fixtures, stress coefficient patterns, gray, ragged
+sizes, the 4096x4096 frame) and for libjpeg-written files with other sampling factors, optimised (custom) Huffman tables,
+one component and restart intervals (host path), and the host decoder's error for malformed streams."""
+import io
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def J():
+    import jpezy_amd
+    jpezy_amd.load_library()
+    return jpezy_amd
+
+
+@pytest.fixture(scope="module")
+def ctx(J):
+    c = J.Context(0)
+    c.set_huffdec_min_bytes(0)          # every scan through the GPU decoder, however small
+    yield c
+    c.close()
+
+
+def _same(J, ctx, data, expect_gpu=None):
+    info, want = J.read_jpeg(data)
+    ginfo, got = ctx.read_jpeg_gpu(data)
+    if expect_gpu is not None:          # the GPU decoder itself ran (and not the host decoder behind it)
+        assert (ctx.last_huffdec_passes() > 0) == expect_gpu, ctx.last_huffdec_passes()
+    assert (ginfo.width, ginfo.height, ginfo.ncomp, ginfo.blocks_per_mcu) == (info.width, info.height, info.ncomp, info.blocks_per_mcu)
+    got = got.cpu().numpy()
+    assert got.shape == want.shape
+    assert np.array_equal(got, want), np.argwhere(got != want)[:5]
+    return info, want
+
+
+def test_fixtures(J, ctx, golden_dir):
+    for path in sorted(golden_dir.glob("*.npz")):
+        z = np.load(path)
+        _, co = _same(J, ctx, z["jpg"].tobytes(), expect_gpu=True)
+        assert np.array_equal(co, z["coeffs"])
+        _same(J, ctx, z["jpg_gray"].tobytes(), expect_gpu=True)
+
+
+@pytest.mark.parametrize("size", [(16, 16), (17, 17), (48, 32), (100, 60), (640, 480), (1920, 1080)])
+def test_stress_streams(J, ctx, size):
+    from tests.test_gpu_entropy import _stress_coeffs
+    W, H = size
+    rng = np.random.default_rng(W * 7 + H)
+    mc, mr = J.mcu_grid(W, H)
+    co = _stress_coeffs(rng, mc * mr).reshape(mr, mc, 6, 64)
+    _, back = _same(J, ctx, J.write_jpeg(co, W, H, False), expect_gpu=True)
+    assert np.array_equal(back, co)
+    g = np.ascontiguousarray(co[:, :, :4])
+    _same(J, ctx, J.write_jpeg(g, W, H, True))
+    # long zero runs and blocks of a single coefficient: few symbols per subsequence, slow synchronisation
+    sparse = np.zeros_like(co)
+    sparse[..., 0] = rng.integers(-50, 50, sparse.shape[:-1])
+    sparse[::3, ::2, :, 63] = 1
+    _same(J, ctx, J.write_jpeg(sparse, W, H, False))
+    _same(J, ctx, J.write_jpeg(np.zeros_like(co), W, H, False))
+
+
+def test_libjpeg_files(J, ctx):
+    from PIL import Image, ImageFile
+    ImageFile.MAXBLOCK = 1 << 22          # optimize=True needs the whole file in one encoder buffer
+    rng = np.random.default_rng(9)
+    img = rng.integers(0, 256, (200, 312, 3), dtype=np.uint8)
+    smooth = (np.add.outer(np.arange(200), np.arange(312)) % 256).astype(np.uint8)
+    smooth = np.stack([smooth, smooth[::-1], smooth[:, ::-1]], axis=-1)
+    variants = [dict(subsampling=2, quality=50), dict(subsampling=0, quality=90), dict(subsampling=1, quality=75),
+                dict(subsampling=2, quality=30, optimize=True), dict(subsampling=0, quality=95, optimize=True),
+                dict(subsampling=2, quality=60, restart_marker_blocks=3)]
+    for pic in (img, smooth):
+        for kw in variants:
+            buf = io.BytesIO()
+            try:
+                Image.fromarray(pic).save(buf, "JPEG", **kw)
+            except TypeError:
+                continue
+            info, _ = _same(J, ctx, buf.getvalue(), expect_gpu="restart_marker_blocks" not in kw)
+            assert (info.restart_interval != 0) == ("restart_marker_blocks" in kw)
+        buf = io.BytesIO()
+        Image.fromarray(pic[..., 1]).save(buf, "JPEG", quality=70)
+        info, _ = _same(J, ctx, buf.getvalue(), expect_gpu=True)
+        assert info.ncomp == 1
+
+
+def test_malformed_streams_get_the_host_decoders_verdict(J, ctx, golden_dir):
+    z = np.load(golden_dir / "rand64.npz")
+    jpg = z["jpg"].tobytes()
+    for bad in (jpg[:700], jpg[:len(jpg) // 2], jpg[:-40], b"", b"\xff\xd8\xff\xd9"):
+        try:
+            J.read_jpeg(bad)
+            host_ok = True
+        except J.JpezyError:
+            host_ok = False
+        if host_ok:
+            _same(J, ctx, bad)
+        else:
+            with pytest.raises(J.JpezyError):
+                ctx.read_jpeg_gpu(bad)
+    # a corrupted byte in the middle of the entropy data: whatever the host decoder says
+    for pos in (800, 1500, len(jpg) - 100):
+        bad = bytearray(jpg)
+        bad[pos] ^= 0x5A
+        bad = bytes(bad)
+        try:
+            info, want = J.read_jpeg(bad)
+        except J.JpezyError:
+            with pytest.raises(J.JpezyError):
+                ctx.read_jpeg_gpu(bad)
+            continue
+        assert np.array_equal(ctx.read_jpeg_gpu(bad)[1].cpu().numpy(), want)
+
+
+def test_full_frame_and_decode_pipeline(J, ctx, oracle):
+    import torch
+    W = H = 2048
+    r, g, b = oracle.synth_rgb(W, H, frame=5)
+    jpg = ctx.encode_jpeg(r, g, b, W, H)
+    info, co = _same(J, ctx, jpg, expect_gpu=True)
+    print("synchronisation passes for the 2048x2048 frame:", ctx.last_huffdec_passes())
+    # .jpg -> RGB with both stages on the GPU
+    ginfo, dco = ctx.read_jpeg_gpu(jpg)
+    planes = [torch.empty(W * H, dtype=torch.uint8, device="cuda") for _ in range(3)]
+    ctx.dequant_idct_dev(dco, W, H, planes[0], planes[1], planes[2])
+    torch.cuda.synchronize()
+    want = ctx.dequant_idct(co, W, H)
+    for a, e in zip(planes, want):
+        assert np.array_equal(a.cpu().numpy(), e)
+
+
+def test_decode_jpeg_end_to_end(J, ctx, oracle):
+    """jpezy_decode_jpeg = decoder::decode: own-layout files through the GPU Huffman decoder + fused IDCT kernel, other
+    layouts through the host head + generic kernels; both equal the oracle's decoder."""
+    from PIL import Image
+    W, H = 208, 120
+    r, g, b = oracle.synth_rgb(W, H, frame=77)
+    jpg = ctx.encode_jpeg(r, g, b, W, H)
+    for gray in (False, True):
+        info, rr, gg, bb = ctx.decode_jpeg(jpg, gray=gray)
+        want = oracle.decode_jpeg(jpg, gray)
+        assert (info.width, info.height) == (W, H)
+        for a, e in zip((rr, gg, bb), want[-3:]):
+            assert np.array_equal(a, np.asarray(e).reshape(-1)[: W * H])
+    assert ctx.last_huffdec_passes() > 0
+    img = np.random.default_rng(5).integers(0, 256, (72, 104, 3), dtype=np.uint8)
+    buf = io.BytesIO()
+    Image.fromarray(img).save(buf, "JPEG", subsampling=0, quality=85)
+    info, rr, gg, bb = ctx.decode_jpeg(buf.getvalue())
+    want = oracle.decode_jpeg(buf.getvalue(), False)
+    for a, e in zip((rr, gg, bb), want[-3:]):
+        assert np.array_equal(a, np.asarray(e).reshape(-1)[: 104 * 72])
+    with pytest.raises(J.JpezyError):
+        ctx.decode_jpeg(jpg[:500])

@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Development probe: Huffman decoding of a 4096x4096 random-pixel .jpg on the GPU vs on the host."""
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import jpezy_amd as J  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+
+
+def main():
+    ctx = J.Context(0)
+    for (W, H) in ((4096, 4096), (1920, 1080)):
+        rng = np.random.default_rng(1)
+        r, g, b = (rng.integers(0, 256, W * H, dtype=np.uint8) for _ in range(3))
+        jpg = ctx.encode_jpeg(r, g, b, W, H)
+        yy, xx = np.mgrid[0:H, 0:W]
+        sm = ((xx * 3 + yy * 2) // 8 % 256).astype(np.uint8).reshape(-1)
+        jpg_s = ctx.encode_jpeg(sm, sm[::-1].copy(), np.roll(sm, 77), W, H)
+        for name, data in (("random pixels", jpg), ("smooth", jpg_s)):
+            info, want = J.read_jpeg(data)
+            t = time.perf_counter(); J.read_jpeg(data); th = time.perf_counter() - t
+            ctx.read_jpeg_gpu(data); torch.cuda.synchronize()
+            t = time.perf_counter()
+            for _ in range(5):
+                ginfo, got = ctx.read_jpeg_gpu(data)
+            torch.cuda.synchronize()
+            tg = (time.perf_counter() - t) / 5
+            ok = np.array_equal(got.cpu().numpy(), want)
+            print(f"{W}x{H} {name}: {len(data) / 1e6:.2f} MB; GPU Huffman decode {tg * 1e3:.2f} ms ({ctx.last_huffdec_passes()} passes) = "
+                  f"{W * H / tg / 1e6:.0f} Mpx/s; host {th * 1e3:.1f} ms = {W * H / th / 1e6:.0f} Mpx/s; identical: {ok}")
+
+
+if __name__ == "__main__":
+    main()

@@ -31,6 +31,11 @@ def main():
             torch.cuda.synchronize()
             tg = (time.perf_counter() - t) / 5
             ok = np.array_equal(got.cpu().numpy(), want)
+            t = time.perf_counter()
+            for _ in range(3):
+                ctx.decode_jpeg(data)
+            te = (time.perf_counter() - t) / 3
+            print(f"{W}x{H} {name}: jpezy_decode_jpeg (.jpg bytes on the host -> r,g,b planes on the host, Huffman + IDCT + colour on the GPU): {te * 1e3:.2f} ms")
             print(f"{W}x{H} {name}: {len(data) / 1e6:.2f} MB; GPU Huffman decode {tg * 1e3:.2f} ms ({ctx.last_huffdec_passes()} passes) = "
                   f"{W * H / tg / 1e6:.0f} Mpx/s; host {th * 1e3:.1f} ms = {W * H / th / 1e6:.0f} Mpx/s; identical: {ok}")
 

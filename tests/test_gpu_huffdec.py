@@ -157,3 +157,13 @@ def test_decode_jpeg_end_to_end(J, ctx, oracle):
         assert np.array_equal(a, np.asarray(e).reshape(-1)[: 104 * 72])
     with pytest.raises(J.JpezyError):
         ctx.decode_jpeg(jpg[:500])
+
+
+def test_differential_fuzz_small(J, ctx):
+    """a short run of tools/fuzz_huffdec.py: random sizes, contents, qualities, sampling factors, optimised tables"""
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    out = subprocess.run([sys.executable, str(root / "tools" / "fuzz_huffdec.py"), "30"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "files identical" in out.stdout, out.stdout + out.stderr

@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""Differential fuzz of the GPU Huffman decoder against the host decoder: random sizes, contents, qualities, sampling
+factors, optimised tables (libjpeg via PIL) and jpezy's own encoder; every scan goes to the GPU decoder (min_bytes 0)."""
+import io
+import sys
+from pathlib import Path
+
+import numpy as np
+from PIL import Image, ImageFile
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import jpezy_amd as J  # noqa: E402
+
+ImageFile.MAXBLOCK = 1 << 24
+
+
+def content(rng, H, W, kind):
+    yy, xx = np.mgrid[0:H, 0:W]
+    if kind == 0:
+        return rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    if kind == 1:   # smooth + noise
+        base = (np.sin(xx / 37.0) * 60 + np.cos(yy / 23.0) * 50 + 128)
+        return np.clip(base[..., None] + rng.normal(0, 6, (H, W, 3)), 0, 255).astype(np.uint8)
+    if kind == 2:   # blobs and edges
+        img = np.zeros((H, W, 3), np.float64)
+        for _ in range(20):
+            cx, cy, rad = rng.integers(0, W), rng.integers(0, H), rng.integers(5, max(6, min(H, W) // 3))
+            img[(xx - cx) ** 2 + (yy - cy) ** 2 < rad * rad] = rng.integers(0, 256, 3)
+        return np.clip(img + rng.normal(0, 2, img.shape), 0, 255).astype(np.uint8)
+    if kind == 3:   # flat with a few dots: almost periodic stream
+        img = np.full((H, W, 3), rng.integers(0, 256), np.uint8)
+        img[rng.integers(0, H, 30), rng.integers(0, W, 30)] = 255
+        return img
+    return (rng.integers(0, 4, (H, W, 3)) * 64 + 20).astype(np.uint8)
+
+
+def main():
+    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 150
+    ctx = J.Context(0)
+    ctx.set_huffdec_min_bytes(0)
+    rng = np.random.default_rng(2026)
+    gpu = host = 0
+    for case in range(n_cases):
+        W, H = int(rng.integers(8, 1400)), int(rng.integers(8, 1100))
+        img = content(rng, H, W, int(rng.integers(0, 5)))
+        files = []
+        kw = dict(quality=int(rng.integers(5, 100)), subsampling=int(rng.integers(0, 3)), optimize=bool(rng.integers(0, 2)))
+        buf = io.BytesIO(); Image.fromarray(img).save(buf, "JPEG", **kw); files.append(("pil", kw, buf.getvalue()))
+        if rng.integers(0, 3) == 0:
+            buf = io.BytesIO(); Image.fromarray(img[..., 0]).save(buf, "JPEG", quality=kw["quality"]); files.append(("pil-gray", kw, buf.getvalue()))
+        r, g, b = (np.ascontiguousarray(img[..., k]).reshape(-1) for k in range(3))
+        files.append(("jpezy", {}, ctx.encode_jpeg(r, g, b, W, H, gray=bool(rng.integers(0, 2)))))
+        for name, kw, data in files:
+            info, want = J.read_jpeg(data)
+            _, got = ctx.read_jpeg_gpu(data)
+            if ctx.last_huffdec_passes():
+                gpu += 1
+            else:
+                host += 1
+            if not np.array_equal(got.cpu().numpy(), want):
+                print("MISMATCH", case, name, W, H, kw)
+                return 1
+    print(f"{gpu + host} files identical ({gpu} decoded by the GPU decoder, {host} handed to the host decoder)")
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

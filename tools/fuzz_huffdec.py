@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Differential fuzz of the GPU Huffman decoder against the host decoder: random sizes, contents, qualities, sampling
+"""Differential fuzz of the GPU Huffman decoder against the host decoder (and of the GPU entropy coder against the host writer): random sizes, contents, qualities, sampling
 factors, optimised tables (libjpeg via PIL) and jpezy's own encoder; every scan goes to the GPU decoder (min_bytes 0)."""
 import io
 import sys
@@ -49,7 +49,12 @@ def main():
         if rng.integers(0, 3) == 0:
             buf = io.BytesIO(); Image.fromarray(img[..., 0]).save(buf, "JPEG", quality=kw["quality"]); files.append(("pil-gray", kw, buf.getvalue()))
         r, g, b = (np.ascontiguousarray(img[..., k]).reshape(-1) for k in range(3))
-        files.append(("jpezy", {}, ctx.encode_jpeg(r, g, b, W, H, gray=bool(rng.integers(0, 2)))))
+        gray = bool(rng.integers(0, 2))
+        own = ctx.encode_jpeg(r, g, b, W, H, gray=gray)               # FDCT + GPU entropy coder
+        if own != J.write_jpeg(ctx.fdct_quant(r, g, b, W, H, gray=gray), W, H, gray):   # same coefficients through the host writer
+            print("ENCODER MISMATCH", case, W, H, gray)
+            return 1
+        files.append(("jpezy", {}, own))
         for name, kw, data in files:
             info, want = J.read_jpeg(data)
             _, got = ctx.read_jpeg_gpu(data)

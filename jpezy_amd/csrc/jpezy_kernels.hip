@@ -517,6 +517,16 @@ __device__ __forceinline__ uint32_t clamp_byte(double v)   // revise_value, ref 
     return (uint32_t)min(max(iv, 0), 255);
 }
 
+// one coefficient from the LDS staging area as a sign-extended int (ds_read_i16).  The empty asm keeps the compiler from
+// splitting the value into a zero-extended load for the "any non-zero AC" test and a v_bfe_i32 sign extension for the
+// arithmetic (21 extra instructions per quad).
+__device__ __forceinline__ int ld_coef(const int16_t* p)
+{
+    int v = *p;
+    asm("" : "+v"(v));          // not volatile: the loads may still be reordered
+    return v;
+}
+
 #ifndef JPEZY_DEC_WAVES
 #define JPEZY_DEC_WAVES 5
 #endif
@@ -592,13 +602,13 @@ __global__ __launch_bounds__(64 * WPB, JPEZY_DEC_WAVES) void dequant_idct_kernel
         const int16_t* bb = stage + (m * BPM + 2 + bx) * 64;
         int c[8], acor;
 #pragma unroll
-        for (int v = 0; v < 8; ++v) { c[v] = bt[zp[v]]; in[v] = (double)c[v] * dq[v]; cmx = max(cmx, c[v]); cmn = min(cmn, c[v]); }
+        for (int v = 0; v < 8; ++v) { c[v] = ld_coef(bt + zp[v]); in[v] = (double)c[v] * dq[v]; cmx = max(cmx, c[v]); cmn = min(cmn, c[v]); }
         if (u == 0) in[0] = cucv_dc * (double)(c[0] * p.dqt[0]) * 0.25;
         acor = (u ? c[0] : 0) | c[1] | c[2] | c[3] | c[4] | c[5] | c[6] | c[7];
         ac_top = __ballot(acor != 0);
         idct8(in, gtop);
 #pragma unroll
-        for (int v = 0; v < 8; ++v) { c[v] = bb[zp[v]]; in[v] = (double)c[v] * dq[v]; cmx = max(cmx, c[v]); cmn = min(cmn, c[v]); }
+        for (int v = 0; v < 8; ++v) { c[v] = ld_coef(bb + zp[v]); in[v] = (double)c[v] * dq[v]; cmx = max(cmx, c[v]); cmn = min(cmn, c[v]); }
         if (u == 0) in[0] = cucv_dc * (double)(c[0] * p.dqt[0]) * 0.25;
         acor = (u ? c[0] : 0) | c[1] | c[2] | c[3] | c[4] | c[5] | c[6] | c[7];
         ac_bot = __ballot(acor != 0);
@@ -608,7 +618,7 @@ __global__ __launch_bounds__(64 * WPB, JPEZY_DEC_WAVES) void dequant_idct_kernel
             const int16_t* bc = stage + (m * BPM + 3 + comp) * 64;
 #pragma unroll
             for (int v = 0; v < 8; ++v) {
-                c[v] = bc[zp[v]];
+                c[v] = ld_coef(bc + zp[v]);
                 in[v] = (double)c[v] * p.dqscale[(comp * 8 + u) * 8 + v];
                 cmx = max(cmx, c[v]);
                 cmn = min(cmn, c[v]);

@@ -36,7 +36,11 @@ constexpr uint32_t STATE_ERR = 0xC0000000u;
 // dependent global load per symbol): the 256 subsequences of the workgroup plus a tail for the last lane's overrun.
 constexpr int OVERFLOW = 12;      // most subsequences a speculating lane may decode beyond its own (window size)
 constexpr int OVERFLOW_DEFAULT = 3;   // measured on 4096^2 random pixels: 1: 92 % of the proposals true, 3: 99.5 %, 8: all; 2-4 is the fastest overall
-constexpr int WINDOW_WORDS = (WGS + OVERFLOW) * SUBSEQ_BITS / 32 + 16;
+constexpr int WINDOW_LINEAR = (WGS + OVERFLOW) * SUBSEQ_BITS / 32 + 16;
+// A subsequence is 32 words, so lane l's cursor sits at word 32 l + k: without padding all 64 lanes of a wave hit the
+// same LDS bank on every read.  One pad word per 32 spreads them over the banks (word i lives at i + i / 32).
+constexpr int WINDOW_WORDS = WINDOW_LINEAR + WINDOW_LINEAR / 32 + 1;
+__device__ __forceinline__ unsigned pad_index(unsigned i) { return i + (i >> 5); }
 
 struct Cursor {
     const uint32_t* w;            // LDS window, raw words (big-endian bytes)
@@ -51,7 +55,7 @@ struct Cursor {
         const unsigned rel = (unsigned)(p - base);
         const unsigned i = rel >> 5;
         const int sh = (int)(rel & 31);
-        buf = (((unsigned long long)__builtin_bswap32(w[i]) << 32) | __builtin_bswap32(w[i + 1])) << sh;
+        buf = (((unsigned long long)__builtin_bswap32(w[pad_index(i)]) << 32) | __builtin_bswap32(w[pad_index(i + 1)])) << sh;
         avail = 64 - sh;
         next = i + 2;
     }
@@ -62,7 +66,7 @@ struct Cursor {
         avail -= (int)n;
         pos += n;
         if (avail <= 32) {                                // one LDS word per 32 bits consumed
-            buf |= (unsigned long long)__builtin_bswap32(w[next++]) << (32 - avail);
+            buf |= (unsigned long long)__builtin_bswap32(w[pad_index(next++)]) << (32 - avail);
             avail += 32;
         }
     }
@@ -71,7 +75,7 @@ struct Cursor {
 __device__ __forceinline__ void load_window(uint32_t* win, const uint32_t* U, unsigned first_sub, size_t u_words)
 {
     const size_t w0 = (size_t)first_sub * (SUBSEQ_BITS / 32);
-    for (unsigned i = threadIdx.x; i < (unsigned)WINDOW_WORDS; i += WGS) win[i] = w0 + i < u_words ? U[w0 + i] : 0u;
+    for (unsigned i = threadIdx.x; i < (unsigned)WINDOW_LINEAR; i += WGS) win[pad_index(i)] = w0 + i < u_words ? U[w0 + i] : 0u;
 }
 
 // one symbol of table t at the cursor: returns the symbol (or -1) and its code length

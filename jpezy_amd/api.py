@@ -188,7 +188,7 @@ class Context:
         return planes
 
     def dequant_idct_generic(self, coeffs, info, gray=False):
-        """any baseline layout (1/3 components, sampling 1..2): info is the FrameInfo of read_jpeg"""
+        """any baseline layout (1/3 components, sampling 1..4): info is the FrameInfo of read_jpeg"""
         coeffs = np.ascontiguousarray(coeffs, dtype=np.int16)
         W, H = info.width, info.height
         hs = (C.c_uint8 * 3)(*[max(1, info.H[i]) for i in range(3)])

@@ -439,22 +439,23 @@ int jpezy_dequant_idct(jpezy_ctx* c, const int16_t* coeffs, const uint16_t qt[4]
     return JPEZY_OK;
 }
 
-int jpezy_dequant_idct_generic(jpezy_ctx* c, const int16_t* coeffs, const uint16_t qt[4][64], int ncomp, const uint8_t comp_h[3],
-                               const uint8_t comp_v[3], const uint8_t comp_tq[3], int W, int H, int gray, uint8_t* r, uint8_t* g,
-                               uint8_t* b)
+static int dequant_idct_generic_impl(jpezy_ctx* c, const int16_t* coeffs, const uint16_t qt[4][64], int ncomp, const uint8_t comp_h[3],
+                                     const uint8_t comp_v[3], const uint8_t comp_tq[3], int W, int H, int gray, int precision,
+                                     uint8_t* r, uint8_t* g, uint8_t* b)
 {
     if (int rc = check_dims(c, W, H, 1)) return rc;
     if (!coeffs || !qt || !comp_h || !comp_v || !comp_tq || !r || !g || !b) return set_err(JPEZY_E_BADARG, "null pointer");
     if (ncomp != 1 && ncomp != 3) return set_err(JPEZY_E_UNSUPPORTED, "dimension not supported (the reference accepts 1 or 3)");
     GenericDecParams p;
     p.W = W; p.H = H; p.ncomp = ncomp; p.gray = gray != 0;
+    p.level = precision == 8 ? 128 : 2048;                    // ref :654
     p.hmax = p.vmax = 0;
     p.blocks_per_mcu = 0;
     for (int k = 0; k < 3; ++k) { p.ch[k] = p.cv[k] = 1; p.blk_start[k] = 1 << 20; }
     for (int k = 0; k < ncomp; ++k) {
         p.ch[k] = comp_h[k]; p.cv[k] = comp_v[k];
-        if (p.ch[k] < 1 || p.ch[k] > 2 || p.cv[k] < 1 || p.cv[k] > 2)
-            return set_err(JPEZY_E_UNSUPPORTED, "sampling factors outside 1..2");
+        if (p.ch[k] < 1 || p.ch[k] > 4 || p.cv[k] < 1 || p.cv[k] > 4)
+            return set_err(JPEZY_E_UNSUPPORTED, "sampling factors outside 1..4 (ITU-T T.81 B.2.2)");
         p.hmax = p.ch[k] > p.hmax ? p.ch[k] : p.hmax;
         p.vmax = p.cv[k] > p.vmax ? p.cv[k] : p.vmax;
         p.blk_start[k] = p.blocks_per_mcu;
@@ -486,6 +487,13 @@ int jpezy_dequant_idct_generic(jpezy_ctx* c, const int16_t* coeffs, const uint16
     for (int k = 0; k < 3; ++k) HIP_TRY(hipMemcpyAsync(dst[k], c->in[k].p, plane, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return JPEZY_OK;
+}
+
+int jpezy_dequant_idct_generic(jpezy_ctx* c, const int16_t* coeffs, const uint16_t qt[4][64], int ncomp, const uint8_t comp_h[3],
+                               const uint8_t comp_v[3], const uint8_t comp_tq[3], int W, int H, int gray, uint8_t* r, uint8_t* g,
+                               uint8_t* b)
+{
+    return dequant_idct_generic_impl(c, coeffs, qt, ncomp, comp_h, comp_v, comp_tq, W, H, gray, 8, r, g, b);
 }
 
 long jpezy_write_jpeg(const int16_t* coeffs, int W, int H, int gray, const char* comment, uint8_t* out, size_t cap)
@@ -988,7 +996,7 @@ int jpezy_decode_jpeg(jpezy_ctx* c, const uint8_t* data, size_t len, int gray, j
         if (rc < 0) { g_err = err; return rc; }
         const uint8_t hs[3] = { (uint8_t)info->H[0], (uint8_t)info->H[1], (uint8_t)info->H[2] };
         const uint8_t vs[3] = { (uint8_t)info->V[0], (uint8_t)info->V[1], (uint8_t)info->V[2] };
-        return jpezy_dequant_idct_generic(c, co.data(), info->qt, info->ncomp, hs, vs, tq, W, H, gray, r, g, b);
+        return dequant_idct_generic_impl(c, co.data(), info->qt, info->ncomp, hs, vs, tq, W, H, gray, info->precision, r, g, b);
     }
     // jpezy's own layout: Huffman decoding, dequantisation, IDCT and colour conversion all on the device
     HIP_TRY(hipSetDevice(c->device));

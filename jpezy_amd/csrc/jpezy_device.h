@@ -110,6 +110,7 @@ struct GenericDecParams {
     int W, H, ncomp, gray;
     int ch[3], cv[3], hmax, vmax, mcu_cols, mcu_rows, blocks_per_mcu;
     int blk_start[3];         // first block of each component inside an MCU
+    int level;                // level shift of inverse_dct: 128, or 2048 when SOF0 says precision != 8 (ref :654)
 };
 hipError_t launch_dequant_idct_generic(const GenericDecParams& p, hipStream_t stream);
 

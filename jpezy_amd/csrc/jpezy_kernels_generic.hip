@@ -1,8 +1,8 @@
 // jpezy_kernels_generic.hip -- decode for ANY baseline layout the reference's decoder accepts (1 or 3 components,
-// sampling factors 1..2): the reference's arithmetic itself, one sample per lane.
+// sampling factors 1..4): the reference's arithmetic itself, one sample per lane.
 //   generic_idct_kernel : one wavefront per 8x8 block; lane (y, x) accumulates the 64 terms
 //                         ((cu*cv) * (coef*Q)) * cos[u][x] * cos[v][y] in the reference's order (v outer, u inner) and
-//                         stores int(sum/4 + 128)                     (ref decoder/jpezy_decoder.hpp:645-670)
+//                         stores int(sum/4 + sl), sl = 128 (2048 if precision != 8)  (ref decoder/jpezy_decoder.hpp:645-670)
 //   generic_rgb_kernel  : one lane per pixel; nearest-neighbour replication of each component (ref :504-528), then
 //                         make_rgb / revise_value in the reference's FP64 order (ref :531-578, 672-676)
 // Exact by construction (plain IEEE mul/add, -ffp-contract=off), no guard bands.  ~10x slower than the fused kernel of
@@ -40,7 +40,7 @@ __global__ __launch_bounds__(64) void generic_idct_kernel(GenericDecParams p)
             sum += cu * cv * dct[v * 8 + u] * c_cos[u * 8 + x] * c_cos[v * 8 + y];
         }
     }
-    p.samples[blk * 64 + lane] = (int)(sum / 4 + 128);
+    p.samples[blk * 64 + lane] = (int)(sum / 4 + p.level);
 }
 
 __device__ __forceinline__ uint8_t revise(double v) { return (v < 0.0) ? 0 : (v > 255.0) ? 255 : (uint8_t)v; }
@@ -55,12 +55,18 @@ __global__ __launch_bounds__(256) void generic_rgb_kernel(GenericDecParams p)
     const long mcu = (long)uy * p.mcu_cols + ux;
     int s[3] = { 0, 0x80, 0x80 };                              // missing components read 0x80 (ref :104-105)
     for (int c = 0; c < p.ncomp; ++c) {
+        // decode_mcu (ref :504-528) writes block (kx, ky) of the component at plane offset (kx*8, ky*8) -- not scaled by the
+        // replication factor -- as a rectangle of 8*dupx x 8*dupy samples, ky outer, kx inner; the last write to a position
+        // stays.  For H == hmax or H == 1 that is ordinary nearest-neighbour upsampling.  For the other legal factors
+        // (H = 2 or 3 under hmax = 3 or 4) later blocks overwrite part of earlier ones and the right/bottom end of the
+        // plane is never written: it keeps the initial value of comp[] (0 / 0x80, ref :104-105) in every MCU.
         const int dupx = p.hmax / p.ch[c], dupy = p.vmax / p.cv[c];
-        const int sx = ix / dupx, sy = iy / dupy;              // sample inside the component's MCU plane (ref :519-524)
-        const int kx = sx >> 3, ky = sy >> 3;
-        if (kx >= p.ch[c] || ky >= p.cv[c]) continue;          // hmax % H != 0 layouts: the reference leaves stale data; keep 0x80/0
+        const int kx = min(p.ch[c] - 1, ix >> 3), ky = min(p.cv[c] - 1, iy >> 3);      // last block written over (ix, iy)
+        const int xu = ix - kx * 8, yu = iy - ky * 8;
+        if (xu >= 8 * dupx || yu >= 8 * dupy) continue;                                // never written
+        const int sx = xu / dupx, sy = yu / dupy;
         const long blk = mcu * p.blocks_per_mcu + p.blk_start[c] + ky * p.ch[c] + kx;
-        s[c] = p.samples[blk * 64 + (sy & 7) * 8 + (sx & 7)];
+        s[c] = p.samples[blk * 64 + sy * 8 + sx];
     }
     const double yp = s[0], up = s[1], vp = s[2];
     if (!p.gray) {

@@ -362,6 +362,38 @@ def test_generic_decode_of_libjpeg_files(J, ctx, oracle, kw):
             assert np.array_equal(a, e)
 
 
+@pytest.mark.parametrize("name", ["411", "h4v2_partial", "h3_partial", "v4", "h4v4", "one_comp_2x2"])
+def test_generic_decode_sampling_up_to_4(J, ctx, oracle, name):
+    """every H, V the reference's decode_mcu accepts, including its placement of blocks when H does not equal
+    hmax or 1 (overlapping replication rectangles, a never-written end of the plane, ref :504-528) -- the oracle restates
+    that loop literally, the kernel computes the last writer of each pixel."""
+    from test_host_codec import ODD_LAYOUTS
+    from jpeg_synth import synth_jpeg
+    data, co, _ = synth_jpeg(101, 70, ODD_LAYOUTS[name], seed=len(name))
+    info, hco = J.read_jpeg(data)
+    oinfo, oco = oracle.read_jpeg(data)
+    for gray in (False, True):
+        want = oracle.decode_planes(oco, oinfo, gray)
+        got = ctx.dequant_idct_generic(hco, info, gray=gray)
+        for a, e in zip(got, want):
+            assert np.array_equal(a, np.asarray(e).reshape(-1))
+        _, r, g, b = ctx.decode_jpeg(data, gray=gray)                     # decoder::decode end to end
+        for a, e in zip((r, g, b), want):
+            assert np.array_equal(a, np.asarray(e).reshape(-1))
+
+
+def test_sof0_precision_other_than_8_shifts_by_2048(J, ctx, oracle):
+    """inverse_dct's level shift is 128 only when SOF0 says precision 8, otherwise 2048 (ref :654); the samples then clamp
+    to 255 almost everywhere -- reproduced, not rejected"""
+    from jpeg_synth import synth_jpeg
+    for comps in ([(2, 2, 0, 0), (1, 1, 1, 1), (1, 1, 1, 1)], [(1, 1, 0, 0), (1, 1, 1, 1), (1, 1, 1, 1)]):
+        data, _, _ = synth_jpeg(64, 48, comps, seed=5, precision=12, amp=200)
+        _, er, eg, eb = oracle.decode_jpeg(data)
+        _, r, g, b = ctx.decode_jpeg(data)
+        for a, e in zip((r, g, b), (er, eg, eb)):
+            assert np.array_equal(a, np.asarray(e).reshape(-1))
+
+
 def test_two_contexts_from_two_threads(J, oracle):
     """ABI contract (include/jpezy_hip.h): a context is used by one thread at a time, distinct contexts may run
     concurrently -- two host threads create their own context and encode/decode different frames at the same time."""

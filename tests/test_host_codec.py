@@ -156,6 +156,29 @@ def test_read_jpeg_matches_oracle_on_libjpeg_files(oracle):
     assert info.ncomp == 1 and np.array_equal(co, oc)
 
 
+ODD_LAYOUTS = {
+    "411": [(4, 1, 0, 0), (1, 1, 1, 1), (1, 1, 1, 1)],
+    "h4v2_partial": [(4, 2, 0, 0), (2, 1, 1, 1), (2, 2, 1, 1)],           # H = 2 under hmax = 4: decode_mcu's overlapping writes
+    "h3_partial": [(3, 1, 0, 0), (1, 1, 1, 1), (2, 1, 1, 0)],             # hmax % H != 0: the end of the plane is never written
+    "v4": [(1, 4, 0, 0), (1, 2, 1, 1), (1, 3, 0, 1)],
+    "h4v4": [(4, 4, 0, 0), (3, 3, 1, 1), (2, 2, 1, 1)],                   # 29 blocks per MCU
+    "one_comp_2x2": [(2, 2, 0, 0)],
+}
+
+
+@pytest.mark.parametrize("name", sorted(ODD_LAYOUTS))
+def test_read_jpeg_of_layouts_libjpeg_does_not_write(oracle, name):
+    """sampling factors up to 4 and factors that do not divide hmax/vmax (ref decoder/jpezy_decoder.hpp:279-305 takes any
+    nibble): the host head delivers the synthesised coefficients, and so does the oracle's restatement"""
+    from jpeg_synth import synth_jpeg
+    data, co, _ = synth_jpeg(101, 70, ODD_LAYOUTS[name], seed=len(name))
+    oinfo, oco = oracle.read_jpeg(data)
+    info, hco = api.read_jpeg(data)
+    assert np.array_equal(np.asarray(oco).reshape(-1), co)
+    assert np.array_equal(np.asarray(hco).reshape(-1), co)
+    assert (info.hmax, info.vmax, info.blocks_per_mcu) == (oinfo.hmax, oinfo.vmax, oinfo.blocks_per_mcu)
+
+
 def test_malformed_streams_fail_cleanly(golden_dir):
     z = np.load(golden_dir / "rand64.npz")
     jpg = z["jpg"].tobytes()

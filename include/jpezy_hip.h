@@ -201,8 +201,8 @@ int jpezy_read_jpeg_gpu(jpezy_ctx* ctx, const uint8_t* data, size_t len, jpezy_f
 /*
  * decoder::decode end to end (decoder/jpezy_decoder.hpp:76-134): .jpg bytes in, planar r,g,b (plane_cap >= width*height
  * bytes each) out; info receives the header fields.  jpezy's own layout (3 components sampled 2x2/1x1/1x1, 8 bit) runs
- * Huffman decoding, dequantisation, IDCT and colour conversion on the device; every other baseline layout the
- * reference accepts takes the host Huffman decoder and the generic kernels.  r,g,b NULL: header only.
+ * Huffman decoding, dequantisation, IDCT and colour conversion on the device in one fused kernel; every other baseline
+ * layout the reference accepts takes the same device Huffman decoder and the generic kernels.  r,g,b NULL: header only.
  */
 int jpezy_decode_jpeg(jpezy_ctx* ctx, const uint8_t* data, size_t len, int gray, jpezy_frame_info* info, uint8_t* r,
                       uint8_t* g, uint8_t* b, size_t plane_cap);

@@ -441,7 +441,7 @@ int jpezy_dequant_idct(jpezy_ctx* c, const int16_t* coeffs, const uint16_t qt[4]
 
 static int dequant_idct_generic_impl(jpezy_ctx* c, const int16_t* coeffs, const uint16_t qt[4][64], int ncomp, const uint8_t comp_h[3],
                                      const uint8_t comp_v[3], const uint8_t comp_tq[3], int W, int H, int gray, int precision,
-                                     uint8_t* r, uint8_t* g, uint8_t* b)
+                                     uint8_t* r, uint8_t* g, uint8_t* b, bool coeffs_on_device = false)
 {
     if (int rc = check_dims(c, W, H, 1)) return rc;
     if (!coeffs || !qt || !comp_h || !comp_v || !comp_tq || !r || !g || !b) return set_err(JPEZY_E_BADARG, "null pointer");
@@ -467,7 +467,8 @@ static int dequant_idct_generic_impl(jpezy_ctx* c, const int16_t* coeffs, const 
     HIP_TRY(hipSetDevice(c->device));
     const size_t nblk = (size_t)p.mcu_cols * p.mcu_rows * p.blocks_per_mcu;
     const size_t plane = (size_t)W * H;
-    if (int rc = c->out.reserve(nblk * 64 * sizeof(int16_t))) return rc;
+    if (!coeffs_on_device)
+        if (int rc = c->out.reserve(nblk * 64 * sizeof(int16_t))) return rc;
     if (int rc = c->scratch.reserve(nblk * 64 * sizeof(int) + 3 * 64 * sizeof(int))) return rc;
     for (int k = 0; k < 3; ++k)
         if (int rc = c->in[k].reserve(plane)) return rc;
@@ -476,9 +477,9 @@ static int dequant_idct_generic_impl(jpezy_ctx* c, const int16_t* coeffs, const 
         for (int i = 0; i < 64; ++i) h_qt[k][i] = qt[(k < ncomp ? comp_tq[k] : 0) & 3][i];
     int* d_qt = (int*)((char*)c->scratch.p + nblk * 64 * sizeof(int));
     HIP_TRY(hipMemcpyAsync(d_qt, h_qt, sizeof h_qt, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemcpyAsync(c->out.p, coeffs, nblk * 64 * sizeof(int16_t), hipMemcpyHostToDevice, c->stream));
+    if (!coeffs_on_device) HIP_TRY(hipMemcpyAsync(c->out.p, coeffs, nblk * 64 * sizeof(int16_t), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));                  // h_qt lives on this stack frame
-    p.coeffs = (const int16_t*)c->out.p;
+    p.coeffs = coeffs_on_device ? coeffs : (const int16_t*)c->out.p;
     p.samples = (int*)c->scratch.p;
     p.qt = d_qt;
     p.r = (uint8_t*)c->in[0].p; p.g = (uint8_t*)c->in[1].p; p.b = (uint8_t*)c->in[2].p;
@@ -814,8 +815,8 @@ int jpezy_read_jpeg_gpu(jpezy_ctx* c, const uint8_t* data, size_t len, jpezy_fra
     const size_t total_blocks = nmcu * (size_t)bpm, total = total_blocks * 64;
     if (coeff_cap < total) return set_err(JPEZY_E_NOSPACE, "read_jpeg_gpu: coefficient buffer too small");
 
-    // what the GPU decoder takes: no restart intervals, at most 12 blocks per MCU, every selected table present
-    bool gpu_ok = info->restart_interval == 0 && bpm <= 12 && total_blocks < 0xFFFFFFFFull && setup.scan_pos < len;
+    // what the GPU decoder takes: no restart intervals, at most 48 blocks per MCU (3 components of 4 x 4), every selected table present
+    bool gpu_ok = info->restart_interval == 0 && bpm <= 48 && total_blocks < 0xFFFFFFFFull && setup.scan_pos < len;
     for (int i = 0; i < info->ncomp && gpu_ok; ++i)
         gpu_ok = setup.Td[i] >= 0 && setup.Td[i] <= 2 && setup.present[setup.Td[i]] && setup.present[4 + setup.Td[i]];
     if (!gpu_ok) return read_jpeg_host_to_device(c, data, len, info, d_coeffs, total);
@@ -855,12 +856,23 @@ int jpezy_read_jpeg_gpu(jpezy_ctx* c, const uint8_t* data, size_t len, jpezy_fra
         if (setup.present[td]) build_dev_table(S.dc[td], setup.bits[td], setup.vals[td], setup.nvals[td]);
         if (setup.present[4 + td]) build_dev_table(S.ac[td], setup.bits[4 + td], setup.vals[4 + td], setup.nvals[4 + td]);
     }
-    S.bpm = bpm;
     S.total_blocks = (unsigned)total_blocks;
     {
-        int b = 0;
+        // The decoder's state carries the block's position inside the MCU only to pick the tables.  It counts modulo the
+        // PERIOD of the table sequence: with one table pair for every block (a one-component file, or all Td equal) a
+        // decoder that has found the right bit position is in the right state whatever MCU phase it guessed.
+        int seq[48], b = 0;
         for (int i = 0; i < info->ncomp; ++i)
-            for (int k = info->H[i] * info->V[i]; k > 0; --k) S.btd[b++] = setup.Td[i];
+            for (int k = info->H[i] * info->V[i]; k > 0; --k) seq[b++] = setup.Td[i];
+        int period = bpm;
+        for (int pd = 1; pd < bpm; ++pd) {
+            if (bpm % pd) continue;
+            bool ok = true;
+            for (int i = pd; i < bpm && ok; ++i) ok = seq[i] == seq[i - pd];
+            if (ok) { period = pd; break; }
+        }
+        S.bpm = period;
+        for (int i = 0; i < period; ++i) S.btd[i] = seq[i];
     }
     HIP_TRY(hipMemcpyAsync(c->h_setup.p, &S, sizeof S, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(c->h_scan.p, scan, n, hipMemcpyHostToDevice, s));
@@ -989,14 +1001,16 @@ int jpezy_decode_jpeg(jpezy_ctx* c, const uint8_t* data, size_t len, int gray, j
     const uint8_t tq[3] = { (uint8_t)info->Tq[0], (uint8_t)info->Tq[1], (uint8_t)info->Tq[2] };
     const bool own_layout = info->ncomp == 3 && info->precision == 8 && info->H[0] == 2 && info->V[0] == 2 && info->H[1] == 1 &&
                             info->V[1] == 1 && info->H[2] == 1 && info->V[2] == 1;
-    if (!own_layout) {   // any other baseline layout decode_mcu handles (:504-528): host Huffman head + the generic kernels
-        std::vector<int16_t> co(ncoef);
-        std::string err;
-        rc = jpezy_host::read_jpeg(data, len, info, co.data(), co.size(), &err);
-        if (rc < 0) { g_err = err; return rc; }
+    if (!own_layout) {   // any other baseline layout decode_mcu handles (:504-528): Huffman decoding on the device as for
+                         // jpezy's own files (the host head for what that decoder declines), then the generic kernels
+        HIP_TRY(hipSetDevice(c->device));
+        if (int rc2 = c->out.reserve(ncoef * sizeof(int16_t))) return rc2;
+        rc = jpezy_read_jpeg_gpu(c, data, len, info, (int16_t*)c->out.p, ncoef);
+        if (rc < 0) return rc;
         const uint8_t hs[3] = { (uint8_t)info->H[0], (uint8_t)info->H[1], (uint8_t)info->H[2] };
         const uint8_t vs[3] = { (uint8_t)info->V[0], (uint8_t)info->V[1], (uint8_t)info->V[2] };
-        return dequant_idct_generic_impl(c, co.data(), info->qt, info->ncomp, hs, vs, tq, W, H, gray, info->precision, r, g, b);
+        return dequant_idct_generic_impl(c, (const int16_t*)c->out.p, info->qt, info->ncomp, hs, vs, tq, W, H, gray, info->precision, r,
+                                         g, b, true);
     }
     // jpezy's own layout: Huffman decoding, dequantisation, IDCT and colour conversion all on the device
     HIP_TRY(hipSetDevice(c->device));

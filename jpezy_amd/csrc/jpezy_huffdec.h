@@ -17,8 +17,8 @@ struct Table {
 
 struct Setup {
     Table dc[3], ac[3];       // indexed by the scan component's table selector Td (the reference uses Td for both)
-    int bpm;                  // blocks per MCU
-    int btd[12];              // Td of block b of an MCU
+    int bpm;                  // period of the table sequence over the blocks of an MCU (divides the blocks per MCU)
+    int btd[48];              // Td of block b of a period
     unsigned total_blocks;
     unsigned pad[2];
 };

@@ -765,24 +765,27 @@ long jpezy_encode_jpeg(jpezy_ctx* c, const uint8_t* r, const uint8_t* g, const u
 // ---- GPU Huffman decoding (decode side) ----
 namespace {
 
-void build_dev_table(jpezy_dev::huffdec::Table& t, const uint8_t bits[16], const uint8_t* vals, int n)
+// false: the counts do not describe a prefix code (more codes of some length than the code space has left) -- such a
+// table is left to the host decoder, whose canonical loop defines what it means
+bool build_dev_table(jpezy_dev::huffdec::Table& t, const uint8_t bits[16], const uint8_t* vals, int n)
 {
     std::memset(&t, 0, sizeof t);
     std::memcpy(t.val, vals, (size_t)n);
-    int code = 0, p = 0;
+    unsigned code = 0;
+    int p = 0;
     for (int l = 1; l <= 16; ++l) {
-        t.valptr[l] = p;
-        t.mincode[l] = code;
+        t.off[l] = p - (int)code;
         for (int c = 0; c < bits[l - 1]; ++c, ++p, ++code) {
             if (l <= 9) {
-                const int lo = code << (9 - l);
-                for (int f = 0; f < (1 << (9 - l)); ++f) t.look[lo + f] = (uint16_t)((l << 8) | vals[p]);
+                const unsigned lo = code << (9 - l);
+                for (unsigned f = 0; f < (1u << (9 - l)); ++f) t.look[lo + f] = (uint16_t)((l << 8) | vals[p]);
             }
         }
-        t.maxcode[l] = bits[l - 1] ? code - 1 : -1;
+        if (code > (1u << l)) return false;
+        if (l >= 9) t.limit[l - 9] = code << (16 - l);
         code <<= 1;
     }
-    t.maxcode[17] = 0x7FFFFFFF;
+    return true;
 }
 
 // host decode + upload: the authoritative path for everything the GPU decoder does not take or is unsure about
@@ -853,9 +856,10 @@ int jpezy_read_jpeg_gpu(jpezy_ctx* c, const uint8_t* data, size_t len, jpezy_fra
     HD::Setup& S = hs[0];
     std::memset(&S, 0, sizeof S);
     for (int td = 0; td < 3; ++td) {
-        if (setup.present[td]) build_dev_table(S.dc[td], setup.bits[td], setup.vals[td], setup.nvals[td]);
-        if (setup.present[4 + td]) build_dev_table(S.ac[td], setup.bits[4 + td], setup.vals[4 + td], setup.nvals[4 + td]);
+        if (setup.present[td]) gpu_ok = build_dev_table(S.dc[td], setup.bits[td], setup.vals[td], setup.nvals[td]) && gpu_ok;
+        if (setup.present[4 + td]) gpu_ok = build_dev_table(S.ac[td], setup.bits[4 + td], setup.vals[4 + td], setup.nvals[4 + td]) && gpu_ok;
     }
+    if (!gpu_ok) return read_jpeg_host_to_device(c, data, len, info, d_coeffs, total);
     S.total_blocks = (unsigned)total_blocks;
     {
         // The decoder's state carries the block's position inside the MCU only to pick the tables.  It counts modulo the

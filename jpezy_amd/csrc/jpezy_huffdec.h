@@ -7,11 +7,13 @@
 namespace jpezy_dev {
 namespace huffdec {
 
-struct Table {
+struct alignas(16) Table {
     uint16_t look[512];   // 9-bit lookup: (code length << 8) | symbol, 0 when the code is longer than 9 bits
-    int maxcode[18];      // canonical decoding of the longer codes: largest code of each length, -1 if none
-    int valptr[17];
-    int mincode[17];
+    // canonical decoding of the longer codes without a loop: limit[l - 9] = first 16-bit left-aligned code word that is NOT
+    // a code of length <= l (non-decreasing in l), so the length of a long code is 10 + #{l in 10..15: word >= limit};
+    // off[l] = index of the first symbol of length l minus the first code of length l
+    uint32_t limit[8];
+    int off[17];
     uint8_t val[256];
 };
 

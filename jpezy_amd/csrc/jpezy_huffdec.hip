@@ -24,7 +24,10 @@
 namespace jpezy_dev {
 namespace huffdec {
 
-constexpr int SUBSEQ_BITS = 1024;
+#ifndef JPEZY_SUBSEQ_BITS
+#define JPEZY_SUBSEQ_BITS 1024
+#endif
+constexpr int SUBSEQ_BITS = JPEZY_SUBSEQ_BITS;
 constexpr int WGS = 256;
 
 // packed lane state: bit 31 valid, bit 30 error, p (bit offset of the next code word past the subsequence end) << 16,
@@ -34,8 +37,8 @@ constexpr uint32_t STATE_ERR = 0xC0000000u;
 
 // A workgroup's window of the unstuffed scan lives in LDS (coalesced copy, then ~100 ns per access instead of a
 // dependent global load per symbol): the 256 subsequences of the workgroup plus a tail for the last lane's overrun.
-constexpr int OVERFLOW = 12;      // most subsequences a speculating lane may decode beyond its own (window size)
-constexpr int OVERFLOW_DEFAULT = 3;   // measured on 4096^2 random pixels: 1: 92 % of the proposals true, 3: 99.5 %, 8: all; 2-4 is the fastest overall
+constexpr int OVERFLOW = 12 * 1024 / SUBSEQ_BITS;      // most subsequences a speculating lane may decode beyond its own (window size)
+constexpr int OVERFLOW_DEFAULT = 3 * 1024 / SUBSEQ_BITS;   // in 1024-bit units: measured on 4096^2 random pixels: 1: 92 % of the proposals true, 3: 99.5 %, 8: all; 2-4 is the fastest overall
 constexpr int WINDOW_LINEAR = (WGS + OVERFLOW) * SUBSEQ_BITS / 32 + 16;
 // A subsequence is 32 words, so lane l's cursor sits at word 32 l + k: without padding all 64 lanes of a wave hit the
 // same LDS bank on every read.  One pad word per 32 spreads them over the banks (word i lives at i + i / 32).
@@ -78,18 +81,18 @@ __device__ __forceinline__ void load_window(uint32_t* win, const uint32_t* U, un
     for (unsigned i = threadIdx.x; i < (unsigned)WINDOW_LINEAR; i += WGS) win[pad_index(i)] = w0 + i < u_words ? U[w0 + i] : 0u;
 }
 
-// one symbol of table t at the cursor: returns the symbol (or -1) and its code length
+// one symbol of table t at the cursor: returns the symbol (or -1) and its code length.  Codes longer than 9 bits take
+// no loop: seven limits (one LDS latency, the loads are independent), six compares, two dependent loads.
 __device__ __forceinline__ int decode_symbol(const Table& t, uint32_t bits, int& len)
 {
     const unsigned e = t.look[bits >> 23];
     if (e) { len = (int)(e >> 8); return (int)(e & 0xFF); }
-#pragma unroll 1
-    for (int l = 10; l <= 16; ++l) {
-        const int code = (int)(bits >> (32 - l));
-        if (code <= t.maxcode[l]) { len = l; return t.val[t.valptr[l] + code - t.mincode[l]]; }
-    }
-    len = 0;
-    return -1;
+    const unsigned w = bits >> 16;
+    const uint4 la = *reinterpret_cast<const uint4*>(t.limit), lb = *reinterpret_cast<const uint4*>(t.limit + 4);
+    const int l = 10 + (w >= la.y) + (w >= la.z) + (w >= la.w) + (w >= lb.x) + (w >= lb.y) + (w >= lb.z);
+    len = l;
+    if (w >= lb.w) { len = 0; return -1; }
+    return t.val[(unsigned)(t.off[l] + (int)(w >> (16 - l))) & 255u];
 }
 
 __device__ __forceinline__ int extend(int v, int cat) { return (v & (1 << (cat - 1))) ? v : v - ((1 << cat) - 1); }
@@ -98,52 +101,37 @@ __device__ __forceinline__ int extend(int v, int cat) { return (v & (1 << (cat -
 // nblocks: blocks completed.  An invalid code or a run past the end of the block: EMIT returns false (the true decode
 // hit it: the stream is bad); a synchronisation pass -- which may well be decoding from a wrong guess, i.e. garbage --
 // abandons the block, moves one bit on and carries on, so that it can still fall into step further down.
+// DC and AC symbols run through the same instructions (the lanes of a wave are at unrelated places of their blocks; two
+// branches would both be executed at every step): a DC symbol is a (run 0, size = category) symbol at k = 0.
 template <bool EMIT>
 __device__ __forceinline__ bool run_subsequence(const Setup& S, Cursor& c, unsigned long long end, unsigned& b, unsigned& k,
                                                 unsigned& nblocks, unsigned long long gidx, int16_t* out)
 {
+    const Table* tabs = S.dc;                                          // dc[0..2] then ac[0..2]
+    int td = S.btd[b];
     while (c.pos < end) {
         const uint32_t bits = c.peek32();
-        const int td = S.btd[b];
+        const bool is_dc = k == 0;
         int len;
-        bool bad = false;
-        if (k == 0) {
-            const int cat = decode_symbol(S.dc[td], bits, len);
-            if (cat < 0 || cat > 16) bad = true;
-            if (bad) {
-                if (EMIT) return false;
-                c.skip(1); b = b + 1 == (unsigned)S.bpm ? 0 : b + 1; ++nblocks;
-                continue;
-            }
-            if (EMIT && gidx + nblocks < S.total_blocks) {
-                const int diff = cat ? extend((int)((bits << len) >> (32 - cat)), cat) : 0;
-                out[(gidx + nblocks) * 64] = (int16_t)diff;            // made absolute by the DC pass
-            }
-            c.skip((unsigned)(len + cat));
-            k = 1;
+        const int sym = decode_symbol(tabs[td + (is_dc ? 0 : 3)], bits, len);
+        const unsigned run = is_dc ? 0u : (unsigned)sym >> 4, s = is_dc ? (unsigned)sym : (unsigned)sym & 15u;
+        const bool eob = !is_dc && sym == 0;
+        if (sym < 0 || (is_dc ? sym > 16 : (!eob && run + k > 63))) {
+            if (EMIT) return false;
+            c.skip(1);
+            k = 64;
         } else {
-            const int rs = decode_symbol(S.ac[td], bits, len);
-            if (rs < 0 || (rs != 0 && ((unsigned)rs >> 4) + k > 63)) {
-                if (EMIT) return false;
-                c.skip(1); k = 0; b = b + 1 == (unsigned)S.bpm ? 0 : b + 1; ++nblocks;
-                continue;
-            }
-            if (rs == 0) {                                             // EOB
-                c.skip((unsigned)len);
-                k = 64;
-            } else {
-                const unsigned run = (unsigned)rs >> 4, s = (unsigned)rs & 15u;
-                k += run;
-                if (EMIT && s && gidx + nblocks < S.total_blocks)
-                    out[(gidx + nblocks) * 64 + k] = (int16_t)extend((int)((bits << len) >> (32 - s)), (int)s);
-                ++k;
-                c.skip((unsigned)len + s);
-            }
-            if (k >= 64) {
-                k = 0;
-                b = b + 1 == (unsigned)S.bpm ? 0 : b + 1;
-                ++nblocks;
-            }
+            const unsigned kk = k + run;
+            if (EMIT && s && gidx + nblocks < S.total_blocks)              // DC: the difference, made absolute by the DC pass
+                out[(gidx + nblocks) * 64 + kk] = (int16_t)extend((int)((bits << len) >> (32 - s)), (int)s);
+            c.skip((unsigned)len + s);
+            k = eob ? 64u : kk + 1;
+        }
+        if (k >= 64) {
+            k = 0;
+            b = b + 1 == (unsigned)S.bpm ? 0 : b + 1;
+            td = S.btd[b];
+            ++nblocks;
         }
     }
     return true;

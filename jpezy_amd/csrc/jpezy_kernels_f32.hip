@@ -350,7 +350,10 @@ __global__ __launch_bounds__(64 * WPB, JPEZY_F32_WAVES) void fdct_quant_f32_kern
     // One quad per wave, one launch of exactly as many waves as quads.  Measured alternatives: a grid-stride loop over a
     // grid sized to the resident workgroups -- same 4096^2 time (the kernel's tail comes from XCD-to-XCD variation, which
     // a static partition cannot balance either) and 8 more VGPRs; resident waves drawing quads from one device-scope
-    // atomic counter -- 240 us instead of 30: 21 k draws on one address serialise at ~10 ns each.
+    // atomic counter -- 240 us instead of 30: 21 k draws on one address serialise at ~10 ns each; 4 resident waves per
+    // SIMD, 4 quads each, the next quad's pixels prefetched during the current one (109 VGPRs) -- 34.7 us: waves started
+    // together stay in the same phase of the quad (all in the LDS transposes, then all in the butterflies), whereas waves
+    // of one-quad launches arrive staggered and overlap each other's latency-bound phases.
     const unsigned qidx = blockIdx.x * (unsigned)WPB + (unsigned)wave;          // quad index inside the frame
     if (qidx >= (unsigned)(p.mcu_rows * p.quads_per_row)) return;     // wave-uniform
     const int frame = (int)blockIdx.y;

@@ -83,6 +83,19 @@ def main():
     # per-XCC end time
     for x in range(8):
         print(f"  XCC {x}: last wave ends {end[xcc == x].max() * tick / 1e3:6.2f} us, first start {t0[xcc == x].min() * tick / 1e3:5.2f}, mean lifetime {d_end[xcc == x].mean() * tick / 1e3:5.2f}")
+    # is the workgroup -> CU binding static?  per CU: when it finishes, and which workgroups it ran
+    invc = np.searchsorted(uc, cukey)
+    lastc = np.zeros(len(uc), dtype=np.int64); np.maximum.at(lastc, invc, end)
+    print("per-CU last end us percentiles:", {q: round(float(np.percentile(lastc, q)) * tick / 1e3, 2) for q in (0, 10, 50, 90, 100)})
+    sekey = xcc * 10 + se
+    for k in np.unique(sekey):
+        sel = sekey == k
+        print(f"  XCC {k // 10} SE {k % 10}: CUs {len(np.unique(cukey[sel]))} waves {sel.sum()} last end {end[sel].max() * tick / 1e3:6.2f} mean lifetime {d_end[sel].mean() * tick / 1e3:5.2f}")
+    wg = np.arange(n) // 2
+    for c in (uc[0], uc[1], uc[len(uc) // 2], uc[np.argmax(lastc)], uc[np.argmin(lastc)]):
+        sel = cukey == c
+        ids = np.unique(wg[sel])
+        print(f"  CU {c}: last end {lastc[np.searchsorted(uc, c)] * tick / 1e3:6.2f} us; workgroups ran (id // 8):", (ids // 8).tolist()[:40], "xcc of ids", np.unique(ids % 8).tolist())
 
 
 if __name__ == "__main__":

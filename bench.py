@@ -85,6 +85,10 @@ def main():
     ap.add_argument("--variant", type=int, default=None, help="encode kernel variant (0 FP64 butterflies, 1 FP32 first level)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-gather", action="store_true", help="skip the separate RCCL gather measurement (N>1)")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="frames in flight: step i is launched on stream i %% S (forked from and joined to the timed stream "
+                         "inside the captured graph; every step has its own ring buffers).  Default 1: launches back to back; "
+                         "with 2 the ramp and drain of consecutive launches overlap (pipeline-level number, see DESIGN.md)")
     ap.add_argument("--no-graph", action="store_true",
                     help="launch the timed steps one by one instead of replaying them as one captured hipGraph "
                          "(the graph saves ~1.5 us of launch gap per 30 us step; same kernels, same work)")
@@ -177,8 +181,18 @@ def main():
         with torch.cuda.stream(cap_stream):
             stream_saved, stream = stream, cap_stream
             with torch.cuda.graph(graph, stream=cap_stream):
-                for i in range(args.steps):
-                    step(i)
+                if args.streams > 1:
+                    side = [torch.cuda.Stream(dev) for _ in range(args.streams)]
+                    for sd in side:
+                        sd.wait_stream(cap_stream)                  # fork
+                    for i in range(args.steps):
+                        stream = side[i % args.streams]
+                        step(i)
+                    for sd in side:
+                        cap_stream.wait_stream(sd)                  # join
+                else:
+                    for i in range(args.steps):
+                        step(i)
             stream = stream_saved
         torch.cuda.synchronize(dev)
         graph.replay()
@@ -222,6 +236,39 @@ def main():
         torch.cuda.synchronize(dev)
         copy_gbs = 2 * half * reps / (c0.elapsed_time(c1) * 1e-3) / 1e9
         del src_bufs, dst_bufs
+
+    # Pipeline-level number, reported beside `value` and never part of it: the same K steps with two frames in flight
+    # (two streams inside one graph; every step has its own ring buffers).  The ramp and drain of consecutive launches
+    # overlap, which a single in-order stream cannot do.
+    pipelined = None
+    if rank == 0 and graph is not None and args.streams == 1 and ring >= 2:
+        g2 = torch.cuda.CUDAGraph()
+        cap_stream = torch.cuda.Stream(dev)
+        cap_stream.wait_stream(stream)
+        with torch.cuda.stream(cap_stream):
+            stream_saved = stream
+            with torch.cuda.graph(g2, stream=cap_stream):
+                side = [torch.cuda.Stream(dev) for _ in range(2)]
+                for sd in side:
+                    sd.wait_stream(cap_stream)
+                for i in range(args.steps):
+                    stream = side[i % 2]
+                    step(i)
+                for sd in side:
+                    cap_stream.wait_stream(sd)
+            stream = stream_saved
+        torch.cuda.synchronize(dev)
+        g2.replay()
+        torch.cuda.synchronize(dev)
+        p0 = time.perf_counter()
+        g2.replay()
+        torch.cuda.synchronize(dev)
+        pdt = time.perf_counter() - p0
+        ctx.fallback_count()
+        pipelined = {"frames_in_flight": 2, "ms_per_step": round(pdt * 1e3 / args.steps, 5),
+                     "value": round(plane * fps * args.steps / pdt / 1e6, 2), "unit": "Mpixels/s",
+                     "note": "this rank only; measured after the timed region; not part of value"}
+        del g2
 
     gather = None
     if multi and not args.no_gather:
@@ -278,7 +325,8 @@ def main():
             "config": {"workload": desc, "name": args.workload, "width": W, "height": H, "mode": "gray" if gray else "color",
                        "frames_per_step": fps, "ring_batches": ring, "pixels_per_step_per_gpu": px_per_step,
                        "inputs": "iid uniform u8 r,g,b planes resident in HBM", "parallelism": f"frames x{world}",
-                       "submission": "one launch per step" + ("" if args.no_graph else ", the K steps captured once and replayed as a hipGraph")},
+                       "submission": "one launch per step" + ("" if args.no_graph else ", the K steps captured once and replayed as a hipGraph")
+                                     + ("" if args.streams <= 1 else f", {args.streams} steps in flight on {args.streams} streams")},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "kernel": ("f32::fdct_quant_f32_kernel" if args.variant in (None, 1) else "fdct_quant_kernel")
@@ -287,6 +335,8 @@ def main():
                          "device_copy_GBs_measured": round(copy_gbs, 1), "frac_of_device_copy": round(achieved / copy_gbs, 4)},
             "exact_fallbacks_per_step": round(nfallback / max(1, args.steps), 2),
         }
+        if pipelined:
+            out["pipelined"] = pipelined
         if gather:
             out["gather"] = gather
         if world == 1 and not args.no_cpu:

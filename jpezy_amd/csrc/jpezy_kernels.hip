@@ -527,11 +527,15 @@ __device__ __forceinline__ int ld_coef(const int16_t* p)
     return v;
 }
 
+// waves per SIMD the register budget is set for: colour 4 (106 VGPRs; at 5 = 96 VGPRs the kernel spills), gray 5
 #ifndef JPEZY_DEC_WAVES
-#define JPEZY_DEC_WAVES 5
+#define JPEZY_DEC_WAVES 4
+#endif
+#ifndef JPEZY_DEC_WAVES_GRAY
+#define JPEZY_DEC_WAVES_GRAY 5
 #endif
 template <bool GRAY, bool ALIGNED, bool FORCE_EXACT>
-__global__ __launch_bounds__(64 * WPB, JPEZY_DEC_WAVES) void dequant_idct_kernel(DecParams p)
+__global__ __launch_bounds__(64 * WPB, GRAY ? JPEZY_DEC_WAVES_GRAY : JPEZY_DEC_WAVES) void dequant_idct_kernel(DecParams p)
 {
     __shared__ __attribute__((aligned(16))) uint32_t lds_all[WPB][DEC_LDS_DWORDS];
     constexpr int BPM = 6;
@@ -679,27 +683,34 @@ __global__ __launch_bounds__(64 * WPB, JPEZY_DEC_WAVES) void dequant_idct_kernel
             for (int y = 0; y < 8; ++y) *reinterpret_cast<double*>(dst + y * C_PITCH) = gc[y];
         }
         wave_sync();
-        double in[16], out[16];
-        const double2* scb = reinterpret_cast<const double2*>(lds + m * C_MCU + (row >> 1) * C_PITCH);
-        const double2* scr = reinterpret_cast<const double2*>(lds + m * C_MCU + C_COMP + (row >> 1) * C_PITCH);
+        // A chroma row serves two pixel rows, i.e. two lanes (l and l ^ 4).  The even-row lane runs the row pass of the Cb
+        // row, the odd-row lane that of the Cr row, and they swap the eight samples and the guard bits (DPP row_shr/shl:4)
+        // -- instead of both lanes computing both rows.
+        const bool odd = (row & 1) != 0;
+        double in[8], out[8];
+        const double2* src = reinterpret_cast<const double2*>(lds + m * C_MCU + (odd ? C_COMP : 0) + (row >> 1) * C_PITCH);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const double2 a = scb[k], b = scr[k];
+            const double2 a = src[k];
             in[2 * k] = a.x; in[2 * k + 1] = a.y;
-            in[8 + 2 * k] = b.x; in[8 + 2 * k + 1] = b.y;
         }
         in[0] += 128.0;
-        in[8] += 128.0;
         idct8(in, out);
-        idct8(in + 8, out + 8);
         {
             float e[8];
+            int mine[8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) Cb[k] = sample_of(out[k], e[k]);
-            cflags = guard_bits8(e, dc_only_cb);
+            for (int k = 0; k < 8; ++k) mine[k] = sample_of(out[k], e[k]);
+            const unsigned myf = guard_bits8(e, odd ? dc_only_cr : dc_only_cb);
+            // DPP inside each 16-lane row: banks 0,2 hold even pixel rows (Cb), banks 1,3 odd ones (Cr)
 #pragma unroll
-            for (int k = 0; k < 8; ++k) Cr[k] = sample_of(out[8 + k], e[k]);
-            cflags |= guard_bits8(e, dc_only_cr) << 8;
+            for (int k = 0; k < 8; ++k) {
+                Cb[k] = __builtin_amdgcn_update_dpp(mine[k], mine[k], 0x114, 0xF, 0xA, false);   // odd lanes take lane - 4's
+                Cr[k] = __builtin_amdgcn_update_dpp(mine[k], mine[k], 0x104, 0xF, 0x5, false);   // even lanes take lane + 4's
+            }
+            const unsigned fcb = (unsigned)__builtin_amdgcn_update_dpp((int)myf, (int)myf, 0x114, 0xF, 0xA, false);
+            const unsigned fcr = (unsigned)__builtin_amdgcn_update_dpp((int)myf, (int)myf, 0x104, 0xF, 0x5, false);
+            cflags = fcb | (fcr << 8);
         }
         if (force) cflags = 0xFFFFu;
     }

@@ -89,6 +89,10 @@ def main():
                     help="frames in flight: step i is launched on stream i %% S (forked from and joined to the timed stream "
                          "inside the captured graph; every step has its own ring buffers).  Default 1: launches back to back; "
                          "with 2 the ramp and drain of consecutive launches overlap (pipeline-level number, see DESIGN.md)")
+    ap.add_argument("--pipelined", action="store_true",
+                    help="after the timed region, replay the same K steps with two frames in flight and report the result as "
+                         "a 'pipelined' object beside value (off by default: the default command launches nothing but the "
+                         "timed kernel, so that a rocprofv3 trace of it averages exactly the launches value is made of)")
     ap.add_argument("--no-graph", action="store_true",
                     help="launch the timed steps one by one instead of replaying them as one captured hipGraph "
                          "(the graph saves ~1.5 us of launch gap per 30 us step; same kernels, same work)")
@@ -241,7 +245,7 @@ def main():
     # (two streams inside one graph; every step has its own ring buffers).  The ramp and drain of consecutive launches
     # overlap, which a single in-order stream cannot do.
     pipelined = None
-    if rank == 0 and graph is not None and args.streams == 1 and ring >= 2:
+    if args.pipelined and rank == 0 and graph is not None and args.streams == 1 and ring >= 2:
         g2 = torch.cuda.CUDAGraph()
         cap_stream = torch.cuda.Stream(dev)
         cap_stream.wait_stream(stream)

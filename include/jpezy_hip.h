@@ -206,6 +206,18 @@ int jpezy_read_jpeg_gpu(jpezy_ctx* ctx, const uint8_t* data, size_t len, jpezy_f
  */
 int jpezy_decode_jpeg(jpezy_ctx* ctx, const uint8_t* data, size_t len, int gray, jpezy_frame_info* info, uint8_t* r,
                       uint8_t* g, uint8_t* b, size_t plane_cap);
+/*
+ * jpezy_decode_jpeg for n files at once (n decoder objects of the reference, decoder/jpezy_decoder.hpp:39-134, one per
+ * file): files are decoded concurrently, up to 8 in flight on the context's device -- a single file's pipeline is
+ * latency-bound, so a batch of 1080p files takes about a fifth of the time of n single calls.  data[i] / len[i]: file i;
+ * r[i], g[i], b[i]: its planes (plane_cap[i] >= width*height bytes each; sizes come from a header-only jpezy_decode_jpeg or
+ * jpezy_read_jpeg call); info[i] and status[i] (JPEZY_OK or that file's negative error code) are written per file.
+ * Returns JPEZY_OK when every file decoded, else the first failing file's code (message: which file and why); the other
+ * files' outputs are complete either way.
+ */
+int jpezy_decode_jpeg_batch(jpezy_ctx* ctx, int n, const uint8_t* const* data, const size_t* len, int gray,
+                            jpezy_frame_info* info, uint8_t* const* r, uint8_t* const* g, uint8_t* const* b,
+                            const size_t* plane_cap, int* status);
 /* Synchronisation passes the last jpezy_read_jpeg_gpu call needed; 0 = the host decoder was used (test/diagnostic hook). */
 int jpezy_ctx_last_huffdec_passes(jpezy_ctx* ctx);
 /* Scans shorter than n bytes are decoded on the host (default 256 KiB: the GPU decoder has ~3 ms of fixed cost); 0

@@ -67,6 +67,7 @@ ABI = [
     ("jpezy_read_jpeg", C.c_int, [_vp, C.c_size_t, C.POINTER(FrameInfo), _vp, C.c_size_t]),
     ("jpezy_read_jpeg_gpu", C.c_int, [_vp, _vp, C.c_size_t, C.POINTER(FrameInfo), _vp, C.c_size_t]),
     ("jpezy_decode_jpeg", C.c_int, [_vp, _vp, C.c_size_t, C.c_int, C.POINTER(FrameInfo), _vp, _vp, _vp, C.c_size_t]),
+    ("jpezy_decode_jpeg_batch", C.c_int, [_vp, C.c_int, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp]),
     ("jpezy_ctx_last_huffdec_passes", C.c_int, [_vp]),
     ("jpezy_ctx_set_huffdec_min_bytes", None, [_vp, C.c_size_t]),
 ]
@@ -257,6 +258,37 @@ class Context:
         r, g, b = (np.empty(n, dtype=np.uint8) for _ in range(3))
         _check(lib.jpezy_decode_jpeg(self._h, _np_ptr(arr), arr.size, int(gray), C.byref(info), _np_ptr(r), _np_ptr(g), _np_ptr(b), n))
         return info, r, g, b
+
+    def decode_jpeg_batch(self, files, gray=False, raise_on_error=True):
+        """list of .jpg byte strings -> list of (FrameInfo, r, g, b) (None for a file that failed when raise_on_error is
+        False); the files are decoded concurrently on this context's device (jpezy_decode_jpeg_batch)."""
+        lib = load_library()
+        n = len(files)
+        arrs = [np.frombuffer(bytes(f), dtype=np.uint8) for f in files]
+        infos = (FrameInfo * n)()
+        sizes = []
+        for i, a in enumerate(arrs):          # header pass on the host: plane sizes
+            rc = lib.jpezy_decode_jpeg(self._h, _np_ptr(a), a.size, int(gray), C.byref(infos[i]), None, None, None, 0)
+            sizes.append(infos[i].width * infos[i].height if rc == 0 else 0)
+        planes = [[np.empty(max(sz, 1), dtype=np.uint8) for _ in range(3)] for sz in sizes]
+        vpa = C.c_void_p * n
+        data = vpa(*[a.ctypes.data for a in arrs])
+        lens = (C.c_size_t * n)(*[a.size for a in arrs])
+        rr, gg, bb = (vpa(*[p[k].ctypes.data for p in planes]) for k in range(3))
+        caps = (C.c_size_t * n)(*sizes)
+        status = (C.c_int * n)()
+        rc = lib.jpezy_decode_jpeg_batch(self._h, n, data, lens, int(gray), infos, rr, gg, bb, caps, status)
+        if rc != 0 and raise_on_error:
+            _check(rc)
+        out = []
+        for i in range(n):
+            if status[i] != 0:
+                out.append(None)
+                continue
+            fi = FrameInfo()
+            C.memmove(C.byref(fi), C.byref(infos[i]), C.sizeof(FrameInfo))
+            out.append((fi, planes[i][0][: sizes[i]], planes[i][1][: sizes[i]], planes[i][2][: sizes[i]]))
+        return out
 
     def set_huffdec_min_bytes(self, n):
         load_library().jpezy_ctx_set_huffdec_min_bytes(self._h, n)

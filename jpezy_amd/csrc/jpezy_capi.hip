@@ -94,6 +94,7 @@ struct jpezy_ctx {
     int h_last_passes = 0;         // synchronisation passes of the last jpezy_read_jpeg_gpu (0: the host decoder was used)
     size_t h_min_bytes = 256 << 10;   // scans shorter than this are decoded on the host (the GPU path has ~3 ms of fixed cost)
     DevBuf e_hdr;                  // JFIF header bytes of the device-resident variant (cached per W, H, comment)
+    std::vector<jpezy_ctx*> workers;   // jpezy_decode_jpeg_batch: one child context (stream, buffers, tables) per file in flight
     uint8_t e_hdr_host[1024];
     size_t e_hdr_len = 0;
 };
@@ -208,6 +209,8 @@ jpezy_ctx* jpezy_ctx_create(int device)
 void jpezy_ctx_destroy(jpezy_ctx* c)
 {
     if (!c) return;
+    for (jpezy_ctx* w : c->workers) jpezy_ctx_destroy(w);
+    c->workers.clear();
     (void)hipSetDevice(c->device);
     if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
     if (c->d_tab) (void)hipFree(c->d_tab);
@@ -1030,6 +1033,41 @@ int jpezy_decode_jpeg(jpezy_ctx* c, const uint8_t* data, size_t len, int gray, j
     uint8_t* dst[3] = { r, g, b };
     for (int k = 0; k < 3; ++k) HIP_TRY(hipMemcpyAsync(dst[k], c->in[k].p, plane, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    return JPEZY_OK;
+}
+
+// Many files: the per-file pipeline is latency-bound (small launches, five host synchronisations), so files are decoded
+// concurrently -- up to 8 in flight, each on a child context of its own (stream, scratch, quantiser tables), one host
+// thread per child.  Files are independent (ref decoder objects are per file): status[i] is file i's own result.
+int jpezy_decode_jpeg_batch(jpezy_ctx* c, int n, const uint8_t* const* data, const size_t* len, int gray, jpezy_frame_info* info,
+                            uint8_t* const* r, uint8_t* const* g, uint8_t* const* b, const size_t* plane_cap, int* status)
+{
+    if (!c || n < 0 || (n > 0 && (!data || !len || !info || !r || !g || !b || !plane_cap || !status)))
+        return set_err(JPEZY_E_BADARG, "decode_jpeg_batch: bad argument");
+    if (n == 0) return JPEZY_OK;
+    unsigned hw = std::thread::hardware_concurrency();
+    if (hw == 0) hw = 4;
+    const int nw = (int)std::min<unsigned>(std::min<unsigned>((unsigned)n, hw), 8u);
+    while ((int)c->workers.size() < nw) {
+        jpezy_ctx* w = jpezy_ctx_create(c->device);
+        if (!w) return JPEZY_E_HIP;                                  // message set by jpezy_ctx_create
+        c->workers.push_back(w);
+    }
+    for (int k = 0; k < nw; ++k) c->workers[k]->h_min_bytes = c->h_min_bytes;
+    std::vector<std::string> msg((size_t)n);
+    auto work = [&](int k) {
+        jpezy_ctx* w = c->workers[(size_t)k];
+        for (int i = k; i < n; i += nw) {
+            status[i] = jpezy_decode_jpeg(w, data[i], len[i], gray, &info[i], r[i], g[i], b[i], plane_cap[i]);
+            if (status[i] < 0) msg[(size_t)i] = g_err;               // this thread's message
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int k = 1; k < nw; ++k) pool.emplace_back(work, k);
+    work(0);
+    for (auto& t : pool) t.join();
+    for (int i = 0; i < n; ++i)
+        if (status[i] < 0) return set_err(status[i], "decode_jpeg_batch: file " + std::to_string(i) + ": " + msg[(size_t)i]);
     return JPEZY_OK;
 }
 

@@ -172,6 +172,49 @@ def test_decode_jpeg_end_to_end(J, ctx, oracle):
         ctx.decode_jpeg(jpg[:500])
 
 
+def test_decode_jpeg_batch(J, ctx, oracle):
+    """jpezy_decode_jpeg_batch: a mixed bag of files (jpezy's own, libjpeg 4:4:4 / 4:2:2 / gray, synthesised odd layouts, one
+    truncated file) decoded concurrently; every file equals the oracle's decoder, the bad one reports its own error and does
+    not disturb the others."""
+    from PIL import Image
+    from test_host_codec import ODD_LAYOUTS
+    from jpeg_synth import synth_jpeg
+    rng = np.random.default_rng(11)
+    files = []
+    for k in range(5):
+        W, H = int(rng.integers(40, 400)), int(rng.integers(40, 300))
+        r, g, b = oracle.synth_rgb(W, H, frame=100 + k)
+        files.append(ctx.encode_jpeg(r, g, b, W, H, gray=bool(k & 1)))
+    for kw in (dict(subsampling=0, quality=90), dict(subsampling=1, quality=60), dict(subsampling=2, quality=35, optimize=True)):
+        img = rng.integers(0, 256, (150, 210, 3), dtype=np.uint8)
+        buf = io.BytesIO()
+        Image.fromarray(img).save(buf, "JPEG", **kw)
+        files.append(buf.getvalue())
+    buf = io.BytesIO()
+    Image.fromarray(rng.integers(0, 256, (99, 131), dtype=np.uint8)).save(buf, "JPEG", quality=80)
+    files.append(buf.getvalue())
+    for name in ("411", "h3_partial", "one_comp_2x2"):
+        files.append(synth_jpeg(200, 120, ODD_LAYOUTS[name], seed=7)[0])
+    bad = len(files)
+    files.append(files[0][: len(files[0]) // 2])
+    files += files[:4]                                   # more files than workers
+    for gray in (False, True):
+        got = ctx.decode_jpeg_batch(files, gray=gray, raise_on_error=False)
+        assert len(got) == len(files)
+        for i, f in enumerate(files):
+            if i == bad:
+                assert got[i] is None
+                continue
+            info, rr, gg, bb = got[i]
+            want = oracle.decode_jpeg(f, gray)
+            n = info.width * info.height
+            for a, e in zip((rr, gg, bb), want[-3:]):
+                assert np.array_equal(a, np.asarray(e).reshape(-1)[:n]), i
+    with pytest.raises(J.JpezyError, match=f"file {bad}"):
+        ctx.decode_jpeg_batch(files)
+    assert ctx.decode_jpeg_batch([]) == []
+
+
 def test_differential_fuzz_small(J, ctx):
     """a short run of tools/fuzz_huffdec.py: random sizes, contents, qualities, sampling factors, optimised tables"""
     import subprocess

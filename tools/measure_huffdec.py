@@ -38,6 +38,24 @@ def main():
             print(f"{W}x{H} {name}: jpezy_decode_jpeg (.jpg bytes on the host -> r,g,b planes on the host, Huffman + IDCT + colour on the GPU): {te * 1e3:.2f} ms")
             print(f"{W}x{H} {name}: {len(data) / 1e6:.2f} MB; GPU Huffman decode {tg * 1e3:.2f} ms ({ctx.last_huffdec_passes()} passes) = "
                   f"{W * H / tg / 1e6:.0f} Mpx/s; host {th * 1e3:.1f} ms = {W * H / th / 1e6:.0f} Mpx/s; identical: {ok}")
+    # a batch of different 1080p files: one call per file vs jpezy_decode_jpeg_batch (up to 8 files in flight)
+    W, H = 1920, 1080
+    files = []
+    for k in range(32):
+        rng = np.random.default_rng(100 + k)
+        r, g, b = (rng.integers(0, 256, W * H, dtype=np.uint8) for _ in range(3))
+        files.append(ctx.encode_jpeg(r, g, b, W, H))
+    ctx.set_huffdec_min_bytes(0)
+    ctx.decode_jpeg_batch(files[:8])
+    t = time.perf_counter()
+    single = [ctx.decode_jpeg(f) for f in files]
+    ts = time.perf_counter() - t
+    t = time.perf_counter()
+    batch = ctx.decode_jpeg_batch(files)
+    tb = time.perf_counter() - t
+    same = all(np.array_equal(a[1], b_[1]) and np.array_equal(a[3], b_[3]) for a, b_ in zip(single, batch))
+    print(f"32 x 1920x1080 random pixels ({len(files[0]) / 1e6:.2f} MB each), .jpg on the host -> planes on the host: one call per file "
+          f"{ts * 1e3 / 32:.2f} ms/file, jpezy_decode_jpeg_batch {tb * 1e3 / 32:.2f} ms/file ({W * H * 32 / tb / 1e6:.0f} Mpx/s); identical: {same}")
 
 
 if __name__ == "__main__":

@@ -1,6 +1,6 @@
 """CPU tests of the oracle (oracle/jpezy_oracle.c): constants, the hazards SURVEY.md names, the committed
 fixtures, and independent cross-checks (libjpeg via PIL, /usr/bin/file).  PARITY UNPINNED: the reference
-has no vectors, so "golden" here means frozen oracle outputs (tools/gen_golden.py)."""
+has no vectors, so "golden" here means frozen oracle outputs (tests/golden/gen_golden.py)."""
 import ctypes as C
 import hashlib
 import io

@@ -9,7 +9,6 @@ import torch
 
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 import jpezy_amd as J  # noqa: E402
-from oracle import oracle as O  # noqa: E402
 
 
 def main():

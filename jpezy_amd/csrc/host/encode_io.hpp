@@ -158,8 +158,10 @@ private:
     {
         pnm.report_error(__func__);
         os << "P3\n" << pnm.width << " " << pnm.height << "\n" << pnm.max_color << "\n";
-        for (const auto& px : pnm.rgb_img)
-            os << std::to_integer<unsigned>(px[0]) << " " << std::to_integer<unsigned>(px[1]) << " " << std::to_integer<unsigned>(px[2]) << '\n';
+        write_p3_pixels(os, pnm.rgb_img.size(), [&pnm](std::size_t i) {
+            const auto& px = pnm.rgb_img[i];
+            return std::array<unsigned, 3>{ std::to_integer<unsigned>(px[0]), std::to_integer<unsigned>(px[1]), std::to_integer<unsigned>(px[2]) };
+        });
         return os;
     }
 

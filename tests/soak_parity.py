@@ -1,0 +1,140 @@
+#!/usr/bin/env python3
+"""Soak test (run by hand on the GPU box, not collected by pytest):
+
+    python tests/soak_parity.py [seconds] [workers]
+
+For `seconds` of wall time: random frames of many kinds of content and sizes go through the HIP encode and decode
+kernels (C-ABI, device-pointer entry points) and through the CPU oracle (worker processes); every coefficient and every
+decoded byte must be identical.  The point is statistics: the fast paths reproduce a truncating FP64 reference through
+guard bands and exact fallbacks, so a wrong bound would show up as a rare mismatch -- this runs
+10^10..10^11 samples.  Prints one summary line; exit code 1 on any mismatch (the failing case is saved under
+gpurun_out/soak_fail_*.npz).
+"""
+import os
+import sys
+import time
+from concurrent.futures import ProcessPoolExecutor
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+
+
+def make_frame(kind, W, H, rng):
+    n = W * H
+    if kind == "uniform":
+        return [rng.integers(0, 256, n, dtype=np.uint8) for _ in range(3)]
+    if kind == "lownoise":                       # small noise around a random level: samples crowd the truncation boundaries
+        base = rng.integers(0, 256, 3)
+        amp = int(rng.integers(1, 6))
+        return [np.clip(base[c] + rng.integers(-amp, amp + 1, n), 0, 255).astype(np.uint8) for c in range(3)]
+    if kind == "gradient":
+        yy, xx = np.mgrid[0:H, 0:W]
+        a, b, c = rng.integers(1, 9, 3)
+        return [((xx * a + yy * b) // c % 256).astype(np.uint8).reshape(-1), ((xx * b + yy * c) // a % 256).astype(np.uint8).reshape(-1),
+                ((xx * c + yy * a) // b % 256).astype(np.uint8).reshape(-1)]
+    if kind == "flatblocks":                     # flat 8x8 / 16x16 patches: DC-only blocks, exact-integer samples
+        s = int(rng.choice([8, 16, 32]))
+        out = []
+        for _ in range(3):
+            small = rng.integers(0, 256, ((H + s - 1) // s, (W + s - 1) // s), dtype=np.uint8)
+            out.append(np.repeat(np.repeat(small, s, axis=0), s, axis=1)[:H, :W].reshape(-1).copy())
+        return out
+    if kind == "binary":                         # saturated 0 / 255 noise: the largest coefficients
+        return [(rng.integers(0, 2, n, dtype=np.uint8) * 255) for _ in range(3)]
+    if kind == "grey":                           # r = g = b
+        g = rng.integers(0, 256, n, dtype=np.uint8)
+        return [g, g.copy(), g.copy()]
+    if kind == "mult8":                          # values on a coarse grid: products and sums land on round numbers
+        return [(rng.integers(0, 32, n, dtype=np.uint8) * 8) for _ in range(3)]
+    if kind == "checker":
+        yy, xx = np.mgrid[0:H, 0:W]
+        p = int(rng.integers(1, 5))
+        m = (((xx // p) + (yy // p)) & 1).astype(np.uint8).reshape(-1)
+        lo, hi = sorted(int(v) for v in rng.integers(0, 256, 2))
+        return [(lo + m * (hi - lo)).astype(np.uint8), (hi - m * (hi - lo)).astype(np.uint8), (lo + m * (hi - lo)).astype(np.uint8)]
+    raise ValueError(kind)
+
+
+KINDS = ["uniform", "lownoise", "gradient", "flatblocks", "binary", "grey", "mult8", "checker"]
+SIZES = [(4096, 4096), (1920, 1080), (1237, 911), (640, 480), (4096, 2160), (333, 2047)]
+
+
+def oracle_job(args):
+    kind, W, H, seed, gray = args
+    from oracle import oracle as O
+    rng = np.random.default_rng(seed)
+    r, g, b = make_frame(kind, W, H, rng)
+    co = O.encode_coeffs(r, g, b, W, H, gray=gray)
+    info = O.make_info(W, H, gray_layout=False)
+    co6 = co if not gray else O.encode_coeffs(r, g, b, W, H, gray=False)
+    planes = O.decode_planes(co6, info, gray)
+    return np.asarray(co).reshape(-1), [np.asarray(p).reshape(-1)[: W * H] for p in planes]
+
+
+def main():
+    seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+    workers = int(sys.argv[2]) if len(sys.argv) > 2 else max(1, (os.cpu_count() or 4) - 2)
+    rng = np.random.default_rng(int(time.time()))
+    t_end = time.time() + seconds
+    done = px = bad = 0
+    last = time.time()
+    # the oracle workers are forked BEFORE this process touches the GPU (the first 2 * workers submissions start them all)
+    with ProcessPoolExecutor(workers) as pool:
+        pending = []
+        case = 0
+
+        def submit():
+            nonlocal case
+            kind = KINDS[case % len(KINDS)]
+            W, H = SIZES[int(rng.integers(0, len(SIZES)))]
+            if rng.random() < 0.3:
+                W, H = int(rng.integers(1, 700)), int(rng.integers(1, 700))
+            args = (kind, W, H, int(rng.integers(0, 2**31)), bool(rng.integers(0, 2)))
+            pending.append((args, pool.submit(oracle_job, args)))
+            case += 1
+
+        for _ in range(workers * 2):
+            submit()
+        import torch
+        import jpezy_amd as J
+        ctx = J.Context(0)
+        dev = torch.device("cuda:0")
+        while pending:
+            args, fut = pending.pop(0)
+            kind, W, H, seed, gray = args
+            want_co, want_planes = fut.result()
+            if time.time() < t_end:
+                submit()
+            r, g, b = make_frame(kind, W, H, np.random.default_rng(seed))
+            d = [torch.from_numpy(p).to(dev) for p in (r, g, b)]
+            co = torch.empty(J.coeff_count(W, H, gray), dtype=torch.int16, device=dev)
+            ctx.fdct_quant_dev(d[0], d[1], d[2], W, H, co, gray=gray)
+            co6 = co
+            if gray:
+                co6 = torch.empty(J.coeff_count(W, H, False), dtype=torch.int16, device=dev)
+                ctx.fdct_quant_dev(d[0], d[1], d[2], W, H, co6, gray=False)
+            out = [torch.empty(W * H, dtype=torch.uint8, device=dev) for _ in range(3)]
+            ctx.dequant_idct_dev(co6, W, H, out[0], out[1], out[2], gray=gray)
+            torch.cuda.synchronize()
+            ok = np.array_equal(co.cpu().numpy(), want_co) and all(np.array_equal(o.cpu().numpy(), w) for o, w in zip(out, want_planes))
+            done += 1
+            px += W * H
+            if not ok:
+                bad += 1
+                outdir = ROOT / "gpurun_out"
+                outdir.mkdir(exist_ok=True)
+                np.savez_compressed(outdir / f"soak_fail_{done}.npz", kind=kind, W=W, H=H, seed=seed, gray=gray)
+                print(f"MISMATCH: kind={kind} {W}x{H} seed={seed} gray={gray}", flush=True)
+            if time.time() - last > 30:
+                last = time.time()
+                print(f"... {done} frames, {px / 1e9:.2f} Gpx, {bad} mismatches", flush=True)
+    print(f"soak: {done} frames, {px / 1e9:.2f} Gpx encoded and decoded on the GPU and by the oracle ({workers} worker processes), "
+          f"{bad} mismatches, exact-path samples on the GPU: {ctx.fallback_count()}", flush=True)
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

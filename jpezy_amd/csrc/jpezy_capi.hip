@@ -779,6 +779,7 @@ bool build_dev_table(jpezy_dev::huffdec::Table& t, const uint8_t bits[16], const
     for (int l = 1; l <= 16; ++l) {
         t.off[l] = p - (int)code;
         for (int c = 0; c < bits[l - 1]; ++c, ++p, ++code) {
+            if (code >= (1u << l)) return false;                     // more codes of this length than the code space has left
             if (l <= 9) {
                 const unsigned lo = code << (9 - l);
                 for (unsigned f = 0; f < (1u << (9 - l)); ++f) t.look[lo + f] = (uint16_t)((l << 8) | vals[p]);

@@ -249,7 +249,18 @@ struct DecTable {
     int32_t valptr[17];
     int32_t mincode[17];
     uint8_t look_len[256]; // 8-bit first-level lookup: code length (0 = longer than 8)
+    bool prefix_code = true; // false: the counts over-subscribe the code space; no lookup, the bit-by-bit search decides
     uint8_t look_val[256];
+    // a table no DHT segment defined holds no codes: every symbol read from it fails, like the reference's empty
+    // huffman_table (decode_huffman_impl finds nothing and throws, :629-641)
+    DecTable()
+    {
+        std::memset(look_len, 0, sizeof look_len);
+        std::memset(look_val, 0, sizeof look_val);
+        std::memset(val, 0, sizeof val);
+        for (int l = 0; l < 18; ++l) maxcode[l] = -1;
+        for (int l = 0; l < 17; ++l) valptr[l] = mincode[l] = 0;
+    }
 };
 
 void build_dec(DecTable& t, const uint8_t bits[16], const uint8_t* vals, int n)
@@ -258,12 +269,14 @@ void build_dec(DecTable& t, const uint8_t bits[16], const uint8_t* vals, int n)
     std::memcpy(t.val, vals, (size_t)n);
     std::memset(t.look_len, 0, sizeof t.look_len);
     int code = 0, p = 0;
+    t.prefix_code = true;
     for (int l = 1; l <= 16; ++l) {
+        if (code + (int)bits[l - 1] > (1 << l)) t.prefix_code = false;
         if (bits[l - 1]) {
             t.valptr[l] = p;
             t.mincode[l] = code;
             for (int c = 0; c < bits[l - 1]; ++c, ++p, ++code) {
-                if (l <= 8) {
+                if (l <= 8 && code < (1 << l)) {       // an over-subscribed DHT yields codes no l-bit read can equal: not in the LUT
                     const int lo = code << (8 - l);
                     for (int f = 0; f < (1 << (8 - l)); ++f) {
                         t.look_len[lo + f] = (uint8_t)l;
@@ -280,6 +293,7 @@ void build_dec(DecTable& t, const uint8_t bits[16], const uint8_t* vals, int n)
         code <<= 1;
     }
     t.maxcode[17] = 0x7FFFFFFF;
+    if (!t.prefix_code) std::memset(t.look_len, 0, sizeof t.look_len);
 }
 
 struct Reader {
@@ -338,10 +352,12 @@ inline int decode_symbol(Reader& r, const DecTable& t)
         r.nacc -= l;
         return t.look_val[look];
     }
-    int code = r.get(8);
-    for (l = 9; l <= 16; ++l) {
+    int code = t.prefix_code ? r.get(8) : 0;
+    for (l = t.prefix_code ? 9 : 1; l <= 16; ++l) {
         code = (code << 1) | r.get(1);
-        if (code <= t.maxcode[l]) return t.val[t.valptr[l] + code - t.mincode[l]];
+        // the codes of length l are mincode..maxcode; both tests, so that a DHT whose counts do not describe a prefix code
+        // (over-subscribed, or with gaps) behaves like the reference's search for an equal (length, code) pair (:629-640)
+        if (code >= t.mincode[l] && code <= t.maxcode[l]) return t.val[t.valptr[l] + code - t.mincode[l]];
     }
     return -1;
 }

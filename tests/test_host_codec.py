@@ -199,3 +199,35 @@ def test_write_jpeg_batch_is_threaded_and_byte_identical(oracle):
     bad[3, 0, 0, 0, 5] = 2000          # outside K.5: that frame fails, the call reports it
     with pytest.raises(J.JpezyError):
         J.write_jpeg_batch(bad, W, H, F)
+
+
+def test_host_codec_under_asan_ubsan_on_mutated_files():
+    """tests/fuzz/run_host_fuzz.py: the marker parser, Huffman reader and writer built with AddressSanitizer + UBSan (g++, CPU)
+    and fed mutated files -- bit flips, truncations, insertions, header field edits.  Any out-of-bounds access fails the run.
+    (Found in round 1: an over-subscribed DHT overran the 8-bit lookup table; a scan that selects a table no DHT defined
+    read an uninitialised one.)"""
+    import subprocess
+    import sys
+    root = Path(__file__).resolve().parent.parent
+    r = subprocess.run([sys.executable, str(root / "tests" / "fuzz" / "run_host_fuzz.py"), "1500"], capture_output=True, text=True, timeout=900)
+    if "cannot find -lasan" in r.stderr or "libasan" in r.stderr and "No such file" in r.stderr:
+        pytest.skip("no libasan for g++ in this image")
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "decoded" in r.stdout
+
+
+def test_scan_that_selects_an_undefined_table_is_an_error(golden_dir):
+    """the reference's huffman_table of a slot no DHT filled is empty: decode_huffman_impl finds no code and throws
+    (decoder/jpezy_decoder.hpp:629-641)"""
+    z = np.load(sorted(golden_dir.glob("*.npz"))[0])
+    key = [k for k in z.files if k.startswith("jpg")][0]
+    d = bytearray(z[key].tobytes())
+    sos = d.index(b"\xFF\xDA")
+    assert d[sos + 4] == 3
+    d[sos + 6] = 0x22            # first scan component: Td = Ta = 2, never defined
+    with pytest.raises(api.JpezyError):
+        api.read_jpeg(bytes(d))
+    for _ in range(3):           # and stays an error whatever was decoded before (the table used to be uninitialised memory)
+        api.read_jpeg(z[key].tobytes())
+        with pytest.raises(api.JpezyError):
+            api.read_jpeg(bytes(d))

@@ -9,7 +9,9 @@ import numpy as np
 from PIL import Image, ImageFile
 
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent / "tests" / "fuzz"))
 import jpezy_amd as J  # noqa: E402
+from run_host_fuzz import mutate  # noqa: E402
 
 ImageFile.MAXBLOCK = 1 << 24
 
@@ -36,6 +38,8 @@ def content(rng, H, W, kind):
 
 def main():
     n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 150
+    n_mut = int(sys.argv[2]) if len(sys.argv) > 2 else 0      # damaged copies per case: GPU and host decoder must agree on them too
+    mut_ok = mut_err = 0
     ctx = J.Context(0)
     ctx.set_huffdec_min_bytes(0)
     rng = np.random.default_rng(2026)
@@ -65,7 +69,30 @@ def main():
             if not np.array_equal(got.cpu().numpy(), want):
                 print("MISMATCH", case, name, W, H, kw)
                 return 1
-    print(f"{gpu + host} files identical ({gpu} decoded by the GPU decoder, {host} handed to the host decoder)")
+        for m in range(n_mut):
+            # damaged files: same verdict and, when they decode, the same coefficients (the GPU decoder hands anything
+            # irregular to the host decoder; what it keeps must be what the host decoder would have produced)
+            data = mutate(files[m % len(files)][2], rng)
+            try:
+                _, want = J.read_jpeg(data)
+            except J.JpezyError:
+                want = None
+            try:
+                _, got = ctx.read_jpeg_gpu(data)
+                got = got.cpu().numpy()
+            except J.JpezyError:
+                got = None
+            if (want is None) != (got is None) or (want is not None and not np.array_equal(got, want)):
+                print("MUTANT MISMATCH", case, m, W, H, "host", "error" if want is None else "ok", "gpu", "error" if got is None else "ok")
+                Path("gpurun_out").mkdir(exist_ok=True)
+                Path(f"gpurun_out/mutant_{case}_{m}.jpg").write_bytes(data)
+                return 1
+            if want is None:
+                mut_err += 1
+            else:
+                mut_ok += 1
+    print(f"{gpu + host} files identical ({gpu} decoded by the GPU decoder, {host} handed to the host decoder)"
+          + (f"; {mut_ok + mut_err} damaged copies: {mut_ok} decode identically, {mut_err} rejected by both" if n_mut else ""))
     return 0
 
 

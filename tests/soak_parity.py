@@ -58,14 +58,51 @@ def make_frame(kind, W, H, rng):
     raise ValueError(kind)
 
 
-KINDS = ["uniform", "lownoise", "gradient", "flatblocks", "binary", "grey", "mult8", "checker"]
+KINDS = ["uniform", "lownoise", "gradient", "flatblocks", "binary", "grey", "mult8", "checker", "coeffs", "coeffs"]
 SIZES = [(4096, 4096), (1920, 1080), (1237, 911), (640, 480), (4096, 2160), (333, 2047)]
+
+
+def make_coeffs(W, H, rng):
+    """decode-only case: coefficients no encoder of ours produced, with random quantiser tables"""
+    mc, mr = (W + 15) // 16, (H + 15) // 16
+    shape = (mc * mr * 6, 64)
+    mode = int(rng.integers(0, 5))
+    if mode == 0:      # dense, small
+        co = rng.integers(-20, 21, shape, dtype=np.int16)
+    elif mode == 1:    # sparse, large
+        co = np.zeros(shape, np.int16)
+        m = rng.random(shape) < 0.06
+        co[m] = rng.integers(-2047, 2048, int(m.sum()), dtype=np.int16)
+    elif mode == 2:    # whole int16 range in a few blocks: the magnitude guard of the fast path
+        co = rng.integers(-60, 61, shape, dtype=np.int16)
+        rows = rng.integers(0, shape[0], max(1, shape[0] // 50))
+        co[rows] = rng.integers(-32768, 32768, (len(rows), 64), dtype=np.int16)
+    elif mode == 3:    # DC only
+        co = np.zeros(shape, np.int16)
+        co[:, 0] = rng.integers(-1024, 1024, shape[0], dtype=np.int16)
+    else:              # low frequencies only (what a real photograph looks like)
+        co = np.zeros(shape, np.int16)
+        co[:, :10] = rng.integers(-90, 91, (shape[0], 10), dtype=np.int16)
+    qmax = int(rng.choice([8, 40, 255, 2000]))
+    qt = rng.integers(1, qmax + 1, (3, 64))
+    tq = [int(v) for v in rng.integers(0, 3, 3)]
+    return co.reshape(-1), qt, tq
 
 
 def oracle_job(args):
     kind, W, H, seed, gray = args
     from oracle import oracle as O
     rng = np.random.default_rng(seed)
+    if kind == "coeffs":
+        co, qt, tq = make_coeffs(W, H, rng)
+        info = O.make_info(W, H, gray_layout=False)
+        for t in range(3):
+            for i in range(64):
+                info.qt[t][i] = int(qt[t][i])
+        for i in range(3):
+            info.Tq[i] = tq[i]
+        planes = O.decode_planes(co, info, gray)
+        return None, [np.asarray(p).reshape(-1)[: W * H] for p in planes]
     r, g, b = make_frame(kind, W, H, rng)
     co = O.encode_coeffs(r, g, b, W, H, gray=gray)
     info = O.make_info(W, H, gray_layout=False)
@@ -108,6 +145,22 @@ def main():
             want_co, want_planes = fut.result()
             if time.time() < t_end:
                 submit()
+            if kind == "coeffs":
+                co_h, qt, tq = make_coeffs(W, H, np.random.default_rng(seed))
+                qtab = type(J.api.annex_k_tables().qt)()
+                for t in range(3):
+                    for i in range(64):
+                        qtab[t][i] = int(qt[t][i])
+                out = [torch.empty(W * H, dtype=torch.uint8, device=dev) for _ in range(3)]
+                ctx.dequant_idct_dev(torch.from_numpy(co_h).to(dev), W, H, out[0], out[1], out[2], qt=qtab, comp_tq=tuple(tq), gray=gray)
+                torch.cuda.synchronize()
+                ok = all(np.array_equal(o.cpu().numpy(), w) for o, w in zip(out, want_planes))
+                done += 1
+                px += W * H
+                if not ok:
+                    bad += 1
+                    print(f"MISMATCH: kind={kind} {W}x{H} seed={seed} gray={gray}", flush=True)
+                continue
             r, g, b = make_frame(kind, W, H, np.random.default_rng(seed))
             d = [torch.from_numpy(p).to(dev) for p in (r, g, b)]
             co = torch.empty(J.coeff_count(W, H, gray), dtype=torch.int16, device=dev)

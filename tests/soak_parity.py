@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Soak test (run by hand on the GPU box, not collected by pytest):
 
-    python tests/soak_parity.py [seconds] [workers]
+    python tests/soak_parity.py [seconds] [workers] [seed]
 
 For `seconds` of wall time: random frames of many kinds of content and sizes go through the HIP encode and decode
 kernels (C-ABI, device-pointer entry points) and through the CPU oracle (worker processes); every coefficient and every
@@ -114,7 +114,7 @@ def oracle_job(args):
 def main():
     seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     workers = int(sys.argv[2]) if len(sys.argv) > 2 else max(1, (os.cpu_count() or 4) - 2)
-    rng = np.random.default_rng(int(time.time()))
+    rng = np.random.default_rng(int(sys.argv[3]) if len(sys.argv) > 3 else int(time.time()))
     t_end = time.time() + seconds
     done = px = bad = 0
     last = time.time()

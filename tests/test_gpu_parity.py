@@ -452,3 +452,16 @@ def test_out_of_range_dimensions_are_rejected(J, ctx):
     for W, H in ((0, 16), (16, 0), (65536, 1), (1, 65536), (-1, 4)):
         with pytest.raises(J.JpezyError):
             ctx.fdct_quant(z, z, z, W, H)
+
+
+def test_short_soak_against_the_oracle():
+    """tests/soak_parity.py for a few seconds in a process of its own (its oracle workers are forked before that process
+    touches the GPU): ~100 frames of eight kinds of content plus decode-only cases with random quantiser tables, all sizes,
+    every coefficient and decoded byte equal to the oracle's.  The long runs are in profiles/r01j_soak*.txt."""
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    r = subprocess.run([sys.executable, str(root / "tests" / "soak_parity.py"), "8", "6", "20261003"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert " 0 mismatches" in r.stdout

@@ -676,7 +676,8 @@ int jpezy_write_jpeg_gpu_dev(jpezy_ctx* c, const int16_t* d_coeffs, int W, int H
     const size_t chunk = E::chunk_bytes();
     // worst case per block: 64 x (16-bit code + 10 value bits) = 208 bytes
     const size_t u_stride = (nblk * 208 + 8 + chunk - 1) / chunk * chunk;
-    const int per = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_frames, ((size_t)1 << 30) / u_stride));
+    // frames per pass: worst-case streams below ~1 GiB, and at most 65535 (the frame index is a grid dimension)
+    const int per = (int)std::max<size_t>(1, std::min<size_t>(std::min<size_t>((size_t)n_frames, 65535), ((size_t)1 << 30) / u_stride));
     const size_t cpf = jpezy_coeff_count(W, H, gray);
     for (int f0 = 0; f0 < n_frames; f0 += per) {
         const int F = std::min(per, n_frames - f0);
@@ -699,10 +700,10 @@ int jpezy_write_jpeg_gpu_dev(jpezy_ctx* c, const int16_t* d_coeffs, int W, int H
         unsigned long long* d_bytes = (unsigned long long*)c->e_small.p + F;
         uint8_t* out = d_out + (size_t)f0 * out_stride;
         HIP_TRY(hipMemsetAsync(d_status, 0, sizeof(unsigned) * F, s));
-        HIP_TRY(hipMemsetAsync(c->e_U.p, 0, u_stride * F, s));
         HIP_TRY(E::launch_block_bits(job, (uint32_t*)c->e_bits.p, d_status, s));
         HIP_TRY(E::launch_scan_u32((const uint32_t*)c->e_bits.p, (unsigned long long*)c->e_off.p, N, (unsigned long long*)c->e_tmp.p, s));
         HIP_TRY(E::launch_frame_bytes((const unsigned long long*)c->e_off.p, nblk, F, d_bytes, s));
+        HIP_TRY(E::launch_zero_streams((uint32_t*)c->e_U.p, u_stride / 4, d_bytes, F, s));   // instead of a memset of the worst case
         HIP_TRY(E::launch_emit(job, (const unsigned long long*)c->e_off.p, (uint32_t*)c->e_U.p, u_stride / 4, s));
         HIP_TRY(E::launch_ff_count((const uint32_t*)c->e_U.p, u_stride / 4, d_bytes, F, (uint32_t*)c->e_cnt.p, s));
         HIP_TRY(E::launch_scan_u32((const uint32_t*)c->e_cnt.p, (unsigned long long*)c->e_ffoff.p, nchunks, (unsigned long long*)c->e_tmp.p, s));

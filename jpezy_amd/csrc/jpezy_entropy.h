@@ -38,6 +38,8 @@ hipError_t launch_stuff(const uint32_t* U, size_t u_stride_words, const unsigned
 
 // device-resident variant (no host sync): per-frame stream lengths, the fit/size/EOI decision, the header copy
 hipError_t launch_frame_bytes(const unsigned long long* off, size_t per, int n_frames, unsigned long long* bytes, hipStream_t s);
+// clears, per frame, the part of the unstuffed stream buffer the later kernels touch (bytes[f] rounded up to a chunk, plus one)
+hipError_t launch_zero_streams(uint32_t* U, size_t u_stride_words, const unsigned long long* bytes, int n_frames, hipStream_t s);
 hipError_t launch_plan_and_header(unsigned long long* bytes, const unsigned long long* ffoff, size_t chunks_per_frame, const unsigned* status,
                                   int n_frames, const uint8_t* hdr, size_t hdr_len, uint8_t* out, size_t out_stride, long long* sizes,
                                   hipStream_t s);

@@ -428,6 +428,18 @@ __global__ void frame_bytes_kernel(const unsigned long long* off, size_t per, in
     if (f < n_frames) bytes[f] = (off[(size_t)(f + 1) * per] - off[(size_t)f * per] + 7) / 8;
 }
 
+// U is sized for the worst case (208 bytes per block: 82 MB for a 4096x4096 frame, 5 MB of it used on noise, far less on
+// pictures); only what emit_kernel and the byte-stuffing kernels touch is cleared: the stream rounded up to a whole chunk,
+// plus one chunk.  4 KB per workgroup; the workgroups past the end leave at once.
+__global__ __launch_bounds__(256) void zero_streams_kernel(uint32_t* U, size_t u_stride_words, const unsigned long long* bytes)
+{
+    const size_t frame = blockIdx.y;
+    const unsigned long long need = (bytes[frame] + 2 * CHUNK - 1) / CHUNK * CHUNK;
+    const size_t off = ((size_t)blockIdx.x * 256 + threadIdx.x) * 16;
+    if (off >= need || off >= u_stride_words * 4) return;
+    *reinterpret_cast<uint4*>(reinterpret_cast<char*>(U + frame * u_stride_words) + off) = make_uint4(0, 0, 0, 0);
+}
+
 // one thread per frame, after the 0xFF scan: decide whether the frame fits, write its size and its EOI marker, and
 // disable the copy kernels for frames that failed (bytes[f] = 0)
 __global__ void plan_kernel(unsigned long long* bytes, const unsigned long long* ffoff, size_t chunks_per_frame, const unsigned* status,
@@ -456,6 +468,14 @@ __global__ void header_copy_kernel(const uint8_t* hdr, size_t hdr_len, const uns
 hipError_t launch_frame_bytes(const unsigned long long* off, size_t per, int n_frames, unsigned long long* bytes, hipStream_t s)
 {
     hipLaunchKernelGGL(frame_bytes_kernel, dim3((unsigned)((n_frames + 63) / 64)), dim3(64), 0, s, off, per, n_frames, bytes);
+    return hipGetLastError();
+}
+
+hipError_t launch_zero_streams(uint32_t* U, size_t u_stride_words, const unsigned long long* bytes, int n_frames, hipStream_t s)
+{
+    const size_t wgs = (u_stride_words * 4 + 4095) / 4096;
+    if (!wgs || n_frames <= 0) return hipSuccess;
+    hipLaunchKernelGGL(zero_streams_kernel, dim3((unsigned)wgs, (unsigned)n_frames), dim3(256), 0, s, U, u_stride_words, bytes);
     return hipGetLastError();
 }
 

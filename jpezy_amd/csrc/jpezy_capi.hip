@@ -725,7 +725,7 @@ int jpezy_write_jpeg_gpu_batch(jpezy_ctx* c, const int16_t* d_coeffs, int W, int
     const size_t nblk = (size_t)jpezy_mcu_cols(W) * jpezy_mcu_rows(H) * 6;
     // chunk the batch so that the worst-case unstuffed streams (208 bytes per block) stay below ~1 GiB
     const size_t worst = nblk * 208 + 4096;
-    int per = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_frames, ((size_t)1 << 30) / worst));
+    int per = (int)std::max<size_t>(1, std::min<size_t>(std::min<size_t>((size_t)n_frames, 65535), ((size_t)1 << 30) / worst));   // 65535: grid dimension
     bool any_failed = false;
     const size_t cpf = jpezy_coeff_count(W, H, gray);
     for (int f0 = 0; f0 < n_frames; f0 += per) {

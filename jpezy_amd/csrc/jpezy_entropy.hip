@@ -336,32 +336,63 @@ __global__ __launch_bounds__(256) void ff_count_kernel(const uint32_t* U, size_t
     counts[g] = n;
 }
 
-__global__ __launch_bounds__(256) void stuff_kernel(const uint32_t* U, size_t u_stride_words, const unsigned long long* frame_bytes,
-                                                   int n_frames, const unsigned long long* ff_before, uint8_t* out, size_t out_stride)
+// Copy U to the output inserting 0x00 after every 0xFF.  A workgroup takes 256 consecutive chunks of one frame: its output
+// is one contiguous byte range (start = chunk offset + 0xFF bytes before it).  Every thread expands its 64 bytes into LDS
+// at the position they have in that range, shifted so that LDS words line up with the 4-byte words of the destination;
+// the range then goes out as whole words, coalesced (byte stores only for the partial first and last word, which the
+// neighbouring workgroups complete).  Byte stores straight to global memory -- 64 lanes, 64 different cache lines per
+// instruction -- cost 31 us per 4096x4096 frame.
+constexpr int STUFF_WG = 256;
+__global__ __launch_bounds__(STUFF_WG) void stuff_kernel(const uint32_t* U, size_t u_stride_words, const unsigned long long* frame_bytes,
+                                                        int n_frames, const unsigned long long* ff_before, uint8_t* out, size_t out_stride)
 {
+    __shared__ uint32_t buf[STUFF_WG * CHUNK * 2 / 4 + 4];
+    uint8_t* const lb = reinterpret_cast<uint8_t*>(buf);
     const size_t chunks_per_frame = u_stride_words * 4 / CHUNK;
-    const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= chunks_per_frame * n_frames) return;
-    const size_t frame = g / chunks_per_frame, c = g - frame * chunks_per_frame;
+    const size_t frame = blockIdx.y;
+    const size_t c0 = (size_t)blockIdx.x * STUFF_WG;
     const unsigned long long nbytes = frame_bytes[frame];
-    if ((unsigned long long)c * CHUNK >= nbytes) return;
-    const unsigned long long before = ff_before[g] - ff_before[frame * chunks_per_frame];
-    uint8_t* dst = out + frame * out_stride + c * CHUNK + before;
-    const uint8_t* src = reinterpret_cast<const uint8_t*>(U + frame * u_stride_words) + c * CHUNK;
-    const int n = (int)((nbytes - (unsigned long long)c * CHUNK) < (unsigned long long)CHUNK ? (nbytes - (unsigned long long)c * CHUNK) : CHUNK);
+    if ((unsigned long long)c0 * CHUNK >= nbytes) return;                       // workgroup-uniform
+    const unsigned long long* ffb = ff_before + frame * chunks_per_frame;        // + c: 0xFF bytes of this and earlier frames before chunk c
+    const unsigned long long ff0 = ffb[c0];
+    uint8_t* const P = out + frame * out_stride + c0 * CHUNK + (ff0 - ffb[0]);   // first output byte of the workgroup
+    const unsigned shift = (unsigned)(reinterpret_cast<uintptr_t>(P) & 3u);
+    const size_t c = c0 + threadIdx.x;
+    if ((unsigned long long)c * CHUNK < nbytes) {
+        const int n = (int)((nbytes - (unsigned long long)c * CHUNK) < (unsigned long long)CHUNK ? (nbytes - (unsigned long long)c * CHUNK) : CHUNK);
+        uint8_t* dst = lb + shift + threadIdx.x * CHUNK + (unsigned)(ffb[c] - ff0);
+        const uint4* src = reinterpret_cast<const uint4*>(reinterpret_cast<const uint8_t*>(U + frame * u_stride_words) + c * CHUNK);
 #pragma unroll 1
-    for (int k = 0; k < CHUNK / 16; ++k) {
-        const uint4 v = reinterpret_cast<const uint4*>(src)[k];
-        const uint32_t wd[4] = { v.x, v.y, v.z, v.w };
+        for (int k = 0; k < CHUNK / 16; ++k) {
+            const uint4 v = src[k];
+            const uint32_t wd[4] = { v.x, v.y, v.z, v.w };
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            if (k * 16 + j < n) {
-                const uint8_t b = (uint8_t)(wd[j >> 2] >> ((j & 3) * 8));
-                *dst++ = b;
-                if (b == 0xFF) *dst++ = 0x00;
+            for (int j = 0; j < 16; ++j) {
+                if (k * 16 + j < n) {
+                    const uint8_t b = (uint8_t)(wd[j >> 2] >> ((j & 3) * 8));
+                    *dst++ = b;
+                    if (b == 0xFF) *dst++ = 0x00;
+                }
             }
         }
     }
+    __syncthreads();
+    // bytes of the workgroup's range: its chunks' bytes plus the 0xFF bytes among them
+    const unsigned long long last_chunk = (nbytes + CHUNK - 1) / CHUNK;          // chunks of the frame that hold data
+    const size_t ce = c0 + STUFF_WG < last_chunk ? c0 + STUFF_WG : (size_t)last_chunk;
+    const unsigned long long src_end = (unsigned long long)ce * CHUNK < nbytes ? (unsigned long long)ce * CHUNK : nbytes;
+    const unsigned total = (unsigned)(src_end - (unsigned long long)c0 * CHUNK) + (unsigned)(ffb[ce] - ff0);
+    uint32_t* const A = reinterpret_cast<uint32_t*>(P - shift);                  // 4-byte aligned
+    const unsigned end = shift + total, nwords = (end + 3) / 4;
+    for (unsigned w = threadIdx.x; w < nwords; w += STUFF_WG) {
+        const unsigned lo = w * 4, hi = lo + 4;
+        if (lo >= shift && hi <= end) {
+            A[w] = buf[w];
+        } else {
+            for (unsigned k = lo < shift ? shift : lo; k < (hi < end ? hi : end); ++k) reinterpret_cast<uint8_t*>(A)[k] = lb[k];
+        }
+    }
+    (void)n_frames;
 }
 
 // ---- host-side driver ----
@@ -411,10 +442,11 @@ hipError_t launch_ff_count(const uint32_t* U, size_t u_stride_words, const unsig
 hipError_t launch_stuff(const uint32_t* U, size_t u_stride_words, const unsigned long long* frame_bytes, int n_frames,
                         const unsigned long long* ff_before, uint8_t* out, size_t out_stride, hipStream_t s)
 {
-    const size_t n = u_stride_words * 4 / CHUNK * n_frames;
-    if (!n) return hipSuccess;
-    hipLaunchKernelGGL(stuff_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, U, u_stride_words, frame_bytes, n_frames, ff_before, out,
-                       out_stride);
+    const size_t chunks = u_stride_words * 4 / CHUNK;
+    if (!chunks || n_frames <= 0) return hipSuccess;
+    if (n_frames > 65535) return hipErrorInvalidValue;                           // the frame index is a grid dimension
+    hipLaunchKernelGGL(stuff_kernel, dim3((unsigned)((chunks + STUFF_WG - 1) / STUFF_WG), (unsigned)n_frames), dim3(STUFF_WG), 0, s, U,
+                       u_stride_words, frame_bytes, n_frames, ff_before, out, out_stride);
     return hipGetLastError();
 }
 

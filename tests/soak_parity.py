@@ -139,7 +139,9 @@ def main():
         import jpezy_amd as J
         ctx = J.Context(0)
         dev = torch.device("cuda:0")
+        case_no = -1
         while pending:
+            case_no += 1
             args, fut = pending.pop(0)
             kind, W, H, seed, gray = args
             want_co, want_planes = fut.result()
@@ -162,17 +164,37 @@ def main():
                     print(f"MISMATCH: kind={kind} {W}x{H} seed={seed} gray={gray}", flush=True)
                 continue
             r, g, b = make_frame(kind, W, H, np.random.default_rng(seed))
-            d = [torch.from_numpy(p).to(dev) for p in (r, g, b)]
-            co = torch.empty(J.coeff_count(W, H, gray), dtype=torch.int16, device=dev)
-            ctx.fdct_quant_dev(d[0], d[1], d[2], W, H, co, gray=gray)
-            co6 = co
+            # Every third case goes through the batch form of the entry points: the frame is copy `slot` of `nf` frames at a
+            # plane stride that is not W*H, from a base address that is not 16-byte aligned (the unaligned kernel variants,
+            # the frame index of the launch); the other frames of the batch hold noise.
+            lrng = np.random.default_rng(seed ^ 0x5A5A)
+            batched = case_no % 3 == 2 and W * H <= (1 << 22)
+            nf = int(lrng.integers(2, 5)) if batched else 1
+            slot = int(lrng.integers(0, nf)) if batched else 0
+            pad = int(lrng.integers(1, 40)) if batched else 0
+            skew = int(lrng.integers(1, 16)) if batched else 0
+            stride = W * H + pad
+            d = []
+            for p in (r, g, b):
+                buf = torch.randint(0, 256, (skew + nf * stride,), dtype=torch.uint8, device=dev)
+                buf[skew + slot * stride: skew + slot * stride + W * H] = torch.from_numpy(p).to(dev)
+                d.append(buf[skew:])
+            nco = J.coeff_count(W, H, gray)
+            co_all = torch.empty(nf * nco, dtype=torch.int16, device=dev)
+            ctx.fdct_quant_dev(d[0], d[1], d[2], W, H, co_all, gray=gray, n_frames=nf, plane_stride=stride)
+            co = co_all[slot * nco:(slot + 1) * nco]
+            co6_all = co_all
+            nco6 = J.coeff_count(W, H, False)
             if gray:
-                co6 = torch.empty(J.coeff_count(W, H, False), dtype=torch.int16, device=dev)
-                ctx.fdct_quant_dev(d[0], d[1], d[2], W, H, co6, gray=False)
-            out = [torch.empty(W * H, dtype=torch.uint8, device=dev) for _ in range(3)]
-            ctx.dequant_idct_dev(co6, W, H, out[0], out[1], out[2], gray=gray)
+                co6_all = torch.empty(nf * nco6, dtype=torch.int16, device=dev)
+                ctx.fdct_quant_dev(d[0], d[1], d[2], W, H, co6_all, gray=False, n_frames=nf, plane_stride=stride)
+            obuf = [torch.zeros(skew + nf * stride, dtype=torch.uint8, device=dev) for _ in range(3)]
+            ctx.dequant_idct_dev(co6_all, W, H, obuf[0][skew:], obuf[1][skew:], obuf[2][skew:], gray=gray, n_frames=nf, plane_stride=stride)
+            out = [o[skew + slot * stride: skew + slot * stride + W * H] for o in obuf]
             torch.cuda.synchronize()
             ok = np.array_equal(co.cpu().numpy(), want_co) and all(np.array_equal(o.cpu().numpy(), w) for o, w in zip(out, want_planes))
+            if batched and pad:      # nothing may be written between the frames
+                ok = ok and all(int(o[skew + slot * stride + W * H: skew + (slot + 1) * stride].max()) == 0 for o in obuf)
             done += 1
             px += W * H
             if not ok:

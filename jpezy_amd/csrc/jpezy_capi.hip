@@ -906,13 +906,9 @@ int jpezy_read_jpeg_gpu(jpezy_ctx* c, const uint8_t* data, size_t len, jpezy_fra
     unsigned* d_changed = (unsigned*)c->h_small.p;
     unsigned* d_error = d_changed + 1;
     unsigned long long* d_lastbit = (unsigned long long*)c->h_small.p + 1;
-    {
-        std::vector<uint32_t> init(n_sub, 0x80000000u);
-        HIP_TRY(hipMemcpyAsync(d_exit, init.data(), (size_t)n_sub * 4, hipMemcpyHostToDevice, s));
-        HIP_TRY(hipMemsetAsync(d_last, 0xFF, (size_t)n_sub * 4, s));
-        HIP_TRY(hipMemsetAsync(d_nblocks, 0, (size_t)n_sub * 4, s));
-        HIP_TRY(hipStreamSynchronize(s));                       // init lives on this stack frame
-    }
+    HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)d_exit, (int)0x80000000u, n_sub, s));
+    HIP_TRY(hipMemsetAsync(d_last, 0xFF, (size_t)n_sub * 4, s));
+    HIP_TRY(hipMemsetAsync(d_nblocks, 0, (size_t)n_sub * 4, s));
     // speculation: every lane decodes through its own and the next 12 subsequences from a guess; the farthest-travelled
     // proposal for every boundary becomes the initial exit state (h_dc doubles as the proposal scratch)
     HIP_TRY(HD::launch_speculate((const HD::Setup*)c->h_setup.p, (const uint32_t*)c->h_U.p, u_bytes / 4, n_sub,

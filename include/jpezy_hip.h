@@ -101,9 +101,10 @@ int jpezy_dequant_idct_dev(jpezy_ctx* ctx, const int16_t* d_coeffs, const uint16
 /*
  * DECODE compute stage for ANY baseline layout the reference's decode_mcu handles (decoder/jpezy_decoder.hpp:504-565):
  * 1 or 3 components, sampling factors 1..4 per direction (block placement as decode_mcu does it, :516-524), any table selectors.  coeffs as jpezy_read_jpeg delivers them
- * ([mcu][component blocks, ky outer, kx inner][64], zig-zag).  This is the reference's own arithmetic executed one
- * sample per lane (the 64-term sum in its exact order) followed by the replication upsample and make_rgb -- correct for
- * every layout, an order of magnitude slower than jpezy_dequant_idct, which handles jpezy_encode's own 2x2,1x1,1x1 files.
+ * ([mcu][component blocks, ky outer, kx inner][64], zig-zag).  Blocks go through a fast FP64 inverse transform with a
+ * guard band; a block with a sample inside the band is recomputed in the reference's own order (the 64-term sum, one
+ * sample per lane), then the replication upsample and make_rgb run one thread per four pixels -- correct for every
+ * layout, about a fifth of the speed of jpezy_dequant_idct, which handles jpezy_encode's own 2x2,1x1,1x1 files in one pass.
  * With ncomp == 1 the missing chroma planes read 0x80 as in the reference (:104-105).
  */
 int jpezy_dequant_idct_generic(jpezy_ctx* ctx, const int16_t* coeffs, const uint16_t qt[4][64], int ncomp,

@@ -472,19 +472,20 @@ static int dequant_idct_generic_impl(jpezy_ctx* c, const int16_t* coeffs, const 
     const size_t plane = (size_t)W * H;
     if (!coeffs_on_device)
         if (int rc = c->out.reserve(nblk * 64 * sizeof(int16_t))) return rc;
-    if (int rc = c->scratch.reserve(nblk * 64 * sizeof(int) + 3 * 64 * sizeof(int))) return rc;
+    if (int rc = c->scratch.reserve(nblk * 64 * sizeof(int))) return rc;
     for (int k = 0; k < 3; ++k)
         if (int rc = c->in[k].reserve(plane)) return rc;
-    int h_qt[3][64];
-    for (int k = 0; k < 3; ++k)
-        for (int i = 0; i < 64; ++i) h_qt[k][i] = qt[(k < ncomp ? comp_tq[k] : 0) & 3][i];
-    int* d_qt = (int*)((char*)c->scratch.p + nblk * 64 * sizeof(int));
-    HIP_TRY(hipMemcpyAsync(d_qt, h_qt, sizeof h_qt, hipMemcpyHostToDevice, c->stream));
+    // per-component dequantiser constants (fast path) and integer quantisers (reference-order path), cached in the context
+    const uint8_t tq3[3] = { comp_tq[0], (uint8_t)(ncomp > 1 ? comp_tq[1] : 0), (uint8_t)(ncomp > 2 ? comp_tq[2] : 0) };
+    if (int rc = upload_dequant(c, qt, tq3, c->stream)) return rc;
     if (!coeffs_on_device) HIP_TRY(hipMemcpyAsync(c->out.p, coeffs, nblk * 64 * sizeof(int16_t), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));                  // h_qt lives on this stack frame
     p.coeffs = coeffs_on_device ? coeffs : (const int16_t*)c->out.p;
     p.samples = (int*)c->scratch.p;
-    p.qt = d_qt;
+    p.qt = c->d_dqt;
+    p.dqscale = c->d_dqscale;
+    p.coef_limit = c->coef_limit;
+    p.force_exact = c->force_exact != 0;
+    p.fallback_count = c->d_counter;
     p.r = (uint8_t*)c->in[0].p; p.g = (uint8_t*)c->in[1].p; p.b = (uint8_t*)c->in[2].p;
     HIP_TRY(launch_dequant_idct_generic(p, c->stream));
     uint8_t* dst[3] = { r, g, b };

@@ -111,6 +111,12 @@ struct GenericDecParams {
     int ch[3], cv[3], hmax, vmax, mcu_cols, mcu_rows, blocks_per_mcu;
     int blk_start[3];         // first block of each component inside an MCU
     int level;                // level shift of inverse_dct: 128, or 2048 when SOF0 says precision != 8 (ref :654)
+    unsigned mw_magic, mw_shift, mh_magic, mh_shift;        // fast_div by hmax*8, vmax*8 (set by the launcher)
+    unsigned dx_magic[3], dx_shift[3], dy_magic[3], dy_shift[3];   // fast_div by hmax/H, vmax/V of each component
+    const double* dqscale;    // [3 comps][8 (u)][8 (v)] cu*cv*Q/4 as for the fused kernel (fast path)
+    int coef_limit;           // raw coefficients above it send their block to the reference-order path
+    int force_exact;          // test hook: every block through the reference-order path
+    unsigned long long* fallback_count;   // samples evaluated in reference order (sharded, COUNTER_SHARDS)
 };
 hipError_t launch_dequant_idct_generic(const GenericDecParams& p, hipStream_t stream);
 

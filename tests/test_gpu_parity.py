@@ -351,11 +351,18 @@ def test_generic_decode_of_libjpeg_files(J, ctx, oracle, kw):
     info, co = J.read_jpeg(buf.getvalue())
     oinfo, oco = oracle.read_jpeg(buf.getvalue())
     assert np.array_equal(co, oco)
+    nsamples = int(np.asarray(co).size)
     for gray in (False, True):
         want = oracle.decode_planes(oco, oinfo, gray)
-        got = ctx.dequant_idct_generic(co, info, gray=gray)
-        for a, e in zip(got, want):
-            assert np.array_equal(a, e)
+        for force in (0, 1):                 # fast path with its guard band / every block in the reference's order
+            ctx.set_force_exact(force)
+            ctx.fallback_count()
+            got = ctx.dequant_idct_generic(co, info, gray=gray)
+            n_exact = ctx.fallback_count()
+            ctx.set_force_exact(0)
+            for a, e in zip(got, want):
+                assert np.array_equal(a, e)
+            assert n_exact == nsamples if force else n_exact < nsamples // 20
     if kw.get("subsampling") == 2:       # jpezy's own layout: the fused kernel must agree with the generic one
         fused = ctx.dequant_idct(co, Wd, Hd, qt=info.qt, comp_tq=tuple(info.Tq[i] for i in range(3)))
         for a, e in zip(fused, oracle.decode_planes(oco, oinfo, False)):
@@ -374,9 +381,12 @@ def test_generic_decode_sampling_up_to_4(J, ctx, oracle, name):
     oinfo, oco = oracle.read_jpeg(data)
     for gray in (False, True):
         want = oracle.decode_planes(oco, oinfo, gray)
-        got = ctx.dequant_idct_generic(hco, info, gray=gray)
-        for a, e in zip(got, want):
-            assert np.array_equal(a, np.asarray(e).reshape(-1))
+        for force in (0, 1):
+            ctx.set_force_exact(force)
+            got = ctx.dequant_idct_generic(hco, info, gray=gray)
+            ctx.set_force_exact(0)
+            for a, e in zip(got, want):
+                assert np.array_equal(a, np.asarray(e).reshape(-1))
         _, r, g, b = ctx.decode_jpeg(data, gray=gray)                     # decoder::decode end to end
         for a, e in zip((r, g, b), want):
             assert np.array_equal(a, np.asarray(e).reshape(-1))

@@ -37,6 +37,26 @@ def main():
             print(f"{W}x{H} {name}: jpezy_decode_jpeg (.jpg bytes on the host -> r,g,b planes on the host, Huffman + IDCT + colour on the GPU): {te * 1e3:.2f} ms")
             print(f"{W}x{H} {name}: {len(data) / 1e6:.2f} MB; GPU Huffman decode {tg * 1e3:.2f} ms ({ctx.last_huffdec_passes()} passes) = "
                   f"{W * H / tg / 1e6:.0f} Mpx/s; host {th * 1e3:.1f} ms = {W * H / th / 1e6:.0f} Mpx/s; identical: {ok}")
+    # files in other layouts (libjpeg): device Huffman decoder + the generic kernels
+    import io
+    from PIL import Image, ImageFile
+    ImageFile.MAXBLOCK = 1 << 26
+    W = H = 4096
+    rng = np.random.default_rng(5)
+    yy, xx = np.mgrid[0:H, 0:W]
+    img = np.clip((np.sin(xx / 37.0) * 60 + np.cos(yy / 23.0) * 50 + 128)[..., None] + rng.normal(0, 12, (H, W, 3)), 0, 255).astype(np.uint8)
+    for name, kw, im in (("4:4:4", dict(subsampling=0, quality=90), img), ("4:2:2", dict(subsampling=1, quality=90), img),
+                         ("one component", dict(quality=90), img[..., 0])):
+        buf = io.BytesIO()
+        Image.fromarray(im).save(buf, "JPEG", **kw)
+        data = buf.getvalue()
+        ctx.decode_jpeg(data)
+        t = time.perf_counter()
+        for _ in range(3):
+            ctx.decode_jpeg(data)
+        te = (time.perf_counter() - t) / 3
+        print(f"{W}x{H} libjpeg {name} ({len(data) / 1e6:.1f} MB): jpezy_decode_jpeg {te * 1e3:.2f} ms ({ctx.last_huffdec_passes()} passes)")
+
     # a batch of different 1080p files: one call per file vs jpezy_decode_jpeg_batch (up to 8 files in flight)
     W, H = 1920, 1080
     files = []

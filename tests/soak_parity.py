@@ -58,7 +58,7 @@ def make_frame(kind, W, H, rng):
     raise ValueError(kind)
 
 
-KINDS = ["uniform", "lownoise", "gradient", "flatblocks", "binary", "grey", "mult8", "checker", "coeffs", "coeffs"]
+KINDS = ["uniform", "lownoise", "gradient", "flatblocks", "binary", "grey", "mult8", "checker", "coeffs", "coeffs", "generic", "generic"]
 SIZES = [(4096, 4096), (1920, 1080), (1237, 911), (640, 480), (4096, 2160), (333, 2047)]
 
 
@@ -89,10 +89,59 @@ def make_coeffs(W, H, rng):
     return co.reshape(-1), qt, tq
 
 
+LAYOUTS = [[(1, 1), (1, 1), (1, 1)], [(2, 1), (1, 1), (1, 1)], [(2, 2), (1, 1), (1, 1)], [(1, 1)], [(2, 2)],
+           [(4, 1), (1, 1), (1, 1)], [(1, 2), (1, 1), (1, 1)], [(4, 2), (2, 1), (2, 2)], [(3, 1), (1, 1), (2, 1)]]
+
+
+def make_generic(W, H, rng):
+    """any-layout decode case: layout, quantiser tables, selectors, coefficients"""
+    lay = LAYOUTS[int(rng.integers(0, len(LAYOUTS)))]
+    hmax, vmax = max(h for h, _ in lay), max(v for _, v in lay)
+    hb, vb = (W + 7) // 8, (H + 7) // 8
+    mc, mr = -(-hb // hmax), -(-vb // vmax)
+    bpm = sum(h * v for h, v in lay)
+    shape = (mc * mr * bpm, 64)
+    mode = int(rng.integers(0, 4))
+    if mode == 0:
+        co = rng.integers(-25, 26, shape, dtype=np.int16)
+    elif mode == 1:
+        co = np.zeros(shape, np.int16)
+        m = rng.random(shape) < 0.08
+        co[m] = rng.integers(-1500, 1501, int(m.sum()), dtype=np.int16)
+    elif mode == 2:
+        co = np.zeros(shape, np.int16)
+        co[:, 0] = rng.integers(-900, 900, shape[0], dtype=np.int16)
+        co[:, 1:6] = rng.integers(-40, 41, (shape[0], 5), dtype=np.int16)
+    else:
+        co = rng.integers(-70, 71, shape, dtype=np.int16)
+        rows = rng.integers(0, shape[0], max(1, shape[0] // 40))
+        co[rows] = rng.integers(-32768, 32768, (len(rows), 64), dtype=np.int16)
+    qt = rng.integers(1, int(rng.choice([10, 60, 255])) + 1, (3, 64))
+    tq = [int(v) for v in rng.integers(0, 3, 3)]
+    return lay, (hmax, vmax, mc, mr, bpm), co.reshape(-1), qt, tq
+
+
+def fill_info(info, W, H, lay, geo, qt, tq):
+    hmax, vmax, mc, mr, bpm = geo
+    info.width, info.height, info.ncomp, info.precision = W, H, len(lay), 8
+    for i, (h, v) in enumerate(lay):
+        info.H[i], info.V[i], info.Tq[i] = h, v, tq[i]
+    info.hmax, info.vmax, info.mcu_cols, info.mcu_rows, info.blocks_per_mcu = hmax, vmax, mc, mr, bpm
+    for t in range(3):
+        for i in range(64):
+            info.qt[t][i] = int(qt[t][i])
+    return info
+
+
 def oracle_job(args):
     kind, W, H, seed, gray = args
     from oracle import oracle as O
     rng = np.random.default_rng(seed)
+    if kind == "generic":
+        lay, geo, co, qt, tq = make_generic(W, H, rng)
+        info = fill_info(O.FrameInfo(), W, H, lay, geo, qt, tq)
+        planes = O.decode_planes(co, info, gray)
+        return None, [np.asarray(p).reshape(-1)[: W * H] for p in planes]
     if kind == "coeffs":
         co, qt, tq = make_coeffs(W, H, rng)
         info = O.make_info(W, H, gray_layout=False)
@@ -129,6 +178,8 @@ def main():
             W, H = SIZES[int(rng.integers(0, len(SIZES)))]
             if rng.random() < 0.3:
                 W, H = int(rng.integers(1, 700)), int(rng.integers(1, 700))
+            if kind == "generic" and W * H > 2_500_000:
+                W, H = 1237, 911
             args = (kind, W, H, int(rng.integers(0, 2**31)), bool(rng.integers(0, 2)))
             pending.append((args, pool.submit(oracle_job, args)))
             case += 1
@@ -147,6 +198,17 @@ def main():
             want_co, want_planes = fut.result()
             if time.time() < t_end:
                 submit()
+            if kind == "generic":
+                lay, geo, co_h, qt, tq = make_generic(W, H, np.random.default_rng(seed))
+                ginfo = fill_info(J.FrameInfo(), W, H, lay, geo, qt, tq)
+                got = ctx.dequant_idct_generic(co_h, ginfo, gray=gray)
+                ok = all(np.array_equal(o, w) for o, w in zip(got, want_planes))
+                done += 1
+                px += W * H
+                if not ok:
+                    bad += 1
+                    print(f"MISMATCH: kind={kind} {W}x{H} seed={seed} gray={gray} layout={lay}", flush=True)
+                continue
             if kind == "coeffs":
                 co_h, qt, tq = make_coeffs(W, H, np.random.default_rng(seed))
                 qtab = type(J.api.annex_k_tables().qt)()

@@ -110,6 +110,15 @@ int jpezy_dequant_idct_dev(jpezy_ctx* ctx, const int16_t* d_coeffs, const uint16
 int jpezy_dequant_idct_generic(jpezy_ctx* ctx, const int16_t* coeffs, const uint16_t qt[4][64], int ncomp,
                                const uint8_t comp_h[3], const uint8_t comp_v[3], const uint8_t comp_tq[3], int W, int H,
                                int gray, uint8_t* r, uint8_t* g, uint8_t* b);
+/*
+ * The same on device memory, asynchronous on `stream` (a hipStream_t): d_coeffs as jpezy_read_jpeg_gpu leaves them,
+ * d_r, d_g, d_b planes of W*H bytes.  precision: the SOF0 sample precision (8, or anything else for the reference's
+ * 2048 level shift, decoder/jpezy_decoder.hpp:654).  The intermediate samples live in the context: one call in flight per
+ * context.
+ */
+int jpezy_dequant_idct_generic_dev(jpezy_ctx* ctx, const int16_t* d_coeffs, const uint16_t qt[4][64], int ncomp,
+                                   const uint8_t comp_h[3], const uint8_t comp_v[3], const uint8_t comp_tq[3], int precision,
+                                   int W, int H, int gray, uint8_t* d_r, uint8_t* d_g, uint8_t* d_b, void* stream);
 
 /* Test hook: route EVERY coefficient / sample through the kernels' exact-order fallback (the path a
  * guard-band hit takes).  0 = normal, 1 = reference-order path, 2 = (encode variant 1 only) the FP64 second

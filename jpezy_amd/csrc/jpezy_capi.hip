@@ -442,12 +442,12 @@ int jpezy_dequant_idct(jpezy_ctx* c, const int16_t* coeffs, const uint16_t qt[4]
     return JPEZY_OK;
 }
 
-static int dequant_idct_generic_impl(jpezy_ctx* c, const int16_t* coeffs, const uint16_t qt[4][64], int ncomp, const uint8_t comp_h[3],
-                                     const uint8_t comp_v[3], const uint8_t comp_tq[3], int W, int H, int gray, int precision,
-                                     uint8_t* r, uint8_t* g, uint8_t* b, bool coeffs_on_device = false)
+// geometry + tables + the two launches of the any-layout decoder on device memory; asynchronous on stream s (the tables are
+// uploaded synchronously when they changed since the last call)
+static int generic_dev_core(jpezy_ctx* c, const int16_t* d_coeffs, const uint16_t qt[4][64], int ncomp, const uint8_t comp_h[3],
+                            const uint8_t comp_v[3], const uint8_t comp_tq[3], int W, int H, int gray, int precision, uint8_t* d_r,
+                            uint8_t* d_g, uint8_t* d_b, hipStream_t s, size_t* nblk_out)
 {
-    if (int rc = check_dims(c, W, H, 1)) return rc;
-    if (!coeffs || !qt || !comp_h || !comp_v || !comp_tq || !r || !g || !b) return set_err(JPEZY_E_BADARG, "null pointer");
     if (ncomp != 1 && ncomp != 3) return set_err(JPEZY_E_UNSUPPORTED, "dimension not supported (the reference accepts 1 or 3)");
     GenericDecParams p;
     p.W = W; p.H = H; p.ncomp = ncomp; p.gray = gray != 0;
@@ -467,27 +467,59 @@ static int dequant_idct_generic_impl(jpezy_ctx* c, const int16_t* coeffs, const 
     const int Hblock = (W >> 3) + ((W & 7) > 0), Vblock = (H >> 3) + ((H & 7) > 0);   // get_blocks, ref :166-169
     p.mcu_cols = Hblock / p.hmax + ((Hblock % p.hmax) ? 1 : 0);
     p.mcu_rows = Vblock / p.vmax + ((Vblock % p.vmax) ? 1 : 0);
-    HIP_TRY(hipSetDevice(c->device));
     const size_t nblk = (size_t)p.mcu_cols * p.mcu_rows * p.blocks_per_mcu;
-    const size_t plane = (size_t)W * H;
-    if (!coeffs_on_device)
-        if (int rc = c->out.reserve(nblk * 64 * sizeof(int16_t))) return rc;
+    if (nblk_out) *nblk_out = nblk;
+    if (!d_coeffs) return JPEZY_OK;                            // geometry only
     if (int rc = c->scratch.reserve(nblk * 64 * sizeof(int))) return rc;
-    for (int k = 0; k < 3; ++k)
-        if (int rc = c->in[k].reserve(plane)) return rc;
     // per-component dequantiser constants (fast path) and integer quantisers (reference-order path), cached in the context
     const uint8_t tq3[3] = { comp_tq[0], (uint8_t)(ncomp > 1 ? comp_tq[1] : 0), (uint8_t)(ncomp > 2 ? comp_tq[2] : 0) };
-    if (int rc = upload_dequant(c, qt, tq3, c->stream)) return rc;
-    if (!coeffs_on_device) HIP_TRY(hipMemcpyAsync(c->out.p, coeffs, nblk * 64 * sizeof(int16_t), hipMemcpyHostToDevice, c->stream));
-    p.coeffs = coeffs_on_device ? coeffs : (const int16_t*)c->out.p;
+    if (int rc = upload_dequant(c, qt, tq3, s)) return rc;
+    p.coeffs = d_coeffs;
     p.samples = (int*)c->scratch.p;
     p.qt = c->d_dqt;
     p.dqscale = c->d_dqscale;
     p.coef_limit = c->coef_limit;
     p.force_exact = c->force_exact != 0;
     p.fallback_count = c->d_counter;
-    p.r = (uint8_t*)c->in[0].p; p.g = (uint8_t*)c->in[1].p; p.b = (uint8_t*)c->in[2].p;
-    HIP_TRY(launch_dequant_idct_generic(p, c->stream));
+    p.r = d_r; p.g = d_g; p.b = d_b;
+    HIP_TRY(launch_dequant_idct_generic(p, s));
+    return JPEZY_OK;
+}
+
+int jpezy_dequant_idct_generic_dev(jpezy_ctx* c, const int16_t* d_coeffs, const uint16_t qt[4][64], int ncomp, const uint8_t comp_h[3],
+                                   const uint8_t comp_v[3], const uint8_t comp_tq[3], int precision, int W, int H, int gray,
+                                   uint8_t* d_r, uint8_t* d_g, uint8_t* d_b, void* stream)
+{
+    if (int rc = check_dims(c, W, H, 1)) return rc;
+    if (!d_coeffs || !qt || !comp_h || !comp_v || !comp_tq || !d_r || !d_g || !d_b) return set_err(JPEZY_E_BADARG, "null pointer");
+    HIP_TRY(hipSetDevice(c->device));
+    return generic_dev_core(c, d_coeffs, qt, ncomp, comp_h, comp_v, comp_tq, W, H, gray, precision, d_r, d_g, d_b, (hipStream_t)stream,
+                            nullptr);
+}
+
+static int dequant_idct_generic_impl(jpezy_ctx* c, const int16_t* coeffs, const uint16_t qt[4][64], int ncomp, const uint8_t comp_h[3],
+                                     const uint8_t comp_v[3], const uint8_t comp_tq[3], int W, int H, int gray, int precision,
+                                     uint8_t* r, uint8_t* g, uint8_t* b, bool coeffs_on_device = false)
+{
+    if (int rc = check_dims(c, W, H, 1)) return rc;
+    if (!coeffs || !qt || !comp_h || !comp_v || !comp_tq || !r || !g || !b) return set_err(JPEZY_E_BADARG, "null pointer");
+    HIP_TRY(hipSetDevice(c->device));
+    size_t nblk = 0;
+    if (int rc = generic_dev_core(c, nullptr, qt, ncomp, comp_h, comp_v, comp_tq, W, H, gray, precision, nullptr, nullptr, nullptr, c->stream,
+                                  &nblk))
+        return rc;
+    const size_t plane = (size_t)W * H;
+    for (int k = 0; k < 3; ++k)
+        if (int rc = c->in[k].reserve(plane)) return rc;
+    const int16_t* d_coeffs = coeffs;
+    if (!coeffs_on_device) {
+        if (int rc = c->out.reserve(nblk * 64 * sizeof(int16_t))) return rc;
+        HIP_TRY(hipMemcpyAsync(c->out.p, coeffs, nblk * 64 * sizeof(int16_t), hipMemcpyHostToDevice, c->stream));
+        d_coeffs = (const int16_t*)c->out.p;
+    }
+    if (int rc = generic_dev_core(c, d_coeffs, qt, ncomp, comp_h, comp_v, comp_tq, W, H, gray, precision, (uint8_t*)c->in[0].p,
+                                  (uint8_t*)c->in[1].p, (uint8_t*)c->in[2].p, c->stream, nullptr))
+        return rc;
     uint8_t* dst[3] = { r, g, b };
     for (int k = 0; k < 3; ++k) HIP_TRY(hipMemcpyAsync(dst[k], c->in[k].p, plane, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));

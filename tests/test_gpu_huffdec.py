@@ -172,6 +172,34 @@ def test_decode_jpeg_end_to_end(J, ctx, oracle):
         ctx.decode_jpeg(jpg[:500])
 
 
+def test_any_layout_pipeline_on_device_memory(J, ctx, oracle):
+    """read_jpeg_gpu -> dequant_idct_generic_dev: files in other layouts decoded without the coefficients or the samples
+    leaving the device (4:4:4, 4:2:2 and one-component files of libjpeg, a synthesised 4:1:1 file)"""
+    import torch
+    from PIL import Image
+    from test_host_codec import ODD_LAYOUTS
+    from jpeg_synth import synth_jpeg
+    rng = np.random.default_rng(23)
+    files = []
+    img = rng.integers(0, 256, (200, 312, 3), dtype=np.uint8)
+    for kw, im in ((dict(subsampling=0, quality=88), img), (dict(subsampling=1, quality=70), img), (dict(quality=75), img[..., 1])):
+        buf = io.BytesIO()
+        Image.fromarray(im).save(buf, "JPEG", **kw)
+        files.append(buf.getvalue())
+    files.append(synth_jpeg(333, 190, ODD_LAYOUTS["411"], seed=3)[0])
+    for data in files:
+        info, d_co = ctx.read_jpeg_gpu(data)
+        assert ctx.last_huffdec_passes() > 0
+        n = info.width * info.height
+        for gray in (False, True):
+            out = [torch.empty(n, dtype=torch.uint8, device=d_co.device) for _ in range(3)]
+            ctx.dequant_idct_generic_dev(d_co, info, out[0], out[1], out[2], gray=gray)
+            torch.cuda.synchronize()
+            want = oracle.decode_jpeg(data, gray)
+            for a, e in zip(out, want[-3:]):
+                assert np.array_equal(a.cpu().numpy(), np.asarray(e).reshape(-1)[:n])
+
+
 def test_decode_jpeg_batch(J, ctx, oracle):
     """jpezy_decode_jpeg_batch: a mixed bag of files (jpezy's own, libjpeg 4:4:4 / 4:2:2 / gray, synthesised odd layouts, one
     truncated file) decoded concurrently; every file equals the oracle's decoder, the bad one reports its own error and does

@@ -104,7 +104,7 @@ int jpezy_dequant_idct_dev(jpezy_ctx* ctx, const int16_t* d_coeffs, const uint16
  * ([mcu][component blocks, ky outer, kx inner][64], zig-zag).  Blocks go through a fast FP64 inverse transform with a
  * guard band; a block with a sample inside the band is recomputed in the reference's own order (the 64-term sum, one
  * sample per lane), then the replication upsample and make_rgb run one thread per four pixels -- correct for every
- * layout, about a fifth of the speed of jpezy_dequant_idct, which handles jpezy_encode's own 2x2,1x1,1x1 files in one pass.
+ * layout, about a third of the speed of jpezy_dequant_idct, which handles jpezy_encode's own 2x2,1x1,1x1 files in one pass.
  * With ncomp == 1 the missing chroma planes read 0x80 as in the reference (:104-105).
  */
 int jpezy_dequant_idct_generic(jpezy_ctx* ctx, const int16_t* coeffs, const uint16_t qt[4][64], int ncomp,

@@ -193,21 +193,39 @@ __global__ __launch_bounds__(256) void generic_rgb_kernel(GenericDecParams p)
         rowblk[c] = (unsigned)p.blk_start[c] + ky * (unsigned)p.ch[c];
         rowsmp[c] = gdiv(yu, p.dy_magic[c], p.dy_shift[c]) * 8u;
     }
-    uint32_t rw = 0, gw = 0, bw = 0;
     const unsigned npx = min(4u, (unsigned)p.W - x0);
-    for (unsigned j = 0; j < npx; ++j) {
-        const unsigned x = x0 + j;
-        const unsigned ux = gdiv(x, p.mw_magic, p.mw_shift), ix = x - ux * mw;
+    int smp[3][4];
+    {
+        // the four pixels sit in one MCU (x0 is a multiple of 4, MCUs are multiples of 8 wide)
+        const unsigned ux = gdiv(x0, p.mw_magic, p.mw_shift), ix0 = x0 - ux * mw;
         const size_t mcu_blk = ((size_t)uy * p.mcu_cols + ux) * (size_t)p.blocks_per_mcu;
-        int s[3] = { 0, 0x80, 0x80 };                            // missing components read 0x80 (ref :104-105)
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
+            const int init = c ? 0x80 : 0;                                              // missing components read 0x80 (ref :104-105)
+            smp[c][0] = smp[c][1] = smp[c][2] = smp[c][3] = init;
+            if (!rowok[c]) continue;
             const unsigned chh = (unsigned)p.ch[c], dupx = (unsigned)p.hmax / chh;
-            const unsigned kx = min(chh - 1u, ix >> 3), xu = ix - kx * 8u;
-            if (rowok[c] && xu < 8u * dupx)
-                s[c] = p.samples[(mcu_blk + rowblk[c] + kx) * 64 + rowsmp[c] + gdiv(xu, p.dx_magic[c], p.dx_shift[c])];
+            if (chh == (unsigned)p.hmax) {              // one sample per pixel: four neighbours of one block row, one 16-byte load
+                const int4 v = *reinterpret_cast<const int4*>(p.samples + (mcu_blk + rowblk[c] + (ix0 >> 3)) * 64 + rowsmp[c] + (ix0 & 7u));
+                smp[c][0] = v.x; smp[c][1] = v.y; smp[c][2] = v.z; smp[c][3] = v.w;
+            } else if (chh == 1u && dupx == 2u) {       // every sample twice
+                const int2 v = *reinterpret_cast<const int2*>(p.samples + (mcu_blk + rowblk[c]) * 64 + rowsmp[c] + (ix0 >> 1));
+                smp[c][0] = smp[c][1] = v.x; smp[c][2] = smp[c][3] = v.y;
+            } else if (chh == 1u && dupx == 4u) {       // one sample for all four
+                smp[c][0] = smp[c][1] = smp[c][2] = smp[c][3] = p.samples[(mcu_blk + rowblk[c]) * 64 + rowsmp[c] + (ix0 >> 2)];
+            } else {                                    // the other legal factors: the last block written over each pixel
+                for (unsigned j = 0; j < 4; ++j) {
+                    const unsigned ix = ix0 + j;
+                    const unsigned kx = min(chh - 1u, ix >> 3), xu = ix - kx * 8u;
+                    if (xu < 8u * dupx) smp[c][j] = p.samples[(mcu_blk + rowblk[c] + kx) * 64 + rowsmp[c] + gdiv(xu, p.dx_magic[c], p.dx_shift[c])];
+                }
+            }
         }
-        const double yp = s[0], up = s[1], vp = s[2];
+    }
+    uint32_t rw = 0, gw = 0, bw = 0;
+#pragma unroll
+    for (unsigned j = 0; j < 4; ++j) {
+        const double yp = smp[0][j], up = smp[1][j], vp = smp[2][j];
         uint32_t r, g, b;
         if (!p.gray) {
             r = revise(yp + (vp - 0x80) * 1.4020);

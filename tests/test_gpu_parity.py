@@ -475,3 +475,30 @@ def test_short_soak_against_the_oracle():
     r = subprocess.run([sys.executable, str(root / "tests" / "soak_parity.py"), "8", "6", "20261003"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert " 0 mismatches" in r.stdout
+
+
+def test_bench_prints_one_contract_line():
+    """bench.py as the driver runs it (fewer steps): ONE JSON line with every key of the contract, the roofline and
+    cpu_baseline objects, and -- with --pipelined -- the two-frames-in-flight figure beside value, never inside it"""
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "2", "--pipelined"],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 6 and d["warmup"] == 2 and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["higher_is_better"] is True and d["data"] == "synthetic" and "workload" in d["config"]
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 1
+    assert d["pipelined"]["frames_in_flight"] == 2 and d["pipelined"]["value"] > 0
+    # value is pixels over wall time of the K steps
+    assert abs(d["value"] - 4096 * 4096 / (d["ms_per_step"] * 1e-3) / 1e6) / d["value"] < 0.01

@@ -5,7 +5,7 @@
 
 Seeds: tests/golden/*.jpg-like fixtures inside the .npz files, files written by PIL/libjpeg in several layouts, the
 synthesised odd layouts of tests/jpeg_synth.py.  Mutations: bit flips, byte overwrites, truncations, insertions and
-deletions, 16-bit field edits in the header.  Any sanitizer report fails the run (exit code != 0).
+deletions, 16-bit field edits in the header.  Then the CLI's P3 reader on mutated text files (tests/fuzz/ppm_fuzz.cpp).  Any sanitizer report fails the run (exit code != 0).
 """
 import io
 import subprocess
@@ -68,6 +68,46 @@ def mutate(d, rng):
     return bytes(b)
 
 
+def ppm_phase(n):
+    """the CLI's P3 reader (jpezy::encode_io) under the same sanitizers, on mutated text files"""
+    exe = Path(tempfile.gettempdir()) / "jpezy_ppm_fuzz"
+    subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-I", str(ROOT / "include"),
+                    str(ROOT / "tests" / "fuzz" / "ppm_fuzz.cpp"), "-o", str(exe), "-L", str(ROOT / "jpezy_amd"), "-ljpezy_hip",
+                    "-Wl,-rpath," + str(ROOT / "jpezy_amd"), "-pthread"], check=True)
+    rng = np.random.default_rng(1)
+
+    def ppm(w, h, extra=""):
+        px = rng.integers(0, 256, (w * h, 3))
+        return ("P3\n" + extra + f"{w} {h}\n255\n" + "\n".join(" ".join(map(str, q)) for q in px) + "\n").encode()
+
+    seeds_ = [ppm(4, 3), ppm(16, 16, "# c\n"), ppm(1, 1), ppm(33, 7), b"P3\n2 2\n255\n1 2 3\n4 5 6\n7 8 9\n10 11 12"]
+    alphabet = b"0123456789 \n\t#-+P3\r\x00\xffa"
+    with tempfile.TemporaryDirectory() as td:
+        names = []
+        for i in range(n):
+            b = bytearray(seeds_[i % len(seeds_)])
+            for _ in range(int(rng.integers(1, 8))):
+                op, pos = int(rng.integers(0, 4)), int(rng.integers(0, max(1, len(b))))
+                if op == 0 and b:
+                    b[pos] = alphabet[int(rng.integers(0, len(alphabet)))]
+                elif op == 1:
+                    b[pos:pos] = bytes(alphabet[int(k)] for k in rng.integers(0, len(alphabet), int(rng.integers(1, 6))))
+                elif op == 2:
+                    del b[pos:pos + int(rng.integers(1, 6))]
+                else:
+                    del b[int(rng.integers(0, len(b) + 1)):]
+            q = Path(td) / f"m{i}.ppm"
+            q.write_bytes(bytes(b))
+            names.append(str(q))
+        lst = Path(td) / "l.txt"
+        lst.write_text("\n".join(names) + "\n")
+        r = subprocess.run([str(exe), "@" + str(lst)], capture_output=True, text=True)
+    print("P3 reader:", r.stderr.strip().splitlines()[-1] if r.stderr.strip() else "")
+    if r.returncode != 0:
+        print(r.stderr[-4000:])
+    return r.returncode
+
+
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
     exe = Path(tempfile.gettempdir()) / "jpezy_host_codec_fuzz"
@@ -92,7 +132,10 @@ def main():
     print(r.stdout.strip())
     if r.returncode != 0:
         print(r.stderr[-4000:])
-    return r.returncode
+        return r.returncode
+    if (ROOT / "jpezy_amd" / "libjpezy_hip.so").exists():       # the reader's header pulls in the class surface, which links the library
+        return ppm_phase(max(200, n // 4))
+    return 0
 
 
 if __name__ == "__main__":

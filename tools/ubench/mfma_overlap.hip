@@ -7,8 +7,9 @@
 #include <cstdio>
 #define N_ITER 2048
 typedef float v4f __attribute__((ext_vector_type(4)));
+typedef short v4s __attribute__((ext_vector_type(4)));
 
-template <int VALU, int MFMA>
+template <int VALU, int MFMA, int BF16 = 0>
 __global__ __launch_bounds__(256) void k(float* out, float seed)
 {
     float f[16];
@@ -21,7 +22,14 @@ __global__ __launch_bounds__(256) void k(float* out, float seed)
             for (int i = 0; i < 16; ++i) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(f[i]) : "v"(g), "v"(h));
         }
 #pragma unroll
-        for (int m = 0; m < MFMA; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(g, h, acc[m], 0, 0, 0);
+        for (int m = 0; m < MFMA; ++m) {
+            if (BF16) {
+                const v4s a = { (short)threadIdx.x, 1, 2, 3 }, b = { 3, 2, 1, (short)threadIdx.x };
+                acc[m] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, acc[m], 0, 0, 0);
+            } else {
+                acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(g, h, acc[m], 0, 0, 0);
+            }
+        }
     }
     float s = 0;
     for (int i = 0; i < 16; ++i) s += f[i];
@@ -29,7 +37,7 @@ __global__ __launch_bounds__(256) void k(float* out, float seed)
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
-template <int VALU, int MFMA>
+template <int VALU, int MFMA, int BF16 = 0>
 static void run(const char* name, int waves_per_simd)
 {
     float* out;
@@ -37,10 +45,10 @@ static void run(const char* name, int waves_per_simd)
     hipMalloc(&out, sizeof(float) * 256 * blocks);
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    hipLaunchKernelGGL((k<VALU, MFMA>), dim3(blocks), dim3(256), 0, 0, out, 1.0f);
+    hipLaunchKernelGGL((k<VALU, MFMA, BF16>), dim3(blocks), dim3(256), 0, 0, out, 1.0f);
     hipDeviceSynchronize();
     hipEventRecord(e0);
-    hipLaunchKernelGGL((k<VALU, MFMA>), dim3(blocks), dim3(256), 0, 0, out, 1.0f);
+    hipLaunchKernelGGL((k<VALU, MFMA, BF16>), dim3(blocks), dim3(256), 0, 0, out, 1.0f);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms = 0;
@@ -58,5 +66,6 @@ int main()
         if (w == 5) { run<1, 0>("valu x16", 5); run<0, 1>("mfma x1", 5); run<1, 1>("valu x16 + mfma x1", 5); run<1, 2>("valu x16 + mfma x2", 5); }
         if (w == 8) { run<1, 0>("valu x16", 8); run<0, 1>("mfma x1", 8); run<1, 1>("valu x16 + mfma x1", 8); run<1, 2>("valu x16 + mfma x2", 8); }
     }
+    run<0, 1, 1>("bf16 mfma 16x16x16 x1", 5); run<1, 1, 1>("valu x16 + bf16 mfma x1", 5); run<0, 2, 1>("bf16 mfma x2", 5); run<1, 2, 1>("valu x16 + bf16 mfma x2", 5);
     return 0;
 }

@@ -527,9 +527,9 @@ __device__ __forceinline__ int ld_coef(const int16_t* p)
     return v;
 }
 
-// waves per SIMD the register budget is set for: colour 4 (106 VGPRs; at 5 = 96 VGPRs the kernel spills), gray 5
+// waves per SIMD the register budget is set for (colour: 84 VGPRs since the chroma column pass runs after the luma halves)
 #ifndef JPEZY_DEC_WAVES
-#define JPEZY_DEC_WAVES 4
+#define JPEZY_DEC_WAVES 5
 #endif
 #ifndef JPEZY_DEC_WAVES_GRAY
 #define JPEZY_DEC_WAVES_GRAY 5
@@ -589,7 +589,8 @@ __global__ __launch_bounds__(64 * WPB, GRAY ? JPEZY_DEC_WAVES_GRAY : JPEZY_DEC_W
     //         with three ballots and their samples are exempt from the guard band below. ----
     const int cq = row, u = cq & 7;
     const int16_t* stage = reinterpret_cast<const int16_t*>(lds);
-    double gtop[8], gbot[8], gc[8];
+    double gtop[8], gbot[8];
+    unsigned cpk[4] = { 0, 0, 0, 0 };                // the chroma column's raw coefficients, two per word
     int cmx = 0, cmn = 0;               // largest / smallest raw coefficient this lane touches
     unsigned long long ac_top, ac_bot, ac_chr = 0;   // lanes whose block column holds a non-zero AC coefficient
     {
@@ -620,17 +621,14 @@ __global__ __launch_bounds__(64 * WPB, GRAY ? JPEZY_DEC_WAVES_GRAY : JPEZY_DEC_W
         if (!GRAY) {
             const int comp = 1 + (cq >> 3);
             const int16_t* bc = stage + (m * BPM + 3 + comp) * 64;
+            // only the eight raw coefficients of the chroma column stay in registers (4 VGPRs); its column pass runs after
+            // the luma halves, when the 32 VGPRs of the two luma columns are free again
 #pragma unroll
-            for (int v = 0; v < 8; ++v) {
-                c[v] = ld_coef(bc + zp[v]);
-                in[v] = (double)c[v] * p.dqscale[(comp * 8 + u) * 8 + v];
-                cmx = max(cmx, c[v]);
-                cmn = min(cmn, c[v]);
-            }
-            if (u == 0) in[0] = cucv_dc * (double)(c[0] * p.dqt[comp * 64]) * 0.25;
+            for (int v = 0; v < 8; ++v) { c[v] = ld_coef(bc + zp[v]); cmx = max(cmx, c[v]); cmn = min(cmn, c[v]); }
             acor = (u ? c[0] : 0) | c[1] | c[2] | c[3] | c[4] | c[5] | c[6] | c[7];
             ac_chr = __ballot(acor != 0);
-            idct8(in, gc);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) cpk[v] = ((unsigned)c[2 * v] & 0xFFFFu) | ((unsigned)c[2 * v + 1] << 16);
         }
     }
     // The block columns of block (m, side) sit in lanes (8*side + k)*4 + m, k = 0..7: bits 0x11111111 << m of the low
@@ -678,6 +676,18 @@ __global__ __launch_bounds__(64 * WPB, GRAY ? JPEZY_DEC_WAVES_GRAY : JPEZY_DEC_W
     unsigned cflags = 0;
     if (!GRAY) {
         {
+            double gc[8];
+            {
+                const int comp = 1 + (cq >> 3);
+                double cin[8];
+#pragma unroll
+                for (int v = 0; v < 8; ++v) {
+                    const int cv_ = (int)(short)(cpk[v >> 1] >> ((v & 1) * 16));
+                    cin[v] = (double)cv_ * p.dqscale[(comp * 8 + u) * 8 + v];
+                }
+                if (u == 0) cin[0] = (JPEZY_S * JPEZY_S) * (double)((int)(short)(cpk[0] & 0xFFFFu) * p.dqt[comp * 64]) * 0.25;
+                idct8(cin, gc);
+            }
             uint32_t* dst = lds + m * C_MCU + (cq >> 3) * C_COMP + u * 2;
 #pragma unroll
             for (int y = 0; y < 8; ++y) *reinterpret_cast<double*>(dst + y * C_PITCH) = gc[y];

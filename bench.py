@@ -2,23 +2,34 @@
 """bench.py -- Mpixels/s of the fused encode (FDCT+quant) stage on MI355X, with its HBM roofline
 fraction and the CPU oracle timed beside it.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload encode4096|decode4096|gray8k|batch1080p]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME]
 
 A *step* is one pass of the hot path over one batch of synthetic input that is already resident in HBM:
 the default workload is BASELINE.json configs[1], one 4096x4096 random-pixel frame per step.  Steps walk
-a ring of distinct frames whose inputs+outputs (8 x 100.7 MB) exceed the 256 MiB Infinity Cache, so the
-kernel really streams from HBM.  N > 1 (launched by torch.distributed.run, one rank per GPU): frames are
-independent, so every rank encodes its own frames (weak scaling, no data-path collective); the RCCL
-gather of coefficient buffers that BASELINE.json's north_star asks for is measured separately and
-reported under "gather", never inside `value`.  The K timed steps are a fixed sequence of K launches (one per
-step, on torch's current stream): they are captured once into a hipGraph and replayed inside the timed region
-(--no-graph launches them one by one: same kernels and work, ~1.5 us more launch gap per step).
+a ring of distinct frames whose inputs+outputs exceed the 256 MiB Infinity Cache, so the kernel really
+streams from HBM.  The K timed steps are a fixed sequence of K launches (one per step, on torch's
+current stream): they are captured once into a hipGraph; a *replay* of that graph is exactly K steps,
+bracketed by barrier + synchronize on both sides.  The replay is repeated R times (--repeats, default 11);
+`ms_per_step` is the MEDIAN replay divided by K (max over ranks per replay), min/max are reported beside it.
+
+--gpus N > 1: when WORLD_SIZE is not set this process starts N copies of itself, one per GPU (RANK /
+LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment) *before it touches the GPU*, and rank 0 prints the
+JSON line; under torch.distributed.run the ranks are taken from the environment as usual.  `value` at N > 1
+is the same workload on every rank (frames are independent: no data-path collective, weak scaling).
+In addition every N > 1 run (and N = 1 with --batch) measures BASELINE configs[3] as north_star states it --
+a batch of 4096 1920x1080 frames sharded by jpezy_amd.sharding.shard_range, strong scaling -- and reports it
+as the object "batch": kernel-only throughput, the RCCL gather of the coefficient buffers to the consumer
+rank, the pipelined end-to-end time (gather overlapped with the kernels chunk by chunk), and the speed-up
+over the same pipeline run on ONE GPU in the same job.
 
 Prints ONE JSON line (rank 0).  `oracle/` is used only for the cpu_baseline leg.
 """
 import argparse
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -37,7 +48,10 @@ WORKLOADS = {
     "gray8k": (7680, 4320, True, 1, "encode", "BASELINE configs[4]: 7680x4320 --gray encode"),
     "batch1080p": (1920, 1080, False, 32, "encode", "BASELINE configs[3] shard: 32 frames 1920x1080 per step"),
     "gray8k_decode": (7680, 4320, True, 1, "decode", "BASELINE configs[4]: 7680x4320 --gray decode (r = g = b = Y)"),
+    "encode4096_jpg": (4096, 4096, False, 1, "encode+entropy",
+                       "4096x4096 planes -> complete .jpg in HBM (FDCT+quant kernel, then the GPU Huffman stage)"),
 }
+BATCH_W, BATCH_H, BATCH_FRAMES = 1920, 1080, 4096      # BASELINE configs[3]
 
 
 def algorithmic_bytes(W, H, gray, direction):
@@ -45,67 +59,303 @@ def algorithmic_bytes(W, H, gray, direction):
     3 B/px of coefficients read + 3 B/px written.  Padded MCU grid for the coefficient side."""
     mc, mr = (W + 15) // 16, (H + 15) // 16
     px = W * H
-    if direction == "encode":
+    if direction.startswith("encode"):
         return 3 * px + mc * mr * (4 if gray else 6) * 128
     return mc * mr * 6 * 128 + 3 * px
 
 
-def cpu_baseline(W, H, gray, budget_s=12.0):
-    """The oracle (a scalar C port of the reference's algorithm) on ONE host core, on a bounded band of
-    MCU rows of the same workload."""
+# ------------------------------------------------------------------------------------------------------------------
+# N > 1 without a launcher: start the ranks ourselves, before any GPU call in this process
+# ------------------------------------------------------------------------------------------------------------------
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(n, argv, timeout=None):
+    """Start `n` copies of the command `argv` (one per rank: RANK, LOCAL_RANK, WORLD_SIZE, LOCAL_WORLD_SIZE,
+    MASTER_ADDR=127.0.0.1, MASTER_PORT in their environment) and wait for them.  Rank 0 inherits stdout (its one JSON
+    line is the job's line); the other ranks' stdout is dropped, stderr is shared.  Returns the first non-zero exit
+    code (0 if every rank succeeded); when a rank fails the others are terminated by PID.  The caller must not have
+    initialised the GPU: the children are plain child processes, nothing is exec'ed over a live HIP context."""
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen(list(argv), env=env, stdout=None if r == 0 else subprocess.DEVNULL))
+    rc, t0 = 0, time.time()
+    live = set(range(n))
+    while live:
+        for r in sorted(live):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            live.discard(r)
+            if code != 0 and rc == 0:
+                rc = code
+                print(f"bench.py: rank {r} exited with code {code}; stopping the other ranks", file=sys.stderr)
+                for q in live:
+                    procs[q].terminate()
+        if timeout is not None and time.time() - t0 > timeout and live:
+            print("bench.py: ranks timed out", file=sys.stderr)
+            for q in live:
+                procs[q].terminate()
+            rc = rc or 124
+            timeout = None
+        time.sleep(0.05)
+    return rc
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# CPU baseline: the oracle (scalar C port of the reference) on the box's host cores
+# ------------------------------------------------------------------------------------------------------------------
+def _host_cores():
+    try:
+        return max(1, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        return os.cpu_count() or 1
+
+
+def _timed_bands(fn, bands, passes, threads):
+    """run fn(y0, y1) over every band `passes` times on `threads` host threads (the C calls release the GIL)"""
+    from concurrent.futures import ThreadPoolExecutor
+    t0 = time.perf_counter()
+    if threads == 1:
+        for _ in range(passes):
+            for y0, y1 in bands:
+                fn(y0, y1)
+    else:
+        def work(band):
+            for _ in range(passes):
+                fn(*band)
+        with ThreadPoolExecutor(max_workers=threads) as ex:
+            list(ex.map(work, bands))
+    return time.perf_counter() - t0
+
+
+def cpu_baseline(W, H, gray, direction, budget_s=8.0):
+    """the oracle's stages on the host, (i) one thread -- the reference is single-threaded --
+    and (ii) MCU-row bands over all host cores, for the compute stage the GPU kernel of this workload replaces
+    (encode: colour+subsample+FDCT+quant+zig-zag; decode: dequant+IDCT+upsample+colour), plus the Huffman stage
+    (tail or head) and the resulting whole-codec rate on one thread.  A bounded band of the workload's frame."""
+    import ctypes as C
     import numpy as np
     from oracle import oracle as O
-    r, g, b = O.synth_rgb(W, min(H, 512))
-    reps = -(-H // min(H, 512))
-    r, g, b = (np.tile(p, reps)[: W * H] for p in (r, g, b))
-    mr = (H + 15) // 16
-    # calibrate on 2 MCU rows, then size the band to the budget
+    L = O.lib()
+    cores = _host_cores()
+    enc = direction.startswith("encode")
+    Hb = min(H, 1024) // 16 * 16 or 16                     # band frame: W x Hb, same width => same memory pattern per row
+    mr = Hb // 16
+    r, g, b = O.synth_rgb(W, min(Hb, 256))
+    reps = -(-Hb // min(Hb, 256))
+    r, g, b = (np.ascontiguousarray(np.tile(p, reps)[: W * Hb]) for p in (r, g, b))
+    mc = (W + 15) // 16
+    u8, i16 = (lambda a: a.ctypes.data_as(C.POINTER(C.c_uint8))), (lambda a: a.ctypes.data_as(C.POINTER(C.c_int16)))
+    if enc:
+        co = np.zeros((mr, mc, 4 if gray else 6, 64), dtype=np.int16)
+        fn = lambda y0, y1: L.jo_encode_coeffs_rows(u8(r), u8(g), u8(b), W, Hb, int(gray), y0, y1, i16(co))  # noqa: E731
+        stage = "colour+subsample+FDCT+quant+zig-zag (ref encoder/jpezy_encoder.hpp:90-172)"
+    else:
+        co = np.zeros((mr, mc, 6, 64), dtype=np.int16)
+        L.jo_encode_coeffs_rows(u8(r), u8(g), u8(b), W, Hb, 0, 0, mr, i16(co))       # real coefficients of the band
+        info = O.make_info(W, Hb)
+        outp = [np.zeros(W * Hb, dtype=np.uint8) for _ in range(3)]
+        fn = lambda y0, y1: L.jo_decode_planes_rows(i16(co), C.byref(info), int(gray), y0, y1, u8(outp[0]), u8(outp[1]), u8(outp[2]))  # noqa: E731
+        stage = "dequant+IDCT+upsample+YCbCr->RGB (ref decoder/jpezy_decoder.hpp:504-578,645-676)"
     t0 = time.perf_counter()
-    O.encode_coeffs(r, g, b, W, H, gray, rows=(0, 2))
-    per_row = (time.perf_counter() - t0) / 2
-    rows = max(2, min(mr, int(budget_s / max(per_row, 1e-9))))
-    passes = max(1, int(budget_s / max(per_row * rows, 1e-9)))
-    t0 = time.perf_counter()
-    for _ in range(passes):
-        O.encode_coeffs(r, g, b, W, H, gray, rows=(0, rows))
-    dt = time.perf_counter() - t0
-    px = rows * 16 * W * passes
-    return {
-        "value": round(px / dt / 1e6, 3), "unit": "Mpixels/s", "cores": 1, "kind": "port",
-        "sample": f"{passes} pass(es) over {rows} of {mr} MCU rows ({px / 1e6:.2f} Mpx) of the {W}x{H} frame, "
-                  f"colour+FDCT+quant+zig-zag stage only, oracle/jpezy_oracle.c -O2 -ffp-contract=off, {dt:.1f} s",
+    fn(0, 1)
+    per_row = max(time.perf_counter() - t0, 1e-6)
+    # (i) one thread
+    rows1 = max(1, min(mr, int(budget_s / per_row)))
+    passes1 = max(1, int(budget_s / (per_row * rows1)))
+    dt1 = _timed_bands(fn, [(0, rows1)], passes1, 1)
+    px1 = rows1 * 16 * W * passes1
+    # (ii) all cores: the band's MCU rows dealt to `cores` threads, each its own contiguous rows
+    per = max(1, mr // cores)
+    bands = [(y, min(y + per, mr)) for y in range(0, per * cores, per) if y < mr][:cores]
+    passesN = max(1, int(0.5 * budget_s / (per_row * per)))
+    dtN = _timed_bands(fn, bands, passesN, len(bands))
+    pxN = sum(y1 - y0 for y0, y1 in bands) * 16 * W * passesN
+    out = {
+        "value": round(px1 / dt1 / 1e6, 3), "unit": "Mpixels/s", "cores": 1, "kind": "port", "stage": stage,
+        "sample": f"{passes1} pass(es) over {rows1} MCU rows ({px1 / 1e6:.1f} Mpx) of a {W}x{Hb} band of the workload's frame, "
+                  f"oracle/jpezy_oracle.c -O2 -ffp-contract=off, {dt1:.1f} s",
+        "all_cores": {"value": round(pxN / dtN / 1e6, 3), "unit": "Mpixels/s", "cores": len(bands),
+                      "sample": f"{len(bands)} threads x {passesN} pass(es) over {per} MCU rows each ({pxN / 1e6:.1f} Mpx), {dtN:.1f} s"},
     }
+    # Huffman stage on one thread (BASELINE.md: compute / Huffman / total split).  Whole band.
+    try:
+        t0 = time.perf_counter()
+        jpg = O.write_jpeg(co, W, Hb, gray=bool(gray and enc))
+        t_tail = time.perf_counter() - t0
+        if enc:
+            t_h, name = t_tail, "encode_huffman + jpezy_writer (ref encoder/jpezy_encoder.hpp:174-225)"
+        else:
+            t0 = time.perf_counter()
+            O.read_jpeg(jpg)
+            t_h, name = time.perf_counter() - t0, "marker parser + decode_huffman (ref decoder/jpezy_decoder.hpp:171-502,583-642)"
+        pxb = W * Hb
+        t_c = pxb / (px1 / dt1)
+        out["huffman_stage"] = {"value": round(pxb / t_h / 1e6, 3), "unit": "Mpixels/s", "cores": 1, "what": name,
+                                "sample": f"one {W}x{Hb} band ({pxb / 1e6:.1f} Mpx, {len(jpg)} B of .jpg), {t_h:.2f} s"}
+        out["total_1core"] = {"value": round(pxb / (t_c + t_h) / 1e6, 3), "unit": "Mpixels/s",
+                              "note": "compute stage + Huffman stage, one thread (what jpezy's own MCU loop does)"}
+    except Exception as e:      # the baseline must never break the bench line
+        out["huffman_stage"] = {"error": str(e)}
+    return out
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="encode4096", choices=sorted(WORKLOADS))
-    ap.add_argument("--ring", type=int, default=0, help="distinct batches in the ring (0 = enough to exceed 512 MiB)")
-    ap.add_argument("--variant", type=int, default=None, help="encode kernel variant (0 FP64 butterflies, 1 FP32 first level)")
-    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--no-gather", action="store_true", help="skip the separate RCCL gather measurement (N>1)")
-    ap.add_argument("--streams", type=int, default=1,
-                    help="frames in flight: step i is launched on stream i %% S (forked from and joined to the timed stream "
-                         "inside the captured graph; every step has its own ring buffers).  Default 1: launches back to back; "
-                         "with 2 the ramp and drain of consecutive launches overlap (pipeline-level number, see DESIGN.md)")
-    ap.add_argument("--pipelined", action="store_true",
-                    help="after the timed region, replay the same K steps with two frames in flight and report the result as "
-                         "a 'pipelined' object beside value (off by default: the default command launches nothing but the "
-                         "timed kernel, so that a rocprofv3 trace of it averages exactly the launches value is made of)")
-    ap.add_argument("--no-graph", action="store_true",
-                    help="launch the timed steps one by one instead of replaying them as one captured hipGraph "
-                         "(the graph saves ~1.5 us of launch gap per 30 us step; same kernels, same work)")
-    ap.add_argument("--force-dist", action="store_true",
-                    help="development aid: initialise torch.distributed (nccl = RCCL) even with one rank, so that the "
-                         "barrier / all_reduce / all_gather calls of the N>1 path run on a single-GPU box")
-    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
-                    help="development aid: run the N>1 control flow with every rank on GPU 0 and the gloo backend "
-                         "(RCCL refuses two ranks on one device); the numbers mean nothing")
-    args = ap.parse_args()
+# ------------------------------------------------------------------------------------------------------------------
+def synth_frames(torch, lo, hi, plane, dev, seed=0x6A70657A79):
+    """planes r,g,b [hi-lo, plane] u8 of global frames [lo, hi): frame f is drawn from its own generator (seed + f),
+    so a frame has the same pixels whichever rank or shard generates it"""
+    n = hi - lo
+    out = torch.empty((3, max(n, 0), plane), dtype=torch.uint8, device=dev)
+    gen = torch.Generator(device=dev)
+    for k in range(n):
+        gen.manual_seed(seed + lo + k)
+        out[:, k] = torch.randint(0, 256, (3, plane), dtype=torch.uint8, device=dev, generator=gen)
+    return out[0], out[1], out[2]
 
+
+def run_batch(args, torch, dist, J, ctx, dev, rank, world, multi, comm_cpu):
+    """BASELINE configs[3]: `--batch-frames` 1920x1080 frames sharded over the ranks (strong scaling).  See the
+    module docstring for what is reported.  comm_cpu: rehearsal on one GPU (gloo cannot move device tensors)."""
+    from jpezy_amd import sharding
+    W, H, F, chunk = BATCH_W, BATCH_H, args.batch_frames, args.batch_chunk
+    plane = W * H
+    cpf = J.coeff_count(W, H, False)
+    lo, hi = sharding.shard_range(F, world, rank)
+    n_local = hi - lo
+    stream = torch.cuda.current_stream(dev)
+    pr, pg, pb = synth_frames(torch, lo, hi, plane, dev)
+    local = torch.empty((max(n_local, 1), cpf), dtype=torch.int16, device=dev)
+
+    def kernels(frames_lo, frames_hi, pr_, pg_, pb_, base, dst):
+        """frames [frames_lo, frames_hi) (global) whose planes start at global frame `base` in pr_/pg_/pb_"""
+        a, b = frames_lo - base, frames_hi - base
+        ctx.fdct_quant_dev(pr_[a:b], pg_[a:b], pb_[a:b], W, H, dst, gray=False, n_frames=b - a, plane_stride=plane,
+                           stream=torch.cuda.current_stream(dev).cuda_stream)
+
+    def sync_all():
+        torch.cuda.synchronize(dev)
+        if multi:
+            dist.barrier()
+
+    def timed(fn, reps=3):
+        ts = []
+        for _ in range(reps):
+            sync_all()
+            t0 = time.perf_counter()
+            fn()
+            sync_all()
+            ts.append(time.perf_counter() - t0)
+        red = torch.tensor(ts, dtype=torch.float64, device="cpu" if comm_cpu else dev)
+        if multi:
+            dist.all_reduce(red, op=dist.ReduceOp.MAX)
+        return statistics.median(red.tolist())
+
+    # (1) kernel-only: every rank encodes its shard, chunk by chunk, into its local buffer
+    def kernel_pass():
+        for a, b in sharding.chunk_spans(lo, hi, chunk):
+            kernels(a, b, pr, pg, pb, lo, local[a - lo:b - lo])
+    kernel_pass()
+    t_kernel = timed(kernel_pass)
+
+    # (2) + (3) gather alone (chunks are copies of the finished local buffer) and the pipelined end-to-end pass
+    comm_dev = "cpu" if comm_cpu else dev
+    out = None
+    if rank == 0:
+        out = torch.empty((F, cpf), dtype=torch.int16, device=comm_dev)
+
+    def chunk_from_local(a, b, dst):
+        if comm_cpu:
+            dst.copy_(local[a - lo:b - lo])
+        else:
+            dst.copy_(local[a - lo:b - lo], non_blocking=True)
+
+    def chunk_encode(a, b, dst):
+        if comm_cpu:
+            kernels(a, b, pr, pg, pb, lo, local[a - lo:b - lo])
+            torch.cuda.synchronize(dev)
+            dst.copy_(local[a - lo:b - lo])
+        else:
+            kernels(a, b, pr, pg, pb, lo, dst)
+
+    def gather_pass():
+        sharding.gather_to_root_pipelined(chunk_from_local, F, cpf, chunk, comm_dev, root=0, out=out)
+
+    def e2e_pass():
+        sharding.gather_to_root_pipelined(chunk_encode, F, cpf, chunk, comm_dev, root=0, out=out)
+
+    t_gather = t_e2e = None
+    if multi:
+        gather_pass()                       # first use builds the point-to-point connections
+        t_gather = timed(gather_pass)
+        e2e_pass()
+        t_e2e = timed(e2e_pass)
+    else:
+        t_e2e = t_kernel                    # one GPU: nothing to gather, the consumer already holds the batch
+
+    # (4) the same pipeline on ONE GPU, in the same job (rank 0 alone; the others wait), and the parity property of the
+    #     sharded path: the gathered batch equals the single-GPU batch bit for bit
+    t_one, same = None, None
+    if multi:
+        if rank == 0:
+            fr, fg, fb = synth_frames(torch, 0, F, plane, dev)
+            full = torch.empty((F, cpf), dtype=torch.int16, device=dev)
+
+            def one_pass():
+                for a, b in sharding.chunk_spans(0, F, chunk):
+                    kernels(a, b, fr, fg, fb, 0, full[a:b])
+            one_pass()
+            ts = []
+            for _ in range(3):
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                one_pass()
+                torch.cuda.synchronize(dev)
+                ts.append(time.perf_counter() - t0)
+            t_one = statistics.median(ts)
+            same = bool(torch.equal(out.to(dev) if comm_cpu else out, full))
+            del fr, fg, fb, full
+        dist.barrier()
+    else:
+        t_one = t_kernel
+
+    if rank != 0:
+        return None
+    px = F * plane
+    bytes_moved = (F - (sharding.shard_range(F, world, 0)[1])) * cpf * 2 if multi else 0
+    res = {
+        "workload": f"BASELINE configs[3]: batch of {F} frames {W}x{H}, sharded by shard_range over {world} GPU(s), strong scaling",
+        "frames": F, "frames_per_rank": sharding.max_shard(F, world), "chunk_frames": chunk,
+        "kernel_only": {"ms": round(t_kernel * 1e3, 3), "Mpixels_per_s": round(px / t_kernel / 1e6, 1),
+                        "note": "every rank encodes its shard; max over ranks; median of 3 passes"},
+        "end_to_end": {"ms": round(t_e2e * 1e3, 3), "Mpixels_per_s": round(px / t_e2e / 1e6, 1),
+                       "note": "inputs resident in each rank's HBM -> whole batch of coefficients on rank 0; gather overlapped with the kernels"},
+        "one_gpu_same_pipeline": {"ms": round(t_one * 1e3, 3), "Mpixels_per_s": round(px / t_one / 1e6, 1),
+                                  "note": "all frames on rank 0's GPU, same chunking, measured in this job"},
+        "speedup_kernel_only": round(t_one / t_kernel, 3),
+        "speedup_end_to_end": round(t_one / t_e2e, 3),
+    }
+    if multi:
+        res["gather"] = {"op": "point-to-point sends to rank 0 (batch_isend_irecv), chunks of the finished local buffers",
+                         "ms": round(t_gather * 1e3, 3), "bytes_into_rank0": bytes_moved,
+                         "GBs_into_rank0": round(bytes_moved / t_gather / 1e9, 2)}
+        hidden = t_kernel + t_gather - t_e2e
+        res["overlap_efficiency"] = round(max(0.0, min(1.0, hidden / max(min(t_kernel, t_gather), 1e-12))), 3)
+        res["gathered_equals_one_gpu_result"] = same
+        if comm_cpu:
+            res["rehearsal"] = "all ranks on GPU 0, gloo + host staging: control flow only, the numbers mean nothing"
+    return res
+
+
+# ------------------------------------------------------------------------------------------------------------------
+def run_rank(args):
     import torch
     import torch.distributed as dist
     import jpezy_amd as J
@@ -113,17 +363,19 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world > 1:
+    if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback for the hot path)")
+    ndev = torch.cuda.device_count()
     if args.rehearse_on_one_gpu:
         local_rank = 0
+    elif local_rank >= ndev:
+        raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {ndev} GPU(s) visible "
+                         "(--rehearse-on-one-gpu runs the N > 1 control flow on one GPU; its numbers mean nothing)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    red_dev = dev                       # where the small reduction tensors live
+    red_dev = dev                               # where the small reduction tensors live
     multi = world > 1 or args.force_dist       # the distributed calls are made
     if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -133,16 +385,16 @@ def main():
         if args.rehearse_on_one_gpu:
             dist.init_process_group("gloo")
             red_dev = torch.device("cpu")
-            args.no_gather = True
         else:
             dist.init_process_group("nccl", device_id=dev)
 
     W, H, gray, fps, direction, desc = WORKLOADS[args.workload]
+    with_entropy = direction == "encode+entropy"
     ctx = J.Context(local_rank)
     if args.variant is not None:
         ctx.set_variant(args.variant)
     plane = W * H
-    ncoef = J.coeff_count(W, H, gray if direction == "encode" else False)
+    ncoef = J.coeff_count(W, H, gray if direction.startswith("encode") else False)
     step_bytes = algorithmic_bytes(W, H, gray, direction) * fps
     ring = args.ring or max(2, -(-(512 << 20) // step_bytes))
 
@@ -152,10 +404,23 @@ def main():
     pr, pg, pb = (torch.randint(0, 256, (ring, fps, plane), dtype=torch.uint8, device=dev, generator=gen) for _ in range(3))
     co = torch.empty((ring, fps, ncoef), dtype=torch.int16, device=dev)
     stream = torch.cuda.current_stream(dev)
+    jpg = jsz = None
+    if with_entropy:
+        cap = J.load_library().jpezy_jpeg_bound(W, H)
+        jpg = torch.empty((ring, fps, cap), dtype=torch.uint8, device=dev)
+        jsz = torch.zeros((ring, fps), dtype=torch.int64, device=dev)
 
     def enc(i):
         k = i % ring
         ctx.fdct_quant_dev(pr[k], pg[k], pb[k], W, H, co[k], gray=gray, n_frames=fps, stream=stream.cuda_stream)
+
+    def entropy(i):
+        k = i % ring
+        ctx.write_jpeg_gpu_dev(co[k], W, H, jpg[k], jsz[k], gray=gray, n_frames=fps, stream=stream.cuda_stream)
+
+    def enc_entropy(i):
+        enc(i)
+        entropy(i)
 
     def dec(i):
         k = i % ring
@@ -166,6 +431,8 @@ def main():
             ctx.fdct_quant_dev(pr[k], pg[k], pb[k], W, H, co[k], gray=False, n_frames=fps, stream=stream.cuda_stream)
         torch.cuda.synchronize(dev)
         step = dec
+    elif with_entropy:
+        step = enc_entropy
     else:
         step = enc
 
@@ -174,55 +441,64 @@ def main():
     torch.cuda.synchronize(dev)
     ctx.fallback_count()           # reset the counter
 
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    if multi:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    graph = None
-    if not args.no_graph:
-        # the K timed steps are a fixed sequence of launches: capture them once, replay them inside the timed region
-        graph = torch.cuda.CUDAGraph()
+    def capture(step_fn, streams=1):
+        nonlocal stream
+        g = torch.cuda.CUDAGraph()
         cap_stream = torch.cuda.Stream(dev)
         cap_stream.wait_stream(stream)
         with torch.cuda.stream(cap_stream):
             stream_saved, stream = stream, cap_stream
-            with torch.cuda.graph(graph, stream=cap_stream):
-                if args.streams > 1:
-                    side = [torch.cuda.Stream(dev) for _ in range(args.streams)]
+            with torch.cuda.graph(g, stream=cap_stream):
+                if streams > 1:
+                    side = [torch.cuda.Stream(dev) for _ in range(streams)]
                     for sd in side:
                         sd.wait_stream(cap_stream)                  # fork
                     for i in range(args.steps):
-                        stream = side[i % args.streams]
-                        step(i)
+                        stream = side[i % streams]
+                        step_fn(i)
                     for sd in side:
                         cap_stream.wait_stream(sd)                  # join
                 else:
                     for i in range(args.steps):
-                        step(i)
+                        step_fn(i)
             stream = stream_saved
         torch.cuda.synchronize(dev)
-        graph.replay()
+        g.replay()                 # instantiate / upload outside the timed region
         torch.cuda.synchronize(dev)
-        ctx.fallback_count()       # reset: only the timed replay is counted
-    t0 = time.perf_counter()
-    ev0.record(stream)
-    if graph is not None:
-        graph.replay()
-    else:
-        for i in range(args.steps):
-            step(i)
-    ev1.record(stream)
-    torch.cuda.synchronize(dev)
-    if multi:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    ev_ms = ev0.elapsed_time(ev1)
+        return g
+
+    graph = None if args.no_graph else capture(step, args.streams)
+    ctx.fallback_count()           # reset: only the timed replays are counted
+
+    # ---- the timed region: R replays of exactly K steps, each bracketed by barrier + synchronize on both sides ----
+    R = max(1, args.repeats)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    wall, evms = [], []
+    for _ in range(R):
+        if multi:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        ev0.record(stream)
+        if graph is not None:
+            graph.replay()
+        else:
+            for i in range(args.steps):
+                step(i)
+        ev1.record(stream)
+        torch.cuda.synchronize(dev)
+        if multi:
+            dist.barrier()
+        wall.append(time.perf_counter() - t0)
+        evms.append(ev0.elapsed_time(ev1))
     nfallback = ctx.fallback_count()
 
-    t = torch.tensor([elapsed, ev_ms], dtype=torch.float64, device=red_dev)
+    t = torch.tensor([wall, evms], dtype=torch.float64, device=red_dev)
     if multi:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed, ev_ms = float(t[0]), float(t[1])
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)       # per replay: the slowest rank
+    wall, evms = t[0].tolist(), t[1].tolist()
+    elapsed = statistics.median(wall)
+    ev_ms = statistics.median(evms)
 
     # besides the vendor peak, report a device-copy bandwidth measured on this box with the same byte count
     # and the same ring (one plain copy kernel per step: half the bytes read, half written)
@@ -243,29 +519,37 @@ def main():
         copy_gbs = 2 * half * reps / (c0.elapsed_time(c1) * 1e-3) / 1e9
         del src_bufs, dst_bufs
 
+    # entropy stage alone (workload encode4096_jpg): its own launch sequence, timed with HIP events on the same stream
+    entropy_roof = None
+    if with_entropy and rank == 0:
+        torch.cuda.synchronize(dev)
+        sizes = jsz[0].tolist()
+        if min(sizes) <= 0:
+            raise SystemExit(f"GPU entropy stage reported {sizes}")
+        g3 = capture(entropy)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ems = []
+        for _ in range(R):
+            torch.cuda.synchronize(dev)
+            e0.record(stream)
+            g3.replay()
+            e1.record(stream)
+            torch.cuda.synchronize(dev)
+            ems.append(e0.elapsed_time(e1))
+        ent_ms = statistics.median(ems) / args.steps
+        ebytes = ncoef * 2 * fps + int(sum(sizes))         # coefficients read once + the .jpg bytes written once
+        ea = ebytes / (ent_ms * 1e-3) / 1e9
+        entropy_roof = {"bound": "hbm", "achieved": round(ea, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(ea / HBM_PEAK_GBS, 4), "traffic": None,
+                        "kernel": "entropy stage (block_bits + scans + emit + ff_count + stuff), all launches of one frame",
+                        "algorithmic_bytes_per_step": ebytes, "avg_step_ms_hip_events": round(ent_ms, 5),
+                        "jpg_bytes_per_frame": int(sum(sizes) / len(sizes))}
+        del g3
+
     # Pipeline-level number, reported beside `value` and never part of it: the same K steps with two frames in flight
-    # (two streams inside one graph; every step has its own ring buffers).  The ramp and drain of consecutive launches
-    # overlap, which a single in-order stream cannot do.
     pipelined = None
     if args.pipelined and rank == 0 and graph is not None and args.streams == 1 and ring >= 2:
-        g2 = torch.cuda.CUDAGraph()
-        cap_stream = torch.cuda.Stream(dev)
-        cap_stream.wait_stream(stream)
-        with torch.cuda.stream(cap_stream):
-            stream_saved = stream
-            with torch.cuda.graph(g2, stream=cap_stream):
-                side = [torch.cuda.Stream(dev) for _ in range(2)]
-                for sd in side:
-                    sd.wait_stream(cap_stream)
-                for i in range(args.steps):
-                    stream = side[i % 2]
-                    step(i)
-                for sd in side:
-                    cap_stream.wait_stream(sd)
-            stream = stream_saved
-        torch.cuda.synchronize(dev)
-        g2.replay()
-        torch.cuda.synchronize(dev)
+        g2 = capture(step, 2)
         p0 = time.perf_counter()
         g2.replay()
         torch.cuda.synchronize(dev)
@@ -276,29 +560,13 @@ def main():
                      "note": "this rank only; measured after the timed region; not part of value"}
         del g2
 
-    gather = None
-    if multi and not args.no_gather:
-        # north_star: gather the coefficient buffers over xGMI -- jpezy_amd.sharding.gather_coefficients,
-        # one all_gather of this rank's step output (fps frames per rank).
-        from jpezy_amd import sharding
-        src = co[0].reshape(-1)
-        for _ in range(3):
-            sharding.gather_coefficients(src, fps * world, ncoef)
-        torch.cuda.synchronize(dev)
-        dist.barrier()
-        g0 = time.perf_counter()
-        reps = 10
-        for _ in range(reps):
-            sharding.gather_coefficients(src, fps * world, ncoef)
-        torch.cuda.synchronize(dev)
-        dist.barrier()
-        gdt = (time.perf_counter() - g0) / reps
-        gt = torch.tensor([gdt], dtype=torch.float64, device=dev)
-        dist.all_reduce(gt, op=dist.ReduceOp.MAX)
-        gdt = float(gt[0])
-        gather = {"op": "all_gather_into_tensor(int16 coefficients of one step)", "bytes_per_rank": src.numel() * 2,
-                  "ms": round(gdt * 1e3, 4), "algbw_GBs": round(src.numel() * 2 * world / gdt / 1e9, 2),
-                  "note": "measured after the timed region; not part of value"}
+    batch = None
+    if (multi and not args.no_batch) or args.batch:
+        del graph
+        graph = None
+        del pr, pg, pb, co
+        torch.cuda.empty_cache()
+        batch = run_batch(args, torch, dist, J, ctx, dev, rank, world, world > 1, args.rehearse_on_one_gpu)
 
     if rank == 0:
         px_per_step = plane * fps
@@ -306,52 +574,114 @@ def main():
         ms_per_step = elapsed * 1e3 / args.steps
         kern_ms = ev_ms / args.steps
         achieved = step_bytes / (kern_ms * 1e-3) / 1e9
-        traffic = None
+        traffic = tsrc = None
         tfile = ROOT / "profiles" / "traffic.json"
         if tfile.exists():
             try:
-                traffic = json.loads(tfile.read_text()).get(args.workload)
+                tj = json.loads(tfile.read_text())
+                traffic = tj.get(args.workload, {}).get("bytes_per_launch")
+                tsrc = tj.get(args.workload, {}).get("source")
             except Exception:
                 traffic = None
+        if with_entropy:
+            traffic = None
+        metric = {"encode": "Mpixels/s encode (FDCT+quant)", "decode": "Mpixels/s decode (dequant+IDCT)",
+                  "encode+entropy": "Mpixels/s encode (FDCT+quant + GPU Huffman stage)"}[direction]
+        kernel = ("f32::fdct_quant_f32_kernel" if args.variant in (None, 1) else "fdct_quant_kernel") \
+            if direction.startswith("encode") else "dequant_idct_kernel"
         out = {
-            "metric": "Mpixels/s encode (FDCT+quant)" if direction == "encode" else "Mpixels/s decode (dequant+IDCT)",
+            "metric": metric,
             "value": round(total_px / elapsed / 1e6, 2),
             "unit": "Mpixels/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 5),
+            "ms_per_step_min": round(min(wall) * 1e3 / args.steps, 5),
+            "ms_per_step_max": round(max(wall) * 1e3 / args.steps, 5),
+            "repeats": R,
+            "timing": f"median of {R} replays of exactly {args.steps} steps; each replay bracketed by barrier + synchronize, max over ranks",
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             # the arithmetic the path computes in: encode variant 1 = FP32 first level (FP64 only on guard-band hits),
             # encode variant 0 and decode = FP64; either way the results are the reference's FP64 results bit for bit
-            "dtype": "f32+f64 guard" if (direction == "encode" and args.variant in (None, 1)) else "f64",
+            "dtype": "f32+f64 guard" if (direction.startswith("encode") and args.variant in (None, 1)) else "f64",
             "data": "synthetic",
             "config": {"workload": desc, "name": args.workload, "width": W, "height": H, "mode": "gray" if gray else "color",
                        "frames_per_step": fps, "ring_batches": ring, "pixels_per_step_per_gpu": px_per_step,
                        "inputs": "iid uniform u8 r,g,b planes resident in HBM", "parallelism": f"frames x{world}",
-                       "submission": "one launch per step" + ("" if args.no_graph else ", the K steps captured once and replayed as a hipGraph")
+                       "submission": ("one launch per step" if not with_entropy else "FDCT launch + entropy-stage launches per step")
+                                     + ("" if args.no_graph else ", the K steps captured once and replayed as a hipGraph")
                                      + ("" if args.streams <= 1 else f", {args.streams} steps in flight on {args.streams} streams")},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": ("f32::fdct_quant_f32_kernel" if args.variant in (None, 1) else "fdct_quant_kernel")
-                         if direction == "encode" else "dequant_idct_kernel",
-                         "algorithmic_bytes_per_launch": step_bytes, "avg_launch_ms_hip_events": round(kern_ms, 5),
-                         "device_copy_GBs_measured": round(copy_gbs, 1), "frac_of_device_copy": round(achieved / copy_gbs, 4)},
-            "exact_fallbacks_per_step": round(nfallback / max(1, args.steps), 2),
+            "exact_fallbacks_per_step": round(nfallback / max(1, args.steps * R), 2),
         }
+        if not with_entropy:
+            out["roofline"] = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": tsrc,
+                               "kernel": kernel,
+                               "algorithmic_bytes_per_launch": step_bytes, "avg_launch_ms_hip_events": round(kern_ms, 5),
+                               "avg_launch_ms_min_max": [round(min(evms) / args.steps, 5), round(max(evms) / args.steps, 5)],
+                               "device_copy_GBs_measured": round(copy_gbs, 1), "frac_of_device_copy": round(achieved / copy_gbs, 4)}
+        else:
+            out["roofline"] = entropy_roof
+            out["roofline"]["note"] = ("the step's dominant cost is the entropy stage; the FDCT kernel's own roofline is the "
+                                       "default workload's line")
         if pipelined:
             out["pipelined"] = pipelined
-        if gather:
-            out["gather"] = gather
+        if batch:
+            out["batch"] = batch
         if world == 1 and not args.no_cpu:
-            out["cpu_baseline"] = cpu_baseline(W, H, gray)
+            out["cpu_baseline"] = cpu_baseline(W, H, gray, direction)
         print(json.dumps(out), flush=True)
 
     ctx.close()
     if multi:
         dist.destroy_process_group()
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--repeats", type=int, default=11, help="replays of the K-step sequence; ms_per_step is their median")
+    ap.add_argument("--workload", default="encode4096", choices=sorted(WORKLOADS))
+    ap.add_argument("--ring", type=int, default=0, help="distinct batches in the ring (0 = enough to exceed 512 MiB)")
+    ap.add_argument("--variant", type=int, default=None, help="encode kernel variant (0 FP64 butterflies, 1 FP32 first level)")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--batch", action="store_true", help="measure the configs[3] batch pipeline also at N = 1")
+    ap.add_argument("--no-batch", action="store_true", help="N > 1: skip the configs[3] batch measurement")
+    ap.add_argument("--batch-frames", type=int, default=None,
+                    help=f"frames of the configs[3] batch (default {BATCH_FRAMES}; 16 in --rehearse-on-one-gpu)")
+    ap.add_argument("--batch-chunk", type=int, default=64, help="frames per launch / per transfer of the batch pipeline")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="frames in flight: step i is launched on stream i %% S (forked from and joined to the timed stream "
+                         "inside the captured graph; every step has its own ring buffers).  Default 1: launches back to back")
+    ap.add_argument("--pipelined", action="store_true",
+                    help="after the timed region, replay the same K steps with two frames in flight and report the result as "
+                         "a 'pipelined' object beside value (off by default: the default command launches nothing but the "
+                         "timed kernel, so that a rocprofv3 trace of it averages exactly the launches value is made of)")
+    ap.add_argument("--no-graph", action="store_true",
+                    help="launch the timed steps one by one instead of replaying them as one captured hipGraph")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="development aid: initialise torch.distributed (nccl = RCCL) even with one rank")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="development aid: run the N > 1 control flow with every rank on GPU 0, the gloo backend and host "
+                         "staging (RCCL refuses two ranks on one device); the numbers mean nothing")
+    args = ap.parse_args(argv)
+    if args.batch_frames is None:
+        args.batch_frames = 16 if args.rehearse_on_one_gpu else BATCH_FRAMES
+    return args
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher: be the launcher.  Nothing above has touched the GPU (torch is not even imported yet).
+        sys.exit(spawn_ranks(args.gpus, [sys.executable, str(Path(__file__).resolve()), *argv]))
+    run_rank(args)
 
 
 if __name__ == "__main__":

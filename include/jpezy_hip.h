@@ -11,6 +11,17 @@
  * context is used by one thread at a time; distinct contexts (one per GPU) may run concurrently.
  * There is NO CPU fallback: without a HIP device every compute entry point fails with JPEZY_E_NODEVICE.
  *
+ * Device pointers: every coefficient pointer handed to a *_dev / *_gpu entry point must be 16-byte aligned (the
+ * kernels move coefficients as 16-byte accesses; one MCU is 768 or 512 bytes, so only the base matters) -- a
+ * misaligned one is refused with JPEZY_E_BADARG.  Pixel planes may have any alignment (an unaligned kernel variant
+ * takes them).
+ * Streams: the *_dev entry points are asynchronous on the caller's stream and one context may be driven on several
+ * streams by its one thread.  The context-wide device tables (dequantiser constants of jpezy_dequant_idct*_dev, the
+ * cached JFIF header of jpezy_write_jpeg_gpu_dev) are rewritten only when the caller's tables / comment / size
+ * change; the library then waits for the WHOLE device first (launches on other streams may still read them), and it
+ * refuses (JPEZY_E_BADARG) to do so while `stream` is being captured into a hipGraph: make the first call with new
+ * tables outside the capture.
+ *
  * Coefficient buffer layout (both directions), per frame:
  *     int16_t coeffs[mcu_rows][mcu_cols][B][64]
  * MCUs row-major with mcu_cols = ceil(W/16), mcu_rows = ceil(H/16) (encoder/jpezy_encoder.hpp:55-56);

@@ -9,6 +9,7 @@
 #include <cstring>
 #include <algorithm>
 #include <atomic>
+#include <new>
 #include <string>
 #include <thread>
 #include <vector>
@@ -40,6 +41,28 @@ int hip_err(hipError_t e, const char* what)
         hipError_t e__ = (expr);                          \
         if (e__ != hipSuccess) return hip_err(e__, #expr); \
     } while (0)
+
+// No exception crosses the C ABI (include/jpezy_hip.h): every extern "C" body that allocates host memory is a
+// function-try-block ending in JPEZY_CATCH.
+#define JPEZY_CATCH                                                                                         \
+    catch (const std::bad_alloc&) { return set_err(JPEZY_E_NOSPACE, "out of host memory"); }                \
+    catch (const std::exception& e) { return set_err(JPEZY_E_HIP, std::string("unexpected exception: ") + e.what()); }
+
+// coefficient buffers are moved with 16-byte accesses (one MCU = 768 or 512 bytes, so only the base matters)
+inline bool aligned16(const void* p) { return ((uintptr_t)p & 15u) == 0; }
+
+// Context-wide device tables (dequantiser constants, cached JFIF header) may be read by launches still in flight on ANY
+// stream the caller drives this context with: before rewriting them, wait for the whole device; and never from inside
+// a stream capture (a synchronisation there would invalidate the capture).
+int drain_before_table_rewrite(hipStream_t s, const char* what)
+{
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &st) == hipSuccess && st != hipStreamCaptureStatusNone)
+        return set_err(JPEZY_E_BADARG, std::string(what) + ": new tables/header cannot be uploaded while the stream is being captured; "
+                                                            "make the first call with these arguments outside the capture");
+    HIP_TRY(hipDeviceSynchronize());
+    return JPEZY_OK;
+}
 
 const int kQt[2][64] = { JPEZY_QT_LUMA_INIT, JPEZY_QT_CHROMA_INIT };
 const unsigned char kZzInv[64] = JPEZY_ZZ_INV_INIT;   // natural index -> zig-zag position
@@ -130,7 +153,11 @@ jpezy_ctx* jpezy_ctx_create(int device)
         set_err(JPEZY_E_NODEVICE, "device index out of range");
         return nullptr;
     }
-    jpezy_ctx* c = new jpezy_ctx;
+    jpezy_ctx* c = new (std::nothrow) jpezy_ctx;
+    if (!c) {
+        set_err(JPEZY_E_NOSPACE, "out of host memory");
+        return nullptr;
+    }
     c->device = device;
     std::vector<DeviceTables> hbuf(1); // 33 KB: off the stack, and private to this call (contexts may be created concurrently)
     DeviceTables& h = hbuf[0];
@@ -277,6 +304,7 @@ int jpezy_fdct_quant_dev(jpezy_ctx* c, const uint8_t* d_r, const uint8_t* d_g, c
 {
     if (int rc = check_dims(c, W, H, n_frames)) return rc;
     if (!d_r || !d_g || !d_b || !d_coeffs) return set_err(JPEZY_E_BADARG, "null device pointer");
+    if (!aligned16(d_coeffs)) return set_err(JPEZY_E_BADARG, "d_coeffs must be 16-byte aligned");
     if (plane_stride < (size_t)W * H) return set_err(JPEZY_E_BADARG, "plane_stride smaller than W*H");
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t s = (hipStream_t)stream;
@@ -355,8 +383,8 @@ static int upload_dequant(jpezy_ctx* c, const uint16_t qt[4][64], const uint8_t 
     uint16_t sel[3][64];
     for (int k = 0; k < 3; ++k) std::memcpy(sel[k], qt[comp_tq[k] & 3], sizeof sel[k]);
     if (c->dq_valid && !std::memcmp(sel, c->dq_cache, sizeof sel)) return JPEZY_OK;
-    // A previous launch may still be reading the tables: drain the stream before rewriting them.
-    HIP_TRY(hipStreamSynchronize(s));
+    // A previous launch -- on this or another stream -- may still be reading the tables.
+    if (int rc = drain_before_table_rewrite(s, "dequant_idct")) return rc;
     static thread_local double h_scale[3][8][8];
     static thread_local int h_qt[3][64];
     const double S = JPEZY_INV_SQRT2;
@@ -385,6 +413,7 @@ int jpezy_dequant_idct_dev(jpezy_ctx* c, const int16_t* d_coeffs, const uint16_t
 {
     if (int rc = check_dims(c, W, H, n_frames)) return rc;
     if (!d_coeffs || !qt || !comp_tq || !d_r || !d_g || !d_b) return set_err(JPEZY_E_BADARG, "null pointer");
+    if (!aligned16(d_coeffs)) return set_err(JPEZY_E_BADARG, "d_coeffs must be 16-byte aligned");
     if (plane_stride < (size_t)W * H) return set_err(JPEZY_E_BADARG, "plane_stride smaller than W*H");
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t s = (hipStream_t)stream;
@@ -492,6 +521,7 @@ int jpezy_dequant_idct_generic_dev(jpezy_ctx* c, const int16_t* d_coeffs, const 
 {
     if (int rc = check_dims(c, W, H, 1)) return rc;
     if (!d_coeffs || !qt || !comp_h || !comp_v || !comp_tq || !d_r || !d_g || !d_b) return set_err(JPEZY_E_BADARG, "null pointer");
+    if (!aligned16(d_coeffs)) return set_err(JPEZY_E_BADARG, "d_coeffs must be 16-byte aligned");
     HIP_TRY(hipSetDevice(c->device));
     return generic_dev_core(c, d_coeffs, qt, ncomp, comp_h, comp_v, comp_tq, W, H, gray, precision, d_r, d_g, d_b, (hipStream_t)stream,
                             nullptr);
@@ -534,18 +564,19 @@ int jpezy_dequant_idct_generic(jpezy_ctx* c, const int16_t* coeffs, const uint16
 }
 
 long jpezy_write_jpeg(const int16_t* coeffs, int W, int H, int gray, const char* comment, uint8_t* out, size_t cap)
-{
+try {
     std::string err;
     const long n = jpezy_host::write_jpeg(coeffs, W, H, gray != 0, comment, out, cap, &err);
     if (n < 0) g_err = err;
     return n;
 }
+JPEZY_CATCH
 
 size_t jpezy_jpeg_bound(int W, int H) { return jpezy_host::jpeg_bound(W, H); }
 
 int jpezy_write_jpeg_batch(const int16_t* coeffs, int W, int H, int gray, int n_frames, const char* comment, uint8_t* out,
                            size_t cap, long* sizes, int threads)
-{
+try {
     if (!coeffs || !out || !sizes || n_frames <= 0) return set_err(JPEZY_E_BADARG, "write_jpeg_batch: bad argument");
     const size_t cpf = jpezy_coeff_count(W, H, gray);
     if (!cpf) return set_err(JPEZY_E_BADARG, "write_jpeg_batch: bad dimensions");
@@ -566,6 +597,7 @@ int jpezy_write_jpeg_batch(const int16_t* coeffs, int W, int H, int gray, int n_
     for (auto& t : pool) t.join();
     return failed.load() ? set_err(JPEZY_E_FORMAT, "write_jpeg_batch: at least one frame failed (see sizes[])") : JPEZY_OK;
 }
+JPEZY_CATCH
 
 // ---- GPU entropy coding: same bytes as jpezy_write_jpeg, coefficients already on the device ----
 namespace {
@@ -690,6 +722,7 @@ int jpezy_write_jpeg_gpu_dev(jpezy_ctx* c, const int16_t* d_coeffs, int W, int H
     namespace E = jpezy_dev::entropy;
     if (int rc = check_dims(c, W, H, n_frames)) return rc;
     if (!d_coeffs || !d_out || !d_sizes) return set_err(JPEZY_E_BADARG, "write_jpeg_gpu_dev: null pointer");
+    if (!aligned16(d_coeffs)) return set_err(JPEZY_E_BADARG, "write_jpeg_gpu_dev: d_coeffs must be 16-byte aligned");
     HIP_TRY(hipSetDevice(c->device));
     if (int rc = ensure_code_tables(c)) return rc;
     hipStream_t s = (hipStream_t)stream;
@@ -699,7 +732,7 @@ int jpezy_write_jpeg_gpu_dev(jpezy_ctx* c, const int16_t* d_coeffs, int W, int H
     if (!hdr_len) return set_err(JPEZY_E_BADARG, "write_jpeg_gpu_dev: comment too long");
     if (c->e_hdr_len != hdr_len || std::memcmp(c->e_hdr_host, hdr, hdr_len)) {
         if (int rc = c->e_hdr.reserve(sizeof hdr)) return rc;
-        HIP_TRY(hipStreamSynchronize(s));                    // an earlier launch may still read the old header
+        if (int rc = drain_before_table_rewrite(s, "write_jpeg_gpu_dev")) return rc;   // an earlier launch (any stream) may still read the old header
         HIP_TRY(hipMemcpy(c->e_hdr.p, hdr, hdr_len, hipMemcpyHostToDevice));
         std::memcpy(c->e_hdr_host, hdr, hdr_len);
         c->e_hdr_len = hdr_len;
@@ -750,7 +783,7 @@ int jpezy_write_jpeg_gpu_dev(jpezy_ctx* c, const int16_t* d_coeffs, int W, int H
 
 int jpezy_write_jpeg_gpu_batch(jpezy_ctx* c, const int16_t* d_coeffs, int W, int H, int gray, int n_frames, const char* comment,
                                uint8_t* out, size_t cap, long* sizes)
-{
+try {
     if (int rc = check_dims(c, W, H, n_frames)) return rc;
     if (!d_coeffs || !out || !sizes) return set_err(JPEZY_E_BADARG, "write_jpeg_gpu: null pointer");
     HIP_TRY(hipSetDevice(c->device));
@@ -768,6 +801,7 @@ int jpezy_write_jpeg_gpu_batch(jpezy_ctx* c, const int16_t* d_coeffs, int W, int
     }
     return any_failed ? set_err(JPEZY_E_FORMAT, "write_jpeg_gpu: at least one frame failed (see sizes[])") : JPEZY_OK;
 }
+JPEZY_CATCH
 
 long jpezy_write_jpeg_gpu(jpezy_ctx* c, const int16_t* d_coeffs, int W, int H, int gray, const char* comment, uint8_t* out, size_t cap)
 {
@@ -782,7 +816,7 @@ long jpezy_write_jpeg_gpu(jpezy_ctx* c, const int16_t* d_coeffs, int W, int H, i
 // planar RGB on the host -> .jpg bytes on the host, both stages on the GPU (what encoder::encode does end to end)
 long jpezy_encode_jpeg(jpezy_ctx* c, const uint8_t* r, const uint8_t* g, const uint8_t* b, int W, int H, int gray, const char* comment,
                        uint8_t* out, size_t cap)
-{
+try {
     if (int rc = check_dims(c, W, H, 1)) return rc;
     if (!r || !g || !b || !out) return set_err(JPEZY_E_BADARG, "encode_jpeg: null pointer");
     HIP_TRY(hipSetDevice(c->device));
@@ -798,6 +832,7 @@ long jpezy_encode_jpeg(jpezy_ctx* c, const uint8_t* r, const uint8_t* g, const u
         return rc;
     return jpezy_write_jpeg_gpu(c, (const int16_t*)c->e_coef.p, W, H, gray, comment, out, cap);
 }
+JPEZY_CATCH
 
 // ---- GPU Huffman decoding (decode side) ----
 namespace {
@@ -829,6 +864,7 @@ bool build_dev_table(jpezy_dev::huffdec::Table& t, const uint8_t bits[16], const
 // host decode + upload: the authoritative path for everything the GPU decoder does not take or is unsure about
 int read_jpeg_host_to_device(jpezy_ctx* c, const uint8_t* data, size_t len, jpezy_frame_info* info, int16_t* d_coeffs, size_t total)
 {
+    if (total / 64 > 4 * len) return set_err(JPEZY_E_FORMAT, "scan too short for the declared dimensions");
     std::vector<int16_t> tmp(total);
     std::string err;
     const int rc = jpezy_host::read_jpeg(data, len, info, tmp.data(), tmp.size(), &err);
@@ -840,7 +876,7 @@ int read_jpeg_host_to_device(jpezy_ctx* c, const uint8_t* data, size_t len, jpez
 }  // namespace
 
 int jpezy_read_jpeg_gpu(jpezy_ctx* c, const uint8_t* data, size_t len, jpezy_frame_info* info, int16_t* d_coeffs, size_t coeff_cap)
-{
+try {
     namespace HD = jpezy_dev::huffdec;
     namespace E = jpezy_dev::entropy;
     if (!c) return set_err(JPEZY_E_BADARG, "null context");
@@ -855,6 +891,7 @@ int jpezy_read_jpeg_gpu(jpezy_ctx* c, const uint8_t* data, size_t len, jpezy_fra
     const int bpm = info->blocks_per_mcu;
     const size_t total_blocks = nmcu * (size_t)bpm, total = total_blocks * 64;
     if (coeff_cap < total) return set_err(JPEZY_E_NOSPACE, "read_jpeg_gpu: coefficient buffer too small");
+    if (!aligned16(d_coeffs)) return set_err(JPEZY_E_BADARG, "read_jpeg_gpu: d_coeffs must be 16-byte aligned");
 
     // what the GPU decoder takes: no restart intervals, at most 48 blocks per MCU (3 components of 4 x 4), every selected table present
     bool gpu_ok = info->restart_interval == 0 && bpm <= 48 && total_blocks < 0xFFFFFFFFull && setup.scan_pos < len;
@@ -1023,11 +1060,12 @@ int jpezy_read_jpeg_gpu(jpezy_ctx* c, const uint8_t* data, size_t len, jpezy_fra
     c->h_last_passes = passes;
     return JPEZY_OK;
 }
+JPEZY_CATCH
 
 // decoder::decode end to end (ref decoder/jpezy_decoder.hpp:76-134): .jpg bytes in, planar r,g,b out
 int jpezy_decode_jpeg(jpezy_ctx* c, const uint8_t* data, size_t len, int gray, jpezy_frame_info* info, uint8_t* r, uint8_t* g, uint8_t* b,
                       size_t plane_cap)
-{
+try {
     if (!c || !info) return set_err(JPEZY_E_BADARG, "decode_jpeg: bad argument");
     int rc = jpezy_read_jpeg_gpu(c, data, len, info, nullptr, 0);           // header only
     if (rc < 0) return rc;
@@ -1036,6 +1074,8 @@ int jpezy_decode_jpeg(jpezy_ctx* c, const uint8_t* data, size_t len, int gray, j
     if (int rc2 = check_dims(c, W, H, 1)) return rc2;
     if (plane_cap < (size_t)W * H) return set_err(JPEZY_E_NOSPACE, "decode_jpeg: plane buffers too small");
     const size_t ncoef = (size_t)info->mcu_cols * info->mcu_rows * info->blocks_per_mcu * 64;
+    // sized from untrusted SOF0 fields: a block costs at least 2 bits of scan (1-bit DC code + 1-bit EOB code)
+    if (ncoef / 64 > 4 * len) return set_err(JPEZY_E_FORMAT, "decode_jpeg: scan too short for the declared dimensions");
     const uint8_t tq[3] = { (uint8_t)info->Tq[0], (uint8_t)info->Tq[1], (uint8_t)info->Tq[2] };
     const bool own_layout = info->ncomp == 3 && info->precision == 8 && info->H[0] == 2 && info->V[0] == 2 && info->H[1] == 1 &&
                             info->V[1] == 1 && info->H[2] == 1 && info->V[2] == 1;
@@ -1066,13 +1106,14 @@ int jpezy_decode_jpeg(jpezy_ctx* c, const uint8_t* data, size_t len, int gray, j
     HIP_TRY(hipStreamSynchronize(c->stream));
     return JPEZY_OK;
 }
+JPEZY_CATCH
 
 // Many files: the per-file pipeline is latency-bound (small launches, five host synchronisations), so files are decoded
 // concurrently -- up to 8 in flight, each on a child context of its own (stream, scratch, quantiser tables), one host
 // thread per child.  Files are independent (ref decoder objects are per file): status[i] is file i's own result.
 int jpezy_decode_jpeg_batch(jpezy_ctx* c, int n, const uint8_t* const* data, const size_t* len, int gray, jpezy_frame_info* info,
                             uint8_t* const* r, uint8_t* const* g, uint8_t* const* b, const size_t* plane_cap, int* status)
-{
+try {
     if (!c || n < 0 || (n > 0 && (!data || !len || !info || !r || !g || !b || !plane_cap || !status)))
         return set_err(JPEZY_E_BADARG, "decode_jpeg_batch: bad argument");
     if (n == 0) return JPEZY_OK;
@@ -1101,16 +1142,18 @@ int jpezy_decode_jpeg_batch(jpezy_ctx* c, int n, const uint8_t* const* data, con
         if (status[i] < 0) return set_err(status[i], "decode_jpeg_batch: file " + std::to_string(i) + ": " + msg[(size_t)i]);
     return JPEZY_OK;
 }
+JPEZY_CATCH
 
 int jpezy_ctx_last_huffdec_passes(jpezy_ctx* c) { return c ? c->h_last_passes : 0; }
 void jpezy_ctx_set_huffdec_min_bytes(jpezy_ctx* c, size_t n) { if (c) c->h_min_bytes = n; }
 
 int jpezy_read_jpeg(const uint8_t* data, size_t len, jpezy_frame_info* info, int16_t* coeffs, size_t coeff_cap)
-{
+try {
     std::string err;
     const int rc = jpezy_host::read_jpeg(data, len, info, coeffs, coeff_cap, &err);
     if (rc < 0) g_err = err;
     return rc;
 }
+JPEZY_CATCH
 
 }  // extern "C"

@@ -223,10 +223,12 @@ __global__ __launch_bounds__(WGS) void sync_kernel(const Setup* gS, const uint32
     if (live) {
         last_entry[i] = my_last;
         nblocks_out[i] = nb;
-        if (my_exit != exit_before) {
-            exit_state[i] = my_exit;
-            atomicAdd(changed, 1u);                        // number of lanes whose exit state moved in this launch
-        }
+        // a launch cut off by max_inner can leave a lane whose predecessor's exit moved after the lane last decoded
+        // (A -> B -> A inside the launch leaves exit_before == my_exit): such a lane is still pending and must keep
+        // the host iterating, or a stale nblocks/last_entry would pass for the fixed point
+        const bool pending = sh_exit[t] != my_last;
+        if (my_exit != exit_before) exit_state[i] = my_exit;
+        if (my_exit != exit_before || pending) atomicAdd(changed, 1u);   // lanes that moved, or still have to, in this launch
     }
 }
 

@@ -2,11 +2,18 @@
 over xGMI on ROCm, "gloo" in the CPU tests).
 
 Frames of a batch are independent (the only cross-MCU state of the reference, pre_DC and the bit cursor, lives
-in the per-frame serial Huffman tail), so the hot path shards with NO data-path collective: rank k encodes the
-contiguous frame range shard_range(n_frames, world, k).  BASELINE.json's north_star additionally asks for the
-int16 coefficient buffers to be gathered over xGMI; gather_coefficients() does that with one all_gather of
-equal, padded chunks (8 ranks x 3.2 GB for the 4096-frame 1080p batch -- bounded by the 7 x ~153 GB/s links of
-the receiving GPU, so it is reported separately from the kernel throughput).
+in the per-frame serial Huffman tail; the loop being sharded is the MCU loop of encoder::encode, ref
+encoder/jpezy_encoder.hpp:55-67, run once per frame), so the hot path shards with NO data-path collective:
+rank k encodes the contiguous frame range shard_range(n_frames, world, k).  BASELINE.json's north_star
+additionally asks for the int16 coefficient buffers to be gathered over xGMI:
+
+  gather_to_root_pipelined()  the production form: frames are encoded in chunks of `chunk_frames`; while chunk c+1
+                              is being encoded on the compute stream, chunk c travels to the consumer rank (the
+                              one that writes the files) as point-to-point sends on a side stream.  Only the
+                              consumer holds the whole batch (7 x 3.2 GB into one GPU at 8 ranks is
+                              bounded by that GPU's 7 xGMI links, so it is overlapped, not waited for).
+  gather_coefficients()       one monolithic all_gather after all kernels (every rank ends up with the batch);
+                              kept for callers that want replicas, and as the un-overlapped comparison.
 """
 import torch
 import torch.distributed as dist
@@ -23,6 +30,13 @@ def shard_range(n_units, world, rank):
 
 def max_shard(n_units, world):
     return -(-n_units // world)
+
+
+def chunk_spans(lo, hi, chunk_frames):
+    """[lo, hi) cut into consecutive spans of at most chunk_frames frames."""
+    if chunk_frames <= 0:
+        raise ValueError("chunk_frames must be positive")
+    return [(a, min(a + chunk_frames, hi)) for a in range(lo, hi, chunk_frames)]
 
 
 def gather_coefficients(local, n_frames, coeffs_per_frame, group=None):
@@ -56,3 +70,85 @@ def encode_batch_sharded(encode_fn, n_frames, coeffs_per_frame, gather=True, gro
     if not gather or world == 1:
         return lo, hi, local
     return gather_coefficients(local, n_frames, coeffs_per_frame, group)
+
+
+def gather_to_root_pipelined(encode_chunk, n_frames, coeffs_per_frame, chunk_frames, device, root=0, group=None,
+                             out=None, ring=3, dtype=torch.int16):
+    """Sharded encode with the coefficient gather overlapped chunk by chunk.
+
+    encode_chunk(lo, hi, dst): enqueue (on the CURRENT stream of `device`, or compute synchronously on the CPU) the
+        encode of global frames [lo, hi) -- all inside this rank's shard -- into dst, an int16 tensor
+        [hi - lo, coeffs_per_frame].
+    Returns the [n_frames, coeffs_per_frame] batch on `root`, None elsewhere.  `out` may be a preallocated result
+    tensor on root.  Non-root ranks stage chunks in a ring of `ring` buffers; a buffer is reused only after its send
+    has completed.  With one rank (or no process group) this degenerates to encoding straight into `out`.
+    """
+    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    world = dist.get_world_size(group) if multi else 1
+    rank = dist.get_rank(group) if multi else 0
+    on_gpu = torch.device(device).type == "cuda"
+    spans = [chunk_spans(*shard_range(n_frames, world, r), chunk_frames) for r in range(world)]
+    rounds = max(len(s) for s in spans) if spans else 0
+
+    if rank == root:
+        if out is None:
+            out = torch.empty((n_frames, coeffs_per_frame), dtype=dtype, device=device)
+        elif tuple(out.shape) != (n_frames, coeffs_per_frame):
+            raise ValueError("out has the wrong shape")
+    if not multi:
+        for lo, hi in spans[0]:
+            encode_chunk(lo, hi, out[lo:hi])
+        return out
+
+    def as_bytes(t):            # gloo has no int16 point-to-point; bytes travel the same on RCCL
+        return t.reshape(-1).view(torch.uint8)
+
+    comm = torch.cuda.Stream(device) if on_gpu else None
+    stage, pending = [], []     # non-root: staging ring and the work handles that still read each slot
+    if rank != root:
+        stage = [torch.empty((chunk_frames, coeffs_per_frame), dtype=dtype, device=device) for _ in range(ring)]
+        pending = [None] * ring
+    works = []
+    for c in range(rounds):
+        mine = spans[rank][c] if c < len(spans[rank]) else None
+        ev = None
+        if rank == root:
+            if mine:
+                encode_chunk(mine[0], mine[1], out[mine[0]:mine[1]])
+            ops = []
+            for r in range(world):
+                if r != root and c < len(spans[r]):
+                    lo, hi = spans[r][c]
+                    ops.append(dist.P2POp(dist.irecv, as_bytes(out[lo:hi]), r, group))
+        else:
+            ops = []
+            if mine:
+                slot = c % ring
+                if pending[slot] is not None:          # the send that last read this slot must be done
+                    for w in pending[slot]:
+                        w.wait()
+                        works.remove(w)                # (waiting twice on a finished gloo send never returns)
+                    pending[slot] = None
+                buf = stage[slot][: mine[1] - mine[0]]
+                encode_chunk(mine[0], mine[1], buf)
+                if on_gpu:
+                    ev = torch.cuda.Event()
+                    ev.record(torch.cuda.current_stream(device))
+                ops.append(dist.P2POp(dist.isend, as_bytes(buf), root, group))
+        if ops:
+            if on_gpu:
+                # the transfer waits for this chunk's kernels only; the compute stream goes on with chunk c + 1
+                if ev is not None:
+                    comm.wait_event(ev)
+                with torch.cuda.stream(comm):
+                    w = dist.batch_isend_irecv(ops)
+            else:
+                w = dist.batch_isend_irecv(ops)
+            works.extend(w)
+            if rank != root and mine:
+                pending[c % ring] = w
+    for w in works:
+        w.wait()
+    if on_gpu:
+        torch.cuda.current_stream(device).wait_stream(comm)
+    return out if rank == root else None

@@ -1,0 +1,98 @@
+"""BASELINE configs[3] on the GPU (run with -m gpu): the batch of 4096 1920x1080 frames at FULL size on one GPU through the
+same chunked pipeline bench.py times (jpezy_amd.sharding.gather_to_root_pipelined, single rank), sampled frames
+against the oracle, size-independent properties over the whole batch; and the `bench.py --gpus 2` control flow with
+both ranks rehearsing on this one GPU.  The loop being sharded: ref encoder/jpezy_encoder.hpp:55-67, once per frame."""
+import importlib.util
+import json
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _bench():
+    spec = importlib.util.spec_from_file_location("bench", ROOT / "bench.py")
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules["bench"] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_full_4096_frame_1080p_batch_on_one_gpu(oracle):
+    import torch
+    import jpezy_amd as J
+    from jpezy_amd import sharding
+    b = _bench()
+    W, H, F = b.BATCH_W, b.BATCH_H, b.BATCH_FRAMES
+    dev = torch.device("cuda", 0)
+    if torch.cuda.get_device_properties(dev).total_memory < 80 << 30:
+        pytest.skip("needs ~55 GB of HBM")
+    plane = W * H
+    cpf = J.coeff_count(W, H, False)
+    assert cpf == 120 * 68 * 6 * 64
+    ctx = J.Context(0)
+    try:
+        pr, pg, pb = b.synth_frames(torch, 0, F, plane, dev)
+        calls = []
+
+        def make_enc(chunk):
+            def enc(lo, hi, dst):
+                calls.append((lo, hi))
+                ctx.fdct_quant_dev(pr[lo:hi], pg[lo:hi], pb[lo:hi], W, H, dst, gray=False, n_frames=hi - lo,
+                                   plane_stride=plane)
+            return enc
+        out = sharding.gather_to_root_pipelined(make_enc(64), F, cpf, 64, dev)
+        torch.cuda.synchronize(dev)
+        assert out.shape == (F, cpf) and calls == sharding.chunk_spans(0, F, 64)
+        # sampled frames against the oracle: first, last, chunk borders and random ones
+        rng = np.random.default_rng(4096)
+        sample = sorted({0, F - 1, 63, 64, 2048} | set(int(x) for x in rng.integers(0, F, size=5)))
+        assert len(sample) >= 8
+        for f in sample:
+            r, g, bb = (p[f].cpu().numpy() for p in (pr, pg, pb))
+            want = oracle.encode_coeffs(r, g, bb, W, H).reshape(-1)
+            got = out[f].cpu().numpy()
+            assert np.array_equal(got, want), f"frame {f} of the batch differs from the oracle"
+        # a frame is a function of its own pixels only: frame f of the batch generator equals a fresh generation
+        r2, _, _ = b.synth_frames(torch, 4095, 4096, plane, dev)
+        assert torch.equal(r2[0], pr[F - 1])
+        # size-independent properties over the whole batch: (i) the chunking does not matter (one launch of 512 frames
+        # = 8 launches of 64); (ii) the shards of an 8-rank split, encoded on their own, tile the batch exactly
+        out2 = torch.empty((512, cpf), dtype=torch.int16, device=dev)
+        ctx.fdct_quant_dev(pr[1024:1536], pg[1024:1536], pb[1024:1536], W, H, out2, gray=False, n_frames=512, plane_stride=plane)
+        torch.cuda.synchronize(dev)
+        assert torch.equal(out2, out[1024:1536])
+        lo, hi = sharding.shard_range(F, 8, 7)
+        assert (lo, hi) == (3584, 4096)
+        part = sharding.gather_to_root_pipelined(
+            lambda a, c, dst: ctx.fdct_quant_dev(pr[lo + a:lo + c], pg[lo + a:lo + c], pb[lo + a:lo + c], W, H, dst,
+                                                 gray=False, n_frames=c - a, plane_stride=plane), hi - lo, cpf, 100, dev)
+        torch.cuda.synchronize(dev)
+        assert torch.equal(part, out[lo:hi])
+        # the padded bottom MCU row (1080 -> 1088 by edge replication, ref :101) is present in every frame
+        assert int((out.view(F, 68, 120, 6, 64)[:, 67].abs().sum(dim=(1, 2, 3)) > 0).sum()) == F
+    finally:
+        ctx.close()
+
+
+def test_bench_gpus_2_rehearsal_on_one_gpu():
+    """`python bench.py --gpus 2` starts its own two ranks (no launcher); on this one-GPU box they rehearse on GPU 0
+    with gloo + host staging.  Checks the control flow and that the sharded, gathered batch equals the one-GPU batch."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--rehearse-on-one-gpu", "--steps", "3",
+                        "--warmup", "1", "--repeats", "2", "--no-cpu", "--batch-frames", "10", "--batch-chunk", "3"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = json.loads(p.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["repeats"] == 2
+    bt = line["batch"]
+    assert bt["frames"] == 10 and bt["frames_per_rank"] == 5 and bt["gathered_equals_one_gpu_result"] is True
+    assert bt["kernel_only"]["ms"] > 0 and bt["end_to_end"]["ms"] > 0 and bt["gather"]["bytes_into_rank0"] == 5 * 120 * 68 * 6 * 64 * 2
+    assert "rehearsal" in bt

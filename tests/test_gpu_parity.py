@@ -502,3 +502,33 @@ def test_bench_prints_one_contract_line():
     assert d["pipelined"]["frames_in_flight"] == 2 and d["pipelined"]["value"] > 0
     # value is pixels over wall time of the K steps
     assert abs(d["value"] - 4096 * 4096 / (d["ms_per_step"] * 1e-3) / 1e6) / d["value"] < 0.01
+
+
+def test_misaligned_coefficient_pointer_is_refused_not_faulted(J):
+    """coefficients move as 16-byte accesses: a 2-byte-aligned slice must come back as JPEZY_E_BADARG (include/jpezy_hip.h)"""
+    import torch
+    c = J.Context(0)
+    try:
+        W = H = 64
+        n = J.coeff_count(W, H)
+        planes = [torch.zeros(W * H, dtype=torch.uint8, device="cuda:0") for _ in range(3)]
+        buf = torch.zeros(n + 8, dtype=torch.int16, device="cuda:0")
+        with pytest.raises(J.JpezyError, match="16-byte aligned"):
+            c.fdct_quant_dev(*planes, W, H, buf[1:1 + n])
+        with pytest.raises(J.JpezyError, match="16-byte aligned"):
+            c.dequant_idct_dev(buf[1:1 + n], W, H, *planes)
+        c.fdct_quant_dev(*planes, W, H, buf[8:8 + n])            # 16-byte aligned offset: fine
+        torch.cuda.synchronize()
+    finally:
+        c.close()
+
+
+def test_header_declaring_a_huge_frame_over_a_tiny_scan_is_refused(J, ctx, oracle):
+    """SOF0 fields are untrusted: a 700-byte file that declares 65535x65535 must fail with a status, not by running
+    out of memory inside the library (no exception crosses the C ABI)"""
+    r, g, b = oracle.synth_rgb(16, 16)
+    jpg = bytearray(oracle.encode_jpeg(r, g, b, 16, 16))
+    i = jpg.index(b"\xff\xc0")
+    jpg[i + 5:i + 9] = b"\xff\xff\xff\xff"                      # height, width
+    with pytest.raises(J.JpezyError):
+        ctx.decode_jpeg(bytes(jpg))

@@ -72,3 +72,56 @@ def test_sharded_encode_and_gather_gloo(tmp_path, world, n_frames):
     for r in range(world):
         got = np.load(tmp_path / f"full_{r}.npy")
         assert np.array_equal(got, want), f"rank {r} holds a wrong gathered batch"
+
+
+def _worker_pipelined(rank, world, port, n_frames, chunk, W, H, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import oracle as O
+        cpf = ((W + 15) // 16) * ((H + 15) // 16) * 6 * 64
+        calls = []
+
+        def encode_chunk(lo, hi, dst):
+            calls.append((lo, hi))
+            my_lo, my_hi = sharding.shard_range(n_frames, world, rank)
+            assert my_lo <= lo < hi <= my_hi and hi - lo <= chunk      # only this rank's frames, chunk by chunk
+            for k, f in enumerate(range(lo, hi)):
+                dst[k].copy_(torch.from_numpy(O.encode_coeffs(*O.synth_rgb(W, H, frame=f), W, H).reshape(-1)))
+
+        full = sharding.gather_to_root_pipelined(encode_chunk, n_frames, cpf, chunk, "cpu", root=0, ring=2)
+        if rank == 0:
+            np.save(Path(out_dir) / "full.npy", full.numpy())
+        else:
+            assert full is None
+        np.save(Path(out_dir) / f"calls_{rank}.npy", np.array(calls, dtype=np.int64).reshape(-1, 2))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_frames,chunk", [(2, 7, 2), (3, 8, 1), (3, 2, 4)])
+def test_pipelined_gather_to_root_gloo(tmp_path, world, n_frames, chunk):
+    """chunked, overlapped gather-to-consumer: uneven shards, ragged last chunks, a rank with no frames,
+    staging ring shorter than the number of chunks"""
+    W, H = 32, 16
+    port = _free_port()
+    mp.spawn(_worker_pipelined, args=(world, port, n_frames, chunk, W, H, str(tmp_path)), nprocs=world, join=True)
+    from oracle import oracle as O
+    want = np.stack([O.encode_coeffs(*O.synth_rgb(W, H, frame=f), W, H).reshape(-1) for f in range(n_frames)])
+    assert np.array_equal(np.load(tmp_path / "full.npy"), want)
+    seen = []
+    for r in range(world):
+        calls = np.load(tmp_path / f"calls_{r}.npy")
+        lo, hi = sharding.shard_range(n_frames, world, r)
+        assert [tuple(c) for c in calls] == sharding.chunk_spans(lo, hi, chunk)
+        seen += [f for a, b in calls for f in range(a, b)]
+    assert sorted(seen) == list(range(n_frames))                      # every frame encoded exactly once
+
+
+def test_pipelined_single_rank_no_process_group():
+    cpf, n = 8, 5
+    def enc(lo, hi, dst):
+        dst.copy_(torch.arange(lo * cpf, hi * cpf, dtype=torch.int16).reshape(hi - lo, cpf))
+    out = sharding.gather_to_root_pipelined(enc, n, cpf, 2, "cpu")
+    assert torch.equal(out.reshape(-1), torch.arange(n * cpf, dtype=torch.int16))

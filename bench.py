@@ -113,10 +113,28 @@ def spawn_ranks(n, argv, timeout=None):
 # CPU baseline: the oracle (scalar C port of the reference) on the box's host cores
 # ------------------------------------------------------------------------------------------------------------------
 def _host_cores():
+    """cores this process may really use: the affinity mask, capped by the cgroup CPU quota (a GPU box hands a job a
+    share of the host -- 16 cores per GPU -- through the quota while the mask still shows every core)"""
     try:
-        return max(1, len(os.sched_getaffinity(0)))
+        n = max(1, len(os.sched_getaffinity(0)))
     except AttributeError:
-        return os.cpu_count() or 1
+        n = os.cpu_count() or 1
+    quota = None
+    try:
+        q, per = Path("/sys/fs/cgroup/cpu.max").read_text().split()[:2]            # cgroup v2
+        if q != "max":
+            quota = int(q) / int(per)
+    except Exception:
+        try:
+            q = int(Path("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read_text())        # cgroup v1
+            per = int(Path("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read_text())
+            if q > 0:
+                quota = q / per
+        except Exception:
+            quota = None
+    if quota:
+        n = max(1, min(n, int(quota + 0.5)))
+    return n
 
 
 def _timed_bands(fn, bands, passes, threads):

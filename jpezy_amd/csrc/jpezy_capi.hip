@@ -973,8 +973,8 @@ try {
     uint32_t* d_exit = (uint32_t*)c->h_state.p;
     uint32_t* d_last = d_exit + n_sub;
     unsigned* d_nblocks = (unsigned*)(d_last + n_sub);
-    unsigned* d_changed = (unsigned*)c->h_small.p;
-    unsigned* d_error = d_changed + 1;
+    unsigned* d_changed = (unsigned*)c->h_small.p + 4;     // [0] lanes that moved, [1] lanes left pending (bytes 16..23 of h_small)
+    unsigned* d_error = (unsigned*)c->h_small.p + 1;
     unsigned long long* d_lastbit = (unsigned long long*)c->h_small.p + 1;
     HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)d_exit, (int)0x80000000u, n_sub, s));
     HIP_TRY(hipMemsetAsync(d_last, 0xFF, (size_t)n_sub * 4, s));
@@ -997,23 +997,26 @@ try {
     // subsequences internally).  Many move -- periodic data such as a flat image never lets a wrong decoder fall into
     // step -- or refinement does not settle quickly: the host decoder takes over.
     {
-        unsigned moved = 0;
+        unsigned moved = 0, mv[2] = { 0, 0 };
+        bool pending = false;        // lanes a max_inner cut-off left with a stale entry: not converged even if nothing moved
         auto pass = [&](int max_inner) -> int {
-            HIP_TRY(hipMemsetAsync(d_changed, 0, sizeof(unsigned), s));
+            HIP_TRY(hipMemsetAsync(d_changed, 0, 2 * sizeof(unsigned), s));
             HIP_TRY(HD::launch_sync((const HD::Setup*)c->h_setup.p, (const uint32_t*)c->h_U.p, u_bytes / 4, n_sub, d_exit, d_last, d_nblocks,
                                     d_changed, max_inner, s));
-            HIP_TRY(hipMemcpyAsync(&moved, d_changed, sizeof moved, hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipMemcpyAsync(mv, d_changed, sizeof mv, hipMemcpyDeviceToHost, s));
             HIP_TRY(hipStreamSynchronize(s));
+            moved = mv[0];
+            pending = mv[1] != 0;
             ++passes;
             return JPEZY_OK;
         };
         if (int r2 = pass(1)) return r2;
-        converged = moved == 0;
+        converged = moved == 0 && !pending;
         // refinement budget: 6 launches of at most 24 propagation steps (~10 ms); isolated wrong lanes settle in one
         if (!converged && moved <= n_sub / 2 + 16) {
             for (int it = 0; it < 6 && !converged; ++it) {
                 if (int r2 = pass(24)) return r2;
-                converged = moved == 0;
+                converged = moved == 0 && !pending;
             }
         }
     }

@@ -35,7 +35,7 @@ hipError_t launch_unstuff_copy(const uint8_t* S, size_t n, const unsigned long l
 hipError_t launch_speculate(const Setup* S, const uint32_t* U, size_t u_words, unsigned n_sub, unsigned long long* proposal,
                             uint32_t* exit_state, hipStream_t s);
 // u_words: 32-bit words of U that may be read (the rest of a workgroup's window reads as zero)
-// *changed += number of lanes whose exit state moved.  max_inner: propagation steps inside a workgroup (1: every lane
+// changed[0] += number of lanes whose exit state moved, changed[1] += lanes left pending by the max_inner cut-off.  max_inner: propagation steps inside a workgroup (1: every lane
 // decodes once from its predecessor's current exit state and nothing more)
 hipError_t launch_sync(const Setup* S, const uint32_t* U, size_t u_words, unsigned n_sub, uint32_t* exit_state, uint32_t* last_entry,
                        unsigned* nblocks, unsigned* changed, int max_inner, hipStream_t s);

@@ -227,8 +227,12 @@ __global__ __launch_bounds__(WGS) void sync_kernel(const Setup* gS, const uint32
         // (A -> B -> A inside the launch leaves exit_before == my_exit): such a lane is still pending and must keep
         // the host iterating, or a stale nblocks/last_entry would pass for the fixed point
         const bool pending = sh_exit[t] != my_last;
-        if (my_exit != exit_before) exit_state[i] = my_exit;
-        if (my_exit != exit_before || pending) atomicAdd(changed, 1u);   // lanes that moved, or still have to, in this launch
+        if (my_exit != exit_before) {
+            exit_state[i] = my_exit;
+            atomicAdd(changed, 1u);                        // changed[0]: lanes whose exit state moved in this launch
+        } else if (pending) {
+            atomicAdd(changed + 1, 1u);                    // changed[1]: lanes that did not move but still have to re-decode
+        }
     }
 }
 

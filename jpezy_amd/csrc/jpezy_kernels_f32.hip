@@ -171,7 +171,11 @@ __device__ __forceinline__ void luma8(const uint32_t* wr, const uint32_t* wg, co
     luma_px2<0, 1>(wr[1], wg[1], wb[1], y[4], y[5], e[4], e[5]);
     luma_px2<2, 3>(wr[1], wg[1], wb[1], y[6], y[7], e[6], e[7]);
     constexpr float TH = 0.5f - LUMA_EPS;
+#ifdef JPEZY_ABL_NOCFLAG    // timing probe (wrong results, tools/ab_build.py): what the colour guard tests and their rare path cost
+    if (false) {
+#else
     if (wave_any(absmax8(e) > TH)) {   // one pixel in 1000: the reference's FP64 rounding decides
+#endif
         bool f;
         f = __builtin_fabsf(e[0]) > TH; if (wave_any(f)) { if (f) y[0] = luma_px_ref<0>(wr[0], wg[0], wb[0]); }
         f = __builtin_fabsf(e[1]) > TH; if (wave_any(f)) { if (f) y[1] = luma_px_ref<1>(wr[0], wg[0], wb[0]); }
@@ -310,7 +314,11 @@ __device__ __forceinline__ void quant_block_column(const float* F, const float* 
 {
     int q[8];
     const float dmin = quant8f(F, ks, j == 0, dc, q);
+#ifdef JPEZY_ABL_NOGUARD    // timing probe (wrong results): what the coefficient guard tests and levels 2/3 cost
+    const bool cand = false;
+#else
     const bool cand = force || dmin < delta1;
+#endif
     // rare on noisy content; flat content (exact zeros) enters and finds nothing to queue.  (Lanes that are not live
     // repeat the quad's last MCU, so leaving them in the vote changes nothing and keeps it a bare v_cmp + s_cmp.)
     if (wave_any(cand)) {
@@ -447,7 +455,11 @@ __global__ __launch_bounds__(64 * WPB, JPEZY_F32_WAVES) void fdct_quant_f32_kern
         chroma_px2<0, 2>(R2[2], G2[2], B2[2], R2[2], G2[2], B2[2], k1, k2, k3, cv[4], cv[5], e[4], e[5]);
         chroma_px2<0, 2>(R2[3], G2[3], B2[3], R2[3], G2[3], B2[3], k1, k2, k3, cv[6], cv[7], e[6], e[7]);
         constexpr float TH = 0.5f - CHROMA_EPS;
+#ifdef JPEZY_ABL_NOCFLAG
+        if (false) {
+#else
         if (wave_any(absmax8(e) > TH)) {
+#endif
             bool f;
             f = __builtin_fabsf(e[0]) > TH; if (wave_any(f)) { if (f) cv[0] = chroma_px_ref<0>(R2[0], G2[0], B2[0], odd); }
             f = __builtin_fabsf(e[1]) > TH; if (wave_any(f)) { if (f) cv[1] = chroma_px_ref<2>(R2[0], G2[0], B2[0], odd); }

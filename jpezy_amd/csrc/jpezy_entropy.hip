@@ -19,6 +19,7 @@
 #include <stdint.h>
 
 #include "jpezy_entropy.h"
+#include "../../include/jpezy_constants.h"   // JPEZY_PAD_BIT
 
 namespace jpezy_dev {
 namespace entropy {
@@ -220,6 +221,18 @@ __global__ __launch_bounds__(WG) void emit_kernel(Job job, const unsigned long l
     bool err = false;
     (void)code_block(r.z, r.pred, L.dc[r.table], L.ac[r.table], w, err);
     w.finish();
+#if JPEZY_PAD_BIT   // alternative frozen choice (include/jpezy_constants.h): one pad bits in the frame's last byte; a
+                    // padded 0xFF is then stuffed like any other by the ff_count / stuff kernels
+    if (g + 1 == (frame + 1) * job.blocks_per_frame) {
+        const unsigned long long end = bitoff[g + 1] - bitoff[frame * job.blocks_per_frame];
+        const unsigned pad = (unsigned)((8 - (end & 7)) & 7);
+        if (pad) {
+            const unsigned bit_in_word = (unsigned)(end & 31);            // MSB-first inside a big-endian word
+            const uint32_t mask = ((1u << pad) - 1u) << (32 - bit_in_word - pad);
+            atomicOr(U + frame * u_stride_words + (size_t)(end >> 5), __builtin_bswap32(mask));
+        }
+    }
+#endif
 }
 
 // ---- exclusive prefix sums: 2048 elements per workgroup, recursive over the workgroup totals ----

@@ -94,8 +94,15 @@ public:
     }
     void flush_partial()
     {
-        if (nacc_ > 0) {   // pad with zero bits (frozen bofstream semantics); cannot be 0xFF
-            put((unsigned)(acc_ << (8 - nacc_)) & 0xFFu);
+        if (nacc_ > 0) {   // pad bits: JPEZY_PAD_BIT (frozen bofstream semantics): 0 -- the byte cannot be 0xFF
+            unsigned byte = (unsigned)(acc_ << (8 - nacc_)) & 0xFFu;
+#if JPEZY_PAD_BIT
+            byte |= (1u << (8 - nacc_)) - 1u;
+            put(byte);
+            if (byte == 0xFF) put(0x00);
+#else
+            put(byte);
+#endif
             nacc_ = 0;
         }
         acc_ = 0;

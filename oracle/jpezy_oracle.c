@@ -218,7 +218,18 @@ static void bw_inc(bitw* w)
 static void bw_byte(bitw* w, unsigned v)
 {
     if (w->overflow) return;
-    if (w->bitpos != 7) { bw_inc(w); w->bitpos = 7; if (w->overflow) return; }
+    if (w->bitpos != 7) {
+#if JPEZY_PAD_BIT   /* alternative frozen choice (include/jpezy_constants.h): pad with ones, stuff a padded 0xFF */
+        w->buf[w->pos] |= (uint8_t)((1u << (w->bitpos + 1)) - 1u);
+        const int full = w->buf[w->pos] == 0xFF;
+        bw_inc(w);
+        w->bitpos = 7;
+        if (w->overflow) return;
+        if (full) { w->buf[w->pos] = 0x00; bw_inc(w); if (w->overflow) return; }
+#else
+        bw_inc(w); w->bitpos = 7; if (w->overflow) return;
+#endif
+    }
     w->buf[w->pos] = (uint8_t)v;
     bw_inc(w);
 }

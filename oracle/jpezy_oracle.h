@@ -9,7 +9,14 @@
  * SrookCppLibraries), so this oracle is pinned only by (i) the reference's source text it restates line
  * by line, (ii) Annex-K tables re-derived from libjpeg, (iii) libjpeg decoding the files it writes.
  * The frozen choices (include/jpezy_constants.h): correctly rounded binary64 cosines, 1.0/sqrt(2.0) in
- * binary64, no FMA contraction, MSB-first bit packing with 0xFF00 stuffing and ZERO pad bits.
+ * binary64, no FMA contraction, MSB-first bit packing with 0xFF00 stuffing and ZERO pad bits (JPEZY_PAD_BIT).
+ * One more frozen reading: the DECODER writes `1.0 / srook::sqrt(2)` with an INT literal (ref
+ * decoder/jpezy_decoder.hpp:655) where the encoder writes `srook::sqrt(2.0)` (ref encoder/jpezy_encoder.hpp:149).
+ * Both are taken as the binary64 sqrt of 2.0 (srook::sqrt is a constexpr template; an overload returning an
+ * integer would make the decoder's DC gain 1 instead of 1/sqrt 2 and every decoded image far too bright, which
+ * the README's round trip rules out).  Whether the int overload rounds differently in the last place is
+ * unknowable here; the alternative-constants build (tools/gen_constants.py --variant alt1, make CONSTANTS=...)
+ * exists so that a different value is a one-header change for oracle and product alike.
  *
  * All `ref` citations are into /root/reference/src/.
  */

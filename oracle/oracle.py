@@ -14,12 +14,19 @@ _HERE = Path(__file__).resolve().parent
 _LIB = None
 
 
-def build(force=False):
-    """Compile libjpezy_oracle.so with gcc (plain IEEE-754 double, no contraction)."""
-    so = _HERE / "libjpezy_oracle.so"
+def build(force=False, constants=None, out=None):
+    """Compile libjpezy_oracle.so with gcc (plain IEEE-754 double, no contraction).  constants/out: build the same
+    sources against an alternative constants header into another file (tests/test_constants_override.py)."""
+    so = Path(out) if out else _HERE / "libjpezy_oracle.so"
     srcs = [_HERE / "jpezy_oracle.c", _HERE / "jpezy_oracle.h", _HERE.parent / "include" / "jpezy_constants.h"]
+    if constants:
+        srcs.append(Path(constants))
     if force or not so.exists() or any(s.stat().st_mtime > so.stat().st_mtime for s in srcs if s.exists()):
-        subprocess.check_call(["make", "-C", str(_HERE), "-B", "libjpezy_oracle.so"], stdout=subprocess.DEVNULL)
+        so.parent.mkdir(parents=True, exist_ok=True)
+        cmd = ["make", "-C", str(_HERE), "-B", f"OUT={so}"]
+        if constants:
+            cmd.append(f"CONSTANTS={Path(constants).resolve()}")
+        subprocess.check_call(cmd + [str(so)], stdout=subprocess.DEVNULL)
     return so
 
 
@@ -40,7 +47,8 @@ class FrameInfo(C.Structure):
 def lib():
     global _LIB
     if _LIB is None:
-        so = build()
+        # JPEZY_ORACLE_LIB: another build of the oracle (alternative constants, tests/test_constants_override.py)
+        so = Path(os.environ["JPEZY_ORACLE_LIB"]) if os.environ.get("JPEZY_ORACLE_LIB") else build()
         L = C.CDLL(str(so))
         u8p, i16p, ip = C.POINTER(C.c_uint8), C.POINTER(C.c_int16), C.POINTER(C.c_int)
         L.jo_rgb_y.argtypes = L.jo_rgb_cb.argtypes = L.jo_rgb_cr.argtypes = [C.c_uint8] * 3

@@ -107,6 +107,7 @@ struct jpezy_ctx {
 #ifdef JPEZY_TRACE
     unsigned long long* d_trace = nullptr;
 #endif
+    DevBuf dump_t;                 // JPEZY_DUMP_T builds: level-1 t values of the last jpezy_fdct_quant_dev call
     DevBuf in[3], out, scratch;    // staging for the host-buffer entry points; scratch: samples of the generic decoder
     // GPU entropy coder (jpezy_entropy.hip): code tables + scratch
     jpezy_dev::entropy::CodeTables* d_codes = nullptr;
@@ -250,7 +251,7 @@ void jpezy_ctx_destroy(jpezy_ctx* c)
     if (c->d_codes) (void)hipFree(c->d_codes);
     if (c->e_pinned) (void)hipHostFree(c->e_pinned);
     for (DevBuf* b : { &c->e_bits, &c->e_off, &c->e_tmp, &c->e_small, &c->e_U, &c->e_cnt, &c->e_ffoff, &c->e_out, &c->e_coef, &c->e_hdr,
-                       &c->h_scan, &c->h_U, &c->h_cnt, &c->h_off, &c->h_state, &c->h_setup, &c->h_small, &c->h_dc }) b->release();
+                       &c->dump_t, &c->h_scan, &c->h_U, &c->h_cnt, &c->h_off, &c->h_state, &c->h_setup, &c->h_small, &c->h_dc }) b->release();
     delete c;
 }
 
@@ -321,6 +322,11 @@ int jpezy_fdct_quant_dev(jpezy_ctx* c, const uint8_t* d_r, const uint8_t* d_g, c
     if (!c->d_trace) HIP_TRY(hipMalloc((void**)&c->d_trace, sizeof(unsigned long long) * 4 * 65536));
     p.trace = c->d_trace;
 #endif
+#ifdef JPEZY_DUMP_T
+    if (int rc = c->dump_t.reserve(p.coeffs_per_frame * (size_t)n_frames * sizeof(float))) return rc;
+    HIP_TRY(hipMemsetAsync(c->dump_t.p, 0, p.coeffs_per_frame * (size_t)n_frames * sizeof(float), s));
+    p.dump_t = (float*)c->dump_t.p;
+#endif
     p.W = W; p.H = H;
     p.mcu_cols = jpezy_mcu_cols(W);
     p.mcu_rows = jpezy_mcu_rows(H);
@@ -341,6 +347,16 @@ int jpezy_fdct_quant_dev(jpezy_ctx* c, const uint8_t* d_r, const uint8_t* d_g, c
     }
     return JPEZY_OK;
 }
+
+#ifdef JPEZY_DUMP_T
+int jpezy_debug_read_t(jpezy_ctx* c, float* host, size_t n)
+{
+    HIP_TRY(hipDeviceSynchronize());
+    if (n * sizeof(float) > c->dump_t.cap) return set_err(JPEZY_E_BADARG, "debug_read_t: more than the last call dumped");
+    HIP_TRY(hipMemcpy(host, c->dump_t.p, n * sizeof(float), hipMemcpyDeviceToHost));
+    return JPEZY_OK;
+}
+#endif
 
 #ifdef JPEZY_TRACE
 int jpezy_debug_read_trace(jpezy_ctx* c, unsigned long long* host, size_t n)

@@ -310,8 +310,17 @@ __device__ __forceinline__ float quant8f(const float* F, const float* ks, bool d
 // delta1: this lane's level-1 guard band (DeviceTables::delta1, a function of the table and of the column j)
 __device__ __forceinline__ void quant_block_column(const float* F, const float* ks, float delta1, int j, int dc,
                                                    bool live, char* base, uint32_t zz_lo, uint32_t zz_hi, int blk_off, int blk,
-                                                   unsigned* queue, bool force)
+                                                   unsigned* queue, bool force
+#ifdef JPEZY_DUMP_T
+                                                   , float* dump_quad
+#endif
+                                                   )
 {
+#ifdef JPEZY_DUMP_T   // diagnostic build: the level-1 values exactly as the guard test sees them
+    if (live && dump_quad)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) dump_quad[blk * 64 + i * 8 + j] = F[i] * ks[i];
+#endif
     int q[8];
     const float dmin = quant8f(F, ks, j == 0, dc, q);
 #ifdef JPEZY_ABL_NOGUARD    // timing probe (wrong results): what the coefficient guard tests and levels 2/3 cost
@@ -384,6 +393,12 @@ __global__ __launch_bounds__(64 * WPB, JPEZY_F32_WAVES) void fdct_quant_f32_kern
     const uint8_t* pg = p.g + (size_t)frame * p.plane_stride;
     const uint8_t* pb = p.b + (size_t)frame * p.plane_stride;
     const DeviceTables* tab = p.tab;
+#ifdef JPEZY_DUMP_T
+    float* dump_quad = p.dump_t ? p.dump_t + (size_t)frame * p.coeffs_per_frame + ((size_t)mcu_y * p.mcu_cols + (size_t)quad_x * 4) * (BPM * 64) : nullptr;
+#define DUMP_ARG , dump_quad
+#else
+#define DUMP_ARG
+#endif
 
     // ---- 1. this lane's 16-pixel row segment of the three planes ----
     uint32_t R[4], G[4], B[4];
@@ -503,13 +518,13 @@ __global__ __launch_bounds__(64 * WPB, JPEZY_F32_WAVES) void fdct_quant_f32_kern
         {
             float F[8];
             fdct8f(col, F);
-            quant_block_column(F, ks, dl, j, dc_top, live, sbase, zz_lo, zz_hi, 0, m * BPM + bx, queue, FORCE != 0);
+            quant_block_column(F, ks, dl, j, dc_top, live, sbase, zz_lo, zz_hi, 0, m * BPM + bx, queue, FORCE != 0 DUMP_ARG);
         }
         __builtin_amdgcn_sched_barrier(0);
         {
             float F[8];
             fdct8f(col + 8, F);
-            quant_block_column(F, ks, dl, j, dc_bot, live, sbase, zz_lo, zz_hi, 2 * STG_BLK, m * BPM + 2 + bx, queue, FORCE != 0);
+            quant_block_column(F, ks, dl, j, dc_bot, live, sbase, zz_lo, zz_hi, 2 * STG_BLK, m * BPM + 2 + bx, queue, FORCE != 0 DUMP_ARG);
         }
     }
 
@@ -537,7 +552,7 @@ __global__ __launch_bounds__(64 * WPB, JPEZY_F32_WAVES) void fdct_quant_f32_kern
         float ks[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) ks[i] = lcol[8].ks[i];
-        quant_block_column(Fc, ks, lcol[8].delta1, j, dc_c, live, sbase, zz_lo, zz_hi, 4 * STG_BLK, m * BPM + 4 + bx, queue, FORCE != 0);
+        quant_block_column(Fc, ks, lcol[8].delta1, j, dc_c, live, sbase, zz_lo, zz_hi, 4 * STG_BLK, m * BPM + 4 + bx, queue, FORCE != 0 DUMP_ARG);
     }
     wave_sync();
 

@@ -44,7 +44,8 @@ def main():
             info, back = J.read_jpeg(jpg)
             verdict[key + "_host_reader"] = bool(np.array_equal(back.reshape(-1), (co if not gray else O.read_jpeg(jpg)[1]).reshape(-1)))
             if gpu:
-                ctx = J.default_context()
+                from jpezy_amd import api as _api
+                ctx = _api.default_context()
                 got = ctx.fdct_quant(r, g, b, w, h, gray=gray)
                 verdict[key + "_gpu_fdct"] = bool(np.array_equal(got, co))
                 for force in (1, 2):

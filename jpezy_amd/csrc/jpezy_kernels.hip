@@ -79,11 +79,27 @@ constexpr int WAVE_LDS_DWORDS = TILE_DWORDS + 64;   // 9728 B per wave, 38912 B 
 
 // Decode kernel LDS slice (dwords): the luma tile is exchanged in two halves (left blocks, then right blocks) so that
 // the slice is 5.4 KB instead of 9.5 KB and LDS no longer caps the kernel at 4 waves per SIMD.
+// Geometry from tools/lds_bank_model.py (the lane groups and bank functions of MI355X_MICROARCH.md): the coefficient
+// staging area has a 144-byte block pitch (the zig-zag-indexed 2-byte column reads of the four MCUs then start 24 banks
+// apart: 108 LDS cycles per wave instead of 192), the luma half tile an MCU stride == 8 (mod 32) dwords (conflict-free
+// ds_write_b64 columns; the ds_read_b128 rows become 2-way: 128 cycles for both instead of 160 -- no pitch makes both
+// directions conflict-free), the chroma tile unpadded rows (64 instead of 80).  Model: 456 -> 324 cycles per wave;
+// counters (profiles/r02e_ab_decode.txt): SQ_LDS_BANK_CONFLICT 219 -> 104, SQ_LDS_IDX_ACTIVE 487 -> 371 per wave -- and
+// 39.5 -> 39.3 us: the kernel is not bound by its LDS traffic.
+#ifdef JPEZY_DEC_LDS_R01     // round-1 geometry, kept for A/B counters (tools/ab_build.py)
+constexpr int DH_PITCH = 20, DH_MCU = 16 * DH_PITCH + 16;                    // 336
+constexpr int DC_PITCH = 20, DC_COMP = 8 * DC_PITCH, DC_MCU = 2 * DC_COMP + 16;
+constexpr int DSTG_PITCH = 128;               // bytes per staged block
+#else
 constexpr int DH_PITCH = 20;                  // 8 doubles + 2 pad
-constexpr int DH_MCU = 16 * DH_PITCH + 16;    // 336
-constexpr int DEC_TILE_DWORDS = 4 * DH_MCU;   // 1344 dwords = 5376 B (== the chroma tile: 4 * C_MCU)
+constexpr int DH_MCU = 16 * DH_PITCH + 8;     // 328
+constexpr int DC_PITCH = 16, DC_COMP = 8 * DC_PITCH, DC_MCU = 2 * DC_COMP + 8;    // 16 / 128 / 264
+constexpr int DSTG_PITCH = 144;
+#endif
+constexpr int DEC_TILE_DWORDS = 4 * 336;      // 1344 dwords = 5376 B
 constexpr int DEC_LDS_DWORDS = DEC_TILE_DWORDS + 16;
-static_assert(4 * C_MCU <= DEC_TILE_DWORDS && 768 <= DEC_TILE_DWORDS && 1024 + 128 <= DEC_TILE_DWORDS, "decode slice too small");
+static_assert(4 * DC_MCU <= DEC_TILE_DWORDS && 4 * DH_MCU <= DEC_TILE_DWORDS && 24 * DSTG_PITCH <= DEC_TILE_DWORDS * 4 &&
+              1024 + 128 <= DEC_TILE_DWORDS, "decode slice too small");
 
 __device__ __forceinline__ void wave_sync()
 {
@@ -563,7 +579,6 @@ __global__ __launch_bounds__(64 * WPB, GRAY ? JPEZY_DEC_WAVES_GRAY : JPEZY_DEC_W
         const int valid_mcus = min(4, p.mcu_cols - quad_x * 4);
         const int valid_bytes = valid_mcus * BPM * 128;
         const uint4* g4 = reinterpret_cast<const uint4*>(gbase);
-        uint4* s4 = reinterpret_cast<uint4*>(lds);
         // all three loads are issued before the first one is waited for (one memory latency per wave, not three)
         uint4 v[3];
         if (valid_mcus == 4) {                       // wave-uniform; every quad but the last of a ragged row
@@ -577,7 +592,10 @@ __global__ __launch_bounds__(64 * WPB, GRAY ? JPEZY_DEC_WAVES_GRAY : JPEZY_DEC_W
             }
         }
 #pragma unroll
-        for (int k = 0; k < 3; ++k) s4[k * 64 + lane] = v[k];
+        for (int k = 0; k < 3; ++k) {
+            const int c = k * 64 + lane;              // 16-byte chunk: block c >> 3, part c & 7
+            *reinterpret_cast<uint4*>(reinterpret_cast<char*>(lds) + (c >> 3) * DSTG_PITCH + (c & 7) * 16) = v[k];
+        }
     }
     wave_sync();
 
@@ -603,8 +621,8 @@ __global__ __launch_bounds__(64 * WPB, GRAY ? JPEZY_DEC_WAVES_GRAY : JPEZY_DEC_W
         }
         const double cucv_dc = JPEZY_S * JPEZY_S;                  // the reference's cu * cv for (0,0): 0.4999999999999999
         const int bx = cq >> 3;
-        const int16_t* bt = stage + (m * BPM + bx) * 64;
-        const int16_t* bb = stage + (m * BPM + 2 + bx) * 64;
+        const int16_t* bt = stage + (m * BPM + bx) * (DSTG_PITCH / 2);
+        const int16_t* bb = stage + (m * BPM + 2 + bx) * (DSTG_PITCH / 2);
         int c[8], acor;
 #pragma unroll
         for (int v = 0; v < 8; ++v) { c[v] = ld_coef(bt + zp[v]); in[v] = (double)c[v] * dq[v]; cmx = max(cmx, c[v]); cmn = min(cmn, c[v]); }
@@ -620,7 +638,7 @@ __global__ __launch_bounds__(64 * WPB, GRAY ? JPEZY_DEC_WAVES_GRAY : JPEZY_DEC_W
         idct8(in, gbot);
         if (!GRAY) {
             const int comp = 1 + (cq >> 3);
-            const int16_t* bc = stage + (m * BPM + 3 + comp) * 64;
+            const int16_t* bc = stage + (m * BPM + 3 + comp) * (DSTG_PITCH / 2);
             // only the eight raw coefficients of the chroma column stay in registers (4 VGPRs); its column pass runs after
             // the luma halves, when the 32 VGPRs of the two luma columns are free again
 #pragma unroll
@@ -688,9 +706,9 @@ __global__ __launch_bounds__(64 * WPB, GRAY ? JPEZY_DEC_WAVES_GRAY : JPEZY_DEC_W
                 if (u == 0) cin[0] = (JPEZY_S * JPEZY_S) * (double)((int)(short)(cpk[0] & 0xFFFFu) * p.dqt[comp * 64]) * 0.25;
                 idct8(cin, gc);
             }
-            uint32_t* dst = lds + m * C_MCU + (cq >> 3) * C_COMP + u * 2;
+            uint32_t* dst = lds + m * DC_MCU + (cq >> 3) * DC_COMP + u * 2;
 #pragma unroll
-            for (int y = 0; y < 8; ++y) *reinterpret_cast<double*>(dst + y * C_PITCH) = gc[y];
+            for (int y = 0; y < 8; ++y) *reinterpret_cast<double*>(dst + y * DC_PITCH) = gc[y];
         }
         wave_sync();
         // A chroma row serves two pixel rows, i.e. two lanes (l and l ^ 4).  The even-row lane runs the row pass of the Cb
@@ -698,7 +716,7 @@ __global__ __launch_bounds__(64 * WPB, GRAY ? JPEZY_DEC_WAVES_GRAY : JPEZY_DEC_W
         // -- instead of both lanes computing both rows.
         const bool odd = (row & 1) != 0;
         double in[8], out[8];
-        const double2* src = reinterpret_cast<const double2*>(lds + m * C_MCU + (odd ? C_COMP : 0) + (row >> 1) * C_PITCH);
+        const double2* src = reinterpret_cast<const double2*>(lds + m * DC_MCU + (odd ? DC_COMP : 0) + (row >> 1) * DC_PITCH);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const double2 a = src[k];

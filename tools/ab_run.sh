@@ -19,7 +19,7 @@ if [ "${PMC:-0}" = "1" ]; then
   for lib in $ROOT/ab/libjpezy_*.so; do
     name=$(basename $lib .so); name=${name#libjpezy_}
     rm -rf /tmp/rp_ab
-    JPEZY_LIB=$lib timeout -k 10 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU --output-format csv -d /tmp/rp_ab -o pmc -- python3 $ROOT/bench.py --steps 20 --warmup 2 --repeats 1 --no-cpu "$@" > /dev/null 2>&1
+    JPEZY_LIB=$lib timeout -k 10 200 rocprofv3 --pmc ${PMC_LIST:-SQ_INSTS_VALU SQ_WAVES SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS} --output-format csv -d /tmp/rp_ab -o pmc -- python3 $ROOT/bench.py --steps 20 --warmup 2 --repeats 1 --no-cpu "$@" > /dev/null 2>&1
     f=$(find /tmp/rp_ab -name '*counter_collection.csv' | head -1)
     python3 - "$f" "$name" <<'PY' | tee -a $ROOT/$OUT
 import csv, sys

@@ -112,6 +112,7 @@ struct jpezy_ctx {
     // GPU entropy coder (jpezy_entropy.hip): code tables + scratch
     jpezy_dev::entropy::CodeTables* d_codes = nullptr;
     DevBuf e_bits, e_off, e_tmp, e_small, e_U, e_cnt, e_ffoff, e_out, e_coef;
+    DevBuf e_status;               // per-frame error flags of the device-resident entropy path: zero between calls (cleared by their consumer)
     uint8_t* e_pinned = nullptr;   // pinned host staging of the stuffed streams
     size_t e_pinned_cap = 0;
     DevBuf h_scan, h_U, h_cnt, h_off, h_state, h_setup, h_small, h_dc;   // GPU Huffman decoder (jpezy_huffdec.hip)
@@ -250,7 +251,7 @@ void jpezy_ctx_destroy(jpezy_ctx* c)
     c->scratch.release();
     if (c->d_codes) (void)hipFree(c->d_codes);
     if (c->e_pinned) (void)hipHostFree(c->e_pinned);
-    for (DevBuf* b : { &c->e_bits, &c->e_off, &c->e_tmp, &c->e_small, &c->e_U, &c->e_cnt, &c->e_ffoff, &c->e_out, &c->e_coef, &c->e_hdr,
+    for (DevBuf* b : { &c->e_bits, &c->e_off, &c->e_tmp, &c->e_small, &c->e_U, &c->e_cnt, &c->e_ffoff, &c->e_out, &c->e_coef, &c->e_hdr, &c->e_status,
                        &c->dump_t, &c->h_scan, &c->h_U, &c->h_cnt, &c->h_off, &c->h_state, &c->h_setup, &c->h_small, &c->h_dc }) b->release();
     delete c;
 }
@@ -778,14 +779,17 @@ int jpezy_write_jpeg_gpu_dev(jpezy_ctx* c, const int16_t* d_coeffs, int W, int H
         if (int rc = c->e_U.reserve(u_stride * F)) return rc;
         if (int rc = c->e_cnt.reserve(nchunks * sizeof(uint32_t))) return rc;
         if (int rc = c->e_ffoff.reserve((nchunks + 1) * sizeof(unsigned long long))) return rc;
-        unsigned* d_status = (unsigned*)c->e_small.p;
+        if (c->e_status.cap < sizeof(unsigned) * (size_t)F) {      // grown (first call, never inside a capture): zero it once;
+            if (int rc = c->e_status.reserve(sizeof(unsigned) * (size_t)F)) return rc;   // from then on plan_header_kernel clears what it reads
+            HIP_TRY(hipMemsetAsync(c->e_status.p, 0, c->e_status.cap, s));
+        }
+        unsigned* d_status = (unsigned*)c->e_status.p;
         unsigned long long* d_bytes = (unsigned long long*)c->e_small.p + F;
         uint8_t* out = d_out + (size_t)f0 * out_stride;
-        HIP_TRY(hipMemsetAsync(d_status, 0, sizeof(unsigned) * F, s));
         HIP_TRY(E::launch_block_bits(job, (uint32_t*)c->e_bits.p, d_status, s));
         HIP_TRY(E::launch_scan_u32((const uint32_t*)c->e_bits.p, (unsigned long long*)c->e_off.p, N, (unsigned long long*)c->e_tmp.p, s));
-        HIP_TRY(E::launch_frame_bytes((const unsigned long long*)c->e_off.p, nblk, F, d_bytes, s));
-        HIP_TRY(E::launch_zero_streams((uint32_t*)c->e_U.p, u_stride / 4, d_bytes, F, s));   // instead of a memset of the worst case
+        // clears what the later kernels touch of the worst-case buffer (not a memset of all of it) and publishes d_bytes
+        HIP_TRY(E::launch_zero_streams((uint32_t*)c->e_U.p, u_stride / 4, (const unsigned long long*)c->e_off.p, nblk, d_bytes, F, s));
         HIP_TRY(E::launch_emit(job, (const unsigned long long*)c->e_off.p, (uint32_t*)c->e_U.p, u_stride / 4, s));
         HIP_TRY(E::launch_ff_count((const uint32_t*)c->e_U.p, u_stride / 4, d_bytes, F, (uint32_t*)c->e_cnt.p, s));
         HIP_TRY(E::launch_scan_u32((const uint32_t*)c->e_cnt.p, (unsigned long long*)c->e_ffoff.p, nchunks, (unsigned long long*)c->e_tmp.p, s));

@@ -36,11 +36,13 @@ hipError_t launch_ff_count(const uint32_t* U, size_t u_stride_words, const unsig
 hipError_t launch_stuff(const uint32_t* U, size_t u_stride_words, const unsigned long long* frame_bytes, int n_frames,
                         const unsigned long long* ff_before, uint8_t* out, size_t out_stride, hipStream_t s);
 
-// device-resident variant (no host sync): per-frame stream lengths, the fit/size/EOI decision, the header copy
-hipError_t launch_frame_bytes(const unsigned long long* off, size_t per, int n_frames, unsigned long long* bytes, hipStream_t s);
-// clears, per frame, the part of the unstuffed stream buffer the later kernels touch (bytes[f] rounded up to a chunk, plus one)
-hipError_t launch_zero_streams(uint32_t* U, size_t u_stride_words, const unsigned long long* bytes, int n_frames, hipStream_t s);
-hipError_t launch_plan_and_header(unsigned long long* bytes, const unsigned long long* ffoff, size_t chunks_per_frame, const unsigned* status,
+// device-resident variant (no host sync).  launch_zero_streams clears, per frame, the part of the unstuffed stream buffer
+// the later kernels touch (the stream rounded up to a chunk, plus one) and publishes bytes[f] = ceil(bits of frame f / 8)
+// from the scanned block offsets off[] (per = blocks per frame).  launch_plan_and_header: the fit/size/EOI decision and the
+// header copy, one workgroup per frame; it consumes AND clears status[f] (the buffer must be zero before the first use).
+hipError_t launch_zero_streams(uint32_t* U, size_t u_stride_words, const unsigned long long* off, size_t per, unsigned long long* bytes,
+                               int n_frames, hipStream_t s);
+hipError_t launch_plan_and_header(unsigned long long* bytes, const unsigned long long* ffoff, size_t chunks_per_frame, unsigned* status,
                                   int n_frames, const uint8_t* hdr, size_t hdr_len, uint8_t* out, size_t out_stride, long long* sizes,
                                   hipStream_t s);
 

@@ -40,6 +40,7 @@ __device__ __forceinline__ void load_tables(LdsTables& L, const CodeTables* T)
 
 // MSB-first writer into 32-bit big-endian words of a zeroed buffer
 struct BitWriter {
+    static constexpr bool writes = true;
     unsigned long long acc;
     int nacc;
     uint32_t* wp;
@@ -69,71 +70,101 @@ struct BitWriter {
 };
 
 struct NoWriter {
+    static constexpr bool writes = false;
     __device__ __forceinline__ void put(uint32_t, int) {}
 };
 
-// codes of one block (ref :174-225).  z: 64 zig-zag coefficients (nullptr: an all-zero block), pred: DC of the previous
-// block of the component.  Returns the length in bits; err is set for values outside the Annex-K tables (the
+// codes of one block (ref :174-225).  z: 64 zig-zag coefficients in LDS (nullptr: an all-zero block), pred: DC of the
+// previous block of the component.  Returns the length in bits; err is set for values outside the Annex-K tables (the
 // reference throws / the host writer returns JPEZY_E_FORMAT).
+// The reference walks all 63 AC positions and counts zeros; here the lane first forms the 63-bit mask of its block's
+// non-zero AC coefficients (MSB = zig-zag position 1 ... so that the next coefficient is a count-leading-zeros away) and
+// then visits only those: the run before a coefficient is the gap between two set bits.  A wave's loop runs as long as
+// its fullest block has non-zero coefficients (about 25 of 63 on noise, a handful on pictures) and every iteration
+// does the same work in every lane -- the position-by-position loop paid both branch sides 63 times.
+// AC coefficients whose positions are the set bits of m (bit 31 - k: position base + k), in order.  Branch-light on
+// purpose: no early exit (a value outside the tables sets `bad` and is coded as size 10), the ZRL codes of the length pass
+// are a multiply, and the next coefficient is requested from LDS before the current one is coded -- each iteration then
+// waits for one LDS round trip (the code-table lookup), not two.
+template <class W>
+__device__ __forceinline__ void code_ac(uint32_t m, int base, const int16_t* z, int& prev, const uint32_t* ac, uint32_t zrl, W& w,
+                                        unsigned& len, unsigned& bad)
+{
+    int lz = __builtin_clz(m | 1u);
+    int vnext = z[base + lz];
+#pragma unroll 1
+    while (m) {
+        const int n = base + lz, v = vnext;
+        m &= 0x7FFFFFFFu >> lz;
+        lz = __builtin_clz(m | 1u);             // 31 when nothing is left: a harmless in-bounds read
+        vnext = z[base + lz];
+        int run = n - prev - 1;
+        prev = n;
+        const unsigned a = (unsigned)(v < 0 ? -v : v);
+        int sz = 32 - __builtin_clz(a);
+        bad |= (unsigned)(sz > 10);
+        sz = sz > 10 ? 10 : sz;
+        const int nz = run >> 4;                // ZRL codes in front of this coefficient (runs over 15, ref :198-206)
+        run &= 15;
+        if (W::writes) {
+            for (int r = nz; r > 0; --r) w.put(zrl >> 8, (int)(zrl & 0xFF));
+        }
+        len += (unsigned)nz * (zrl & 0xFF);
+        const uint32_t e = ac[(run << 4) | sz];
+        // code and value bits in one append: at most 16 + 10 bits
+        const int nb = (int)(e & 0xFF) + sz;
+        w.put(((e >> 8) << sz) | ((uint32_t)(v + (v >> 31)) & ((1u << sz) - 1u)), nb);
+        len += (unsigned)nb;
+    }
+}
+
 template <class W>
 __device__ __forceinline__ unsigned code_block(const int16_t* z, int pred, const uint32_t* dc, const uint32_t* ac, W& w,
                                                bool& err)
 {
-    unsigned len = 0;
-    uint4 c0 = make_uint4(0, 0, 0, 0);
-    if (z) c0 = *reinterpret_cast<const uint4*>(z);
+    unsigned len = 0, bad = 0;
+    uint32_t mhi = 0, mlo = 0;          // bit (31 - n) of mhi: position n in 0..31 is non-zero; mlo likewise for 32..63
+    int dcv = 0;
+    if (z) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const uint4 c = reinterpret_cast<const uint4*>(z)[k];
+            const uint32_t wd[4] = { c.x, c.y, c.z, c.w };
+            uint32_t m8 = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                m8 |= ((wd[j] & 0xFFFFu) ? 1u : 0u) << (7 - 2 * j);
+                m8 |= ((wd[j] >> 16) ? 1u : 0u) << (6 - 2 * j);
+            }
+            if (k < 4) mhi |= m8 << (24 - 8 * k); else mlo |= m8 << (24 - 8 * (k - 4));
+            if (k == 0) dcv = (int)(short)(c.x & 0xFFFFu);
+        }
+        mhi &= 0x7FFFFFFFu;             // position 0 is the DC
+    }
     {
-        const int dcv = (int)(short)(c0.x & 0xFFFFu);
         const int diff = dcv - pred;
         const unsigned a = (unsigned)(diff < 0 ? -diff : diff);
-        const int di = a ? 32 - __builtin_clz(a) : 0;
-        if (di > 11) { err = true; return 0; }
+        int di = a ? 32 - __builtin_clz(a) : 0;
+        bad |= (unsigned)(di > 11);
+        di = di > 11 ? 11 : di;
         const uint32_t e = dc[di];
-        w.put(e >> 8, (int)(e & 0xFF));
-        len += e & 0xFF;
-        if (di) {
-            w.put((uint32_t)(diff + (diff >> 31)) & ((1u << di) - 1u), di);
-            len += di;
-        }
+        // code and value bits in one append: at most 11 + 11 bits
+        const int n = (int)(e & 0xFF) + di;
+        w.put(((e >> 8) << di) | ((uint32_t)(diff + (diff >> 31)) & ((1u << di) - 1u)), n);
+        len += (unsigned)n;
     }
-    int run = 0;
+    int prev = 0;                        // position of the previous non-zero coefficient (0: the DC)
     if (z) {
-#pragma unroll 1
-        for (int k = 0; k < 8; ++k) {
-            const uint4 c = k ? reinterpret_cast<const uint4*>(z)[k] : c0;
-            const uint32_t wd[4] = { c.x, c.y, c.z, c.w };
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                if (k == 0 && j == 0) continue;
-                const int v = (int)(short)((wd[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu);
-                if (v == 0) {
-                    ++run;
-                } else {
-                    const unsigned a = (unsigned)(v < 0 ? -v : v);
-                    const int s = 32 - __builtin_clz(a);
-                    if (s > 10) { err = true; return 0; }
-                    if (run > 15) {
-                        const uint32_t zrl = ac[0xF0];
-                        for (int r = run >> 4; r > 0; --r) { w.put(zrl >> 8, (int)(zrl & 0xFF)); len += zrl & 0xFF; }
-                        run &= 15;
-                    }
-                    const uint32_t e = ac[(run << 4) | s];
-                    // code and value bits in one append: at most 16 + 10 bits
-                    const int n = (int)(e & 0xFF) + s;
-                    w.put(((e >> 8) << s) | ((uint32_t)(v + (v >> 31)) & ((1u << s) - 1u)), n);
-                    len += n;
-                    run = 0;
-                }
-            }
-        }
-    } else {
-        run = 63;
+        const uint32_t zrl = ac[0xF0];
+        code_ac(mhi, 0, z, prev, ac, zrl, w, len, bad);
+        code_ac(mlo, 32, z, prev, ac, zrl, w, len, bad);
     }
-    if (run) {
+    if (prev != 63) {                    // the block ends in zeros (or has no AC coefficient at all): EOB
         const uint32_t e = ac[0x00];
         w.put(e >> 8, (int)(e & 0xFF));
         len += e & 0xFF;
     }
+    if (bad) { err = true; return 0; }
     return len;
 }
 
@@ -294,6 +325,30 @@ size_t scan_tmp_elems(size_t n)
     return t + 4;
 }
 
+// second (and last) launch of a scan whose workgroup totals are few: every workgroup sums the totals in front of it
+// itself (nb * 8 bytes out of the L2) and adds that base to its 2048 elements; the last one also writes the grand total.
+// Replaces the recursive scan of the totals, the add pass and two device-to-device copies: 2 launches instead of 5.
+__global__ __launch_bounds__(SCAN_T) void scan_finish_kernel(unsigned long long* out, const unsigned long long* totals, size_t n, size_t nb)
+{
+    __shared__ unsigned long long wsum[SCAN_T / 64];
+    unsigned long long sum = 0;
+    for (size_t k = threadIdx.x; k < (size_t)blockIdx.x; k += SCAN_T) sum += totals[k];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d, 64);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    unsigned long long o = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_T / 64; ++k) o += wsum[k];
+    const size_t base = (size_t)blockIdx.x * SCAN_N + (size_t)threadIdx.x * SCAN_E;
+#pragma unroll
+    for (int k = 0; k < SCAN_E; ++k)
+        if (base + k < n) out[base + k] += o;
+    if (blockIdx.x == nb - 1 && threadIdx.x == 0) out[n] = o + totals[nb - 1];
+}
+
+constexpr size_t SCAN_FINISH_MAX_WGS = 4096;   // beyond it (n > 8.4 M) the totals are scanned recursively as before
+
 template <typename TIn>
 static hipError_t scan_exclusive(const TIn* in, unsigned long long* out, size_t n, unsigned long long* tmp, hipStream_t s)
 {
@@ -302,9 +357,9 @@ static hipError_t scan_exclusive(const TIn* in, unsigned long long* out, size_t 
     unsigned long long* raw = tmp;             // [nb] workgroup totals
     unsigned long long* scanned = tmp + nb;    // [nb + 1]
     hipLaunchKernelGGL((scan_local_kernel<TIn>), dim3((unsigned)nb), dim3(SCAN_T), 0, s, in, out, raw, n);
-    if (nb == 1) {
-        // total of the single workgroup is the grand total
-        return hipMemcpyAsync(out + n, raw, sizeof(unsigned long long), hipMemcpyDeviceToDevice, s);
+    if (nb <= SCAN_FINISH_MAX_WGS) {
+        hipLaunchKernelGGL(scan_finish_kernel, dim3((unsigned)nb), dim3(SCAN_T), 0, s, out, raw, n, nb);
+        return hipGetLastError();
     }
     hipError_t e = scan_exclusive<unsigned long long>(raw, scanned, nb, scanned + nb + 1, s);
     if (e != hipSuccess) return e;
@@ -466,72 +521,69 @@ hipError_t launch_stuff(const uint32_t* U, size_t u_stride_words, const unsigned
 size_t chunk_bytes() { return CHUNK; }
 
 // ---- fully device-side variant: sizes stay on the device, no host sync ----
-// bytes[f] = ceil(bits of frame f / 8)
-__global__ void frame_bytes_kernel(const unsigned long long* off, size_t per, int n_frames, unsigned long long* bytes)
-{
-    const int f = blockIdx.x * blockDim.x + threadIdx.x;
-    if (f < n_frames) bytes[f] = (off[(size_t)(f + 1) * per] - off[(size_t)f * per] + 7) / 8;
-}
-
 // U is sized for the worst case (208 bytes per block: 82 MB for a 4096x4096 frame, 5 MB of it used on noise, far less on
 // pictures); only what emit_kernel and the byte-stuffing kernels touch is cleared: the stream rounded up to a whole chunk,
-// plus one chunk.  4 KB per workgroup; the workgroups past the end leave at once.
-__global__ __launch_bounds__(256) void zero_streams_kernel(uint32_t* U, size_t u_stride_words, const unsigned long long* bytes)
+// plus one chunk.  4 KB per workgroup; the workgroups past the end leave at once.  The frame's stream length
+// bytes[f] = ceil(bits / 8) is formed here from the scanned offsets (workgroup 0 of the frame publishes it for the kernels
+// that follow) instead of in a launch of its own.
+__global__ __launch_bounds__(256) void zero_streams_kernel(uint32_t* U, size_t u_stride_words, const unsigned long long* off, size_t per,
+                                                          unsigned long long* bytes)
 {
     const size_t frame = blockIdx.y;
-    const unsigned long long need = (bytes[frame] + 2 * CHUNK - 1) / CHUNK * CHUNK;
-    const size_t off = ((size_t)blockIdx.x * 256 + threadIdx.x) * 16;
-    if (off >= need || off >= u_stride_words * 4) return;
-    *reinterpret_cast<uint4*>(reinterpret_cast<char*>(U + frame * u_stride_words) + off) = make_uint4(0, 0, 0, 0);
+    const unsigned long long nb = (off[(frame + 1) * per] - off[frame * per] + 7) / 8;
+    if (blockIdx.x == 0 && threadIdx.x == 0) bytes[frame] = nb;
+    const unsigned long long need = (nb + 2 * CHUNK - 1) / CHUNK * CHUNK;
+    const size_t o = ((size_t)blockIdx.x * 256 + threadIdx.x) * 16;
+    if (o >= need || o >= u_stride_words * 4) return;
+    *reinterpret_cast<uint4*>(reinterpret_cast<char*>(U + frame * u_stride_words) + o) = make_uint4(0, 0, 0, 0);
 }
 
-// one thread per frame, after the 0xFF scan: decide whether the frame fits, write its size and its EOI marker, and
-// disable the copy kernels for frames that failed (bytes[f] = 0)
-__global__ void plan_kernel(unsigned long long* bytes, const unsigned long long* ffoff, size_t chunks_per_frame, const unsigned* status,
-                            int n_frames, size_t hdr_len, uint8_t* out, size_t out_stride, long long* sizes)
+// One workgroup per frame, after the 0xFF scan: thread 0 decides whether the frame fits, writes its size and its EOI marker
+// and disables the copy kernel for a frame that failed (bytes[f] = 0); then the workgroup copies the header.  The frame's
+// error flag is cleared here -- by its only consumer -- so that no launch is spent on zeroing it before the next call.
+__global__ __launch_bounds__(256) void plan_header_kernel(unsigned long long* bytes, const unsigned long long* ffoff, size_t chunks_per_frame,
+                                                         unsigned* status, const uint8_t* hdr, size_t hdr_len, uint8_t* out,
+                                                         size_t out_stride, long long* sizes)
 {
-    const int f = blockIdx.x * blockDim.x + threadIdx.x;
-    if (f >= n_frames) return;
-    const unsigned long long body = bytes[f] + (ffoff[(size_t)(f + 1) * chunks_per_frame] - ffoff[(size_t)f * chunks_per_frame]);
-    const unsigned long long total = hdr_len + body + 2;
-    if (status[f]) { sizes[f] = -5; bytes[f] = 0; return; }              // JPEZY_E_FORMAT
-    if (total > out_stride) { sizes[f] = -6; bytes[f] = 0; return; }     // JPEZY_E_NOSPACE
-    uint8_t* dst = out + (size_t)f * out_stride;
-    dst[hdr_len + body] = 0xFF;
-    dst[hdr_len + body + 1] = 0xD9;
-    sizes[f] = (long long)total;
+    __shared__ int ok;
+    const size_t f = blockIdx.x;
+    uint8_t* dst = out + f * out_stride;
+    if (threadIdx.x == 0) {
+        const unsigned long long body = bytes[f] + (ffoff[(f + 1) * chunks_per_frame] - ffoff[f * chunks_per_frame]);
+        const unsigned long long total = hdr_len + body + 2;
+        const unsigned st = status[f];
+        status[f] = 0;
+        ok = 0;
+        if (st) { sizes[f] = -5; bytes[f] = 0; }                              // JPEZY_E_FORMAT
+        else if (total > out_stride) { sizes[f] = -6; bytes[f] = 0; }         // JPEZY_E_NOSPACE
+        else {
+            dst[hdr_len + body] = 0xFF;
+            dst[hdr_len + body + 1] = 0xD9;
+            sizes[f] = (long long)total;
+            ok = 1;
+        }
+    }
+    __syncthreads();
+    if (ok)
+        for (size_t i = threadIdx.x; i < hdr_len; i += 256) dst[i] = hdr[i];
 }
 
-__global__ void header_copy_kernel(const uint8_t* hdr, size_t hdr_len, const unsigned long long* bytes, int n_frames, uint8_t* out,
-                                   size_t out_stride)
-{
-    const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t f = g / hdr_len, i = g - f * hdr_len;
-    if (f < (size_t)n_frames && bytes[f]) out[f * out_stride + i] = hdr[i];
-}
-
-hipError_t launch_frame_bytes(const unsigned long long* off, size_t per, int n_frames, unsigned long long* bytes, hipStream_t s)
-{
-    hipLaunchKernelGGL(frame_bytes_kernel, dim3((unsigned)((n_frames + 63) / 64)), dim3(64), 0, s, off, per, n_frames, bytes);
-    return hipGetLastError();
-}
-
-hipError_t launch_zero_streams(uint32_t* U, size_t u_stride_words, const unsigned long long* bytes, int n_frames, hipStream_t s)
+hipError_t launch_zero_streams(uint32_t* U, size_t u_stride_words, const unsigned long long* off, size_t per, unsigned long long* bytes,
+                               int n_frames, hipStream_t s)
 {
     const size_t wgs = (u_stride_words * 4 + 4095) / 4096;
     if (!wgs || n_frames <= 0) return hipSuccess;
-    hipLaunchKernelGGL(zero_streams_kernel, dim3((unsigned)wgs, (unsigned)n_frames), dim3(256), 0, s, U, u_stride_words, bytes);
+    hipLaunchKernelGGL(zero_streams_kernel, dim3((unsigned)wgs, (unsigned)n_frames), dim3(256), 0, s, U, u_stride_words, off, per, bytes);
     return hipGetLastError();
 }
 
-hipError_t launch_plan_and_header(unsigned long long* bytes, const unsigned long long* ffoff, size_t chunks_per_frame, const unsigned* status,
+hipError_t launch_plan_and_header(unsigned long long* bytes, const unsigned long long* ffoff, size_t chunks_per_frame, unsigned* status,
                                   int n_frames, const uint8_t* hdr, size_t hdr_len, uint8_t* out, size_t out_stride, long long* sizes,
                                   hipStream_t s)
 {
-    hipLaunchKernelGGL(plan_kernel, dim3((unsigned)((n_frames + 63) / 64)), dim3(64), 0, s, bytes, ffoff, chunks_per_frame, status, n_frames,
-                       hdr_len, out, out_stride, sizes);
-    const size_t n = hdr_len * (size_t)n_frames;
-    hipLaunchKernelGGL(header_copy_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, hdr, hdr_len, bytes, n_frames, out, out_stride);
+    if (n_frames <= 0) return hipSuccess;
+    hipLaunchKernelGGL(plan_header_kernel, dim3((unsigned)n_frames), dim3(256), 0, s, bytes, ffoff, chunks_per_frame, status, hdr, hdr_len,
+                       out, out_stride, sizes);
     return hipGetLastError();
 }
 

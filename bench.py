@@ -408,6 +408,10 @@ def run_rank(args):
 
     W, H, gray, fps, direction, desc = WORKLOADS[args.workload]
     with_entropy = direction == "encode+entropy"
+    if with_entropy and (args.streams > 1 or args.pipelined):
+        # the entropy stage keeps its scratch (code lengths, offsets, unstuffed stream) in the context: two calls in flight on
+        # one context would overwrite each other's offsets (include/jpezy_hip.h); frames in flight need a context each
+        raise SystemExit("--streams / --pipelined are not available for encode4096_jpg: one entropy-stage call in flight per context")
     ctx = J.Context(local_rank)
     if args.variant is not None:
         ctx.set_variant(args.variant)

@@ -180,7 +180,10 @@ int jpezy_write_jpeg_gpu_batch(jpezy_ctx* ctx, const int16_t* d_coeffs, int W, i
  * stream; the coefficients must have been produced on it or be complete), nothing is copied to the host, no host
  * synchronisation.  Frame f's complete file (header, entropy-coded segment, EOI) is written at d_out + f*out_stride
  * and d_sizes[f] (device memory) receives its length, JPEZY_E_FORMAT or JPEZY_E_NOSPACE (out_stride too small; nothing
- * is written past it).  Scratch is sized for the worst case of 208 bytes per block.
+ * is written past it).  Scratch is sized for the worst case of 208 bytes per block and LIVES IN THE CONTEXT (code lengths,
+ * bit offsets, the unstuffed stream): calls of the entropy entry points (this one, jpezy_write_jpeg_gpu[_batch],
+ * jpezy_encode_jpeg, jpezy_read_jpeg_gpu, jpezy_decode_jpeg) on one context must not overlap in time -- issue them on one
+ * stream or order the streams with events; frames that are to be in flight together need a context each.
  */
 int jpezy_write_jpeg_gpu_dev(jpezy_ctx* ctx, const int16_t* d_coeffs, int W, int H, int gray, int n_frames,
                              const char* comment, uint8_t* d_out, size_t out_stride, long long* d_sizes, void* stream);

@@ -609,8 +609,8 @@ def run_rank(args):
             traffic = None
         metric = {"encode": "Mpixels/s encode (FDCT+quant)", "decode": "Mpixels/s decode (dequant+IDCT)",
                   "encode+entropy": "Mpixels/s encode (FDCT+quant + GPU Huffman stage)"}[direction]
-        kernel = ("f32::fdct_quant_f32_kernel" if args.variant in (None, 1) else "fdct_quant_kernel") \
-            if direction.startswith("encode") else "dequant_idct_kernel"
+        kernel = {None: "f32::fdct_quant_f32_kernel", 1: "f32::fdct_quant_f32_kernel", 2: "f32::fdct_quant_mfma_kernel",
+                  0: "fdct_quant_kernel"}[args.variant] if direction.startswith("encode") else "dequant_idct_kernel"
         out = {
             "metric": metric,
             "value": round(total_px / elapsed / 1e6, 2),
@@ -628,7 +628,8 @@ def run_rank(args):
             "vs_baseline": None,
             # the arithmetic the path computes in: encode variant 1 = FP32 first level (FP64 only on guard-band hits),
             # encode variant 0 and decode = FP64; either way the results are the reference's FP64 results bit for bit
-            "dtype": "f32+f64 guard" if (direction.startswith("encode") and args.variant in (None, 1)) else "f64",
+            "dtype": ("f64" if not direction.startswith("encode") or args.variant == 0 else
+                      "f16-limb MFMA (luma) + f32, f64 guard" if args.variant == 2 else "f32+f64 guard"),
             "data": "synthetic",
             "config": {"workload": desc, "name": args.workload, "width": W, "height": H, "mode": "gray" if gray else "color",
                        "frames_per_step": fps, "ring_batches": ring, "pixels_per_step_per_gpu": px_per_step,
@@ -670,7 +671,8 @@ def parse_args(argv=None):
     ap.add_argument("--repeats", type=int, default=11, help="replays of the K-step sequence; ms_per_step is their median")
     ap.add_argument("--workload", default="encode4096", choices=sorted(WORKLOADS))
     ap.add_argument("--ring", type=int, default=0, help="distinct batches in the ring (0 = enough to exceed 512 MiB)")
-    ap.add_argument("--variant", type=int, default=None, help="encode kernel variant (0 FP64 butterflies, 1 FP32 first level)")
+    ap.add_argument("--variant", type=int, default=None, help="encode kernel variant (0 FP64 butterflies, 1 FP32 first level [default], "
+                                                                 "2 = 1 with the luma transforms on the matrix pipe, opt-in)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--batch", action="store_true", help="measure the configs[3] batch pipeline also at N = 1")
     ap.add_argument("--no-batch", action="store_true", help="N > 1: skip the configs[3] batch measurement")

@@ -138,7 +138,10 @@ int jpezy_dequant_idct_generic_dev(jpezy_ctx* ctx, const int16_t* d_coeffs, cons
  * parity tests. */
 void jpezy_ctx_set_force_exact(jpezy_ctx* ctx, int on);
 /* Encode kernel variant: 0 = FP64 butterflies (round-1 kernel), 1 = FP32 first level + FP64 second level +
- * reference-order third level.  Both produce identical coefficients; they differ in speed only. */
+ * reference-order third level (default), 2 = variant 1 with the luma transforms of a quad as one f16-limb matrix product on
+ * the matrix pipe.  All produce identical coefficients in every test; they differ in speed -- and in what the exactness
+ * rests on: variants 0 and 1 on proven error bounds, variant 2 on a MEASURED model of the undocumented accumulation inside
+ * v_mfma_f32_16x16x32_f16 (opt-in for that reason). */
 int jpezy_ctx_set_variant(jpezy_ctx* ctx, int variant);
 /* Synchronises the device and returns how many coefficients/samples were resolved through the
  * exact-order fallback on this context since the previous call (the counter is then reset); -1 on error */

@@ -34,6 +34,14 @@ struct DeviceTables {
     double rq_dc[2];          // 1 / Q_t[0]
     int qt[2][64];            // natural order
     double qinv[2][64];       // 1.0 / Q_t[k] (levels 2/3 of the f32 kernel)
+    // encode variant 2 (luma transforms on the matrix pipe): A operands of v_mfma_f32_16x16x32_f16.  Fragment
+    // f = (limb * 2 + kstep) * 4 + mtile (limb 0 = low); lane l holds the 8 f16 values
+    //   G[p = 16 mtile + (l & 15)][k = 32 kstep + 8 (l >> 4) + jj] * 2^12,  jj = 0..7,  k = 8 y + x,
+    //   G[p][k] = cos_i(y) cos_j(x) cu(j) cv(i) / (4 Q_luma[i*8+j]) for the coefficient (i, j) at zig-zag position p,
+    //   G[0][k] = 1 (the DC row delivers the exact sample sum for the dcq lookup); the samples are scaled by 2^-12.
+    uint16_t mfma_a[16][64][8];
+    // guard band of the four coefficients p = 16 mtile + 4 g .. + 3 a lane (g = lane >> 4) receives per row tile
+    float mfma_delta[4][4];
 };
 
 // The exact-path counter is sharded over COUNTER_SHARDS words: thousands of waves adding to ONE word serialise
@@ -101,6 +109,8 @@ hipError_t launch_fdct_quant(const EncParams& p, bool gray, bool force_exact, hi
 // coefficient through the reference-order chain, 2 every coefficient through the FP64 second level, 3 every quad
 // through the per-lane evaluator of the queue-overflow case.
 hipError_t launch_fdct_quant_f32(const EncParams& p, bool gray, int force, hipStream_t stream);
+// variant 2: variant 1 with the luma transforms on the matrix pipe (opt-in: measured error model, jpezy_kernels_f32.hip)
+hipError_t launch_fdct_quant_mfma(const EncParams& p, bool gray, int force, hipStream_t stream);
 hipError_t launch_dequant_idct(const DecParams& p, bool gray, bool force_exact, hipStream_t stream);
 
 // any-layout decode (jpezy_kernels_generic.hip)

@@ -314,7 +314,7 @@ __device__ __forceinline__ void quant_block_column(const float* F, const float* 
 #ifdef JPEZY_DUMP_T
                                                    , float* dump_quad
 #endif
-                                                   )
+                                                   , int qcap = QUEUE_CAP)
 {
 #ifdef JPEZY_DUMP_T   // diagnostic build: the level-1 values exactly as the guard test sees them
     if (live && dump_quad)
@@ -339,7 +339,7 @@ __device__ __forceinline__ void quant_block_column(const float* F, const float* 
                 if (force) f = true;
                 if (f) {
                     const unsigned slot = atomicAdd(&queue[0], 1u);
-                    if (slot < (unsigned)QUEUE_CAP)
+                    if (slot < (unsigned)qcap)
                         reinterpret_cast<unsigned short*>(queue + 1)[slot] = (unsigned short)((blk << 6) | (i * 8 + j));
                 }
             }
@@ -685,6 +685,410 @@ __global__ __launch_bounds__(64 * WPB, JPEZY_F32_WAVES) void fdct_quant_f32_kern
 #endif
 }
 
+// ======================================================================================================
+// Encode, variant 2: the luma transforms of a quad as one matrix product on the matrix pipe (v_mfma_f32_16x16x32_f16, the
+// constants as two f16 limbs), everything else as in variant 1 (colour conversion with its guard band, chroma butterflies on
+// the VALU, levels 2 and 3 for guard-band hits, exact DC table).  OPT-IN (jpezy_ctx_set_variant(ctx, 2)): the accumulation
+// inside an f16 MFMA is undocumented and is NOT a correctly rounded dot product (tools/ubench/mfma_f16_numerics.hip), so the
+// level-1 guard band of this variant rests on a measured error model (40 x 2^-24 x sum |x G| per coefficient: twice the worst
+// error seen per instruction, four instructions per chain, plus the limb truncation), not on a proof -- DESIGN.md section 4.
+// ======================================================================================================
+constexpr int WPB2 = 2;                           // waves per workgroup (as variant 1: the waves never talk to each other)
+constexpr int XB_PITCH = 144, XM_PITCH = 4 * XB_PITCH + 16;      // sample exchange tile: bytes per block / per MCU (f16 samples)
+constexpr int REGA_BYTES = (4 * XM_PITCH > CT_BYTES) ? 4 * XM_PITCH : CT_BYTES;     // exchange tile, later the chroma tile
+constexpr int TILE2_BYTES = REGA_BYTES + STG_BYTES;
+constexpr int QUEUE2_DWORDS = 64;
+constexpr int QUEUE2_CAP = 2 * (QUEUE2_DWORDS - 1);
+constexpr int WAVE2_LDS_DWORDS = TILE2_BYTES / 4 + QUEUE2_DWORDS;
+__constant__ unsigned char c_zz[64] = JPEZY_ZZ_INIT;
+
+template <bool GRAY, bool ALIGNED, int FORCE>
+__global__ __launch_bounds__(64 * WPB2, JPEZY_F32_WAVES) void fdct_quant_mfma_kernel(EncParams p)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t lds_all[WPB2][WAVE2_LDS_DWORDS];
+    constexpr int BPM = GRAY ? 4 : 6;
+
+    // WPB waves per workgroup; the wave index is made an SGPR so that everything derived from it (quad position, plane
+    // and coefficient base addresses, the LDS slice) is computed once on the scalar unit
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    // The constant operands (16 KB, the same for every wave of the launch) are read from global memory, i.e. out of the L1/L2:
+    // a copy in LDS would have to be shared by ten waves to fit -- measured: workgroups of ten waves behind one barrier run in
+    // lockstep phases and release their slots only together, 40.9 us per 4096^2 frame.
+    const uint4* atab = reinterpret_cast<const uint4*>(p.tab->mfma_a);
+    const unsigned qidx = blockIdx.x * (unsigned)WPB2 + (unsigned)wave;          // quad index inside the frame
+    if (qidx >= (unsigned)(p.mcu_rows * p.quads_per_row)) return;     // wave-uniform
+    const int frame = (int)blockIdx.y;
+    const int mcu_y = (int)fast_div(qidx, p.qpr_magic, p.qpr_shift);
+    const int quad_x = (int)qidx - mcu_y * p.quads_per_row;
+
+#ifdef JPEZY_TRACE
+    const unsigned long long tr_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    uint32_t* lds = lds_all[wave];
+    float* ldsf = reinterpret_cast<float*>(lds);
+    unsigned* queue = lds + TILE2_BYTES / 4;                            // [0] = count, then 16-bit entries
+    if (lane == 0) queue[0] = 0;
+    const int row = lane >> 2, m = lane & 3;
+    const int mcu_x_raw = quad_x * 4 + m;
+    const bool live = mcu_x_raw < p.mcu_cols;
+    const int mcu_x = live ? mcu_x_raw : p.mcu_cols - 1;
+    const int W = p.W, H = p.H;
+    const uint8_t* pr = p.r + (size_t)frame * p.plane_stride;
+    const uint8_t* pg = p.g + (size_t)frame * p.plane_stride;
+    const uint8_t* pb = p.b + (size_t)frame * p.plane_stride;
+    const DeviceTables* tab = p.tab;
+#ifdef JPEZY_DUMP_T
+    float* dump_quad = p.dump_t ? p.dump_t + (size_t)frame * p.coeffs_per_frame + ((size_t)mcu_y * p.mcu_cols + (size_t)quad_x * 4) * (BPM * 64) : nullptr;
+#define DUMP_ARG , dump_quad
+#else
+#define DUMP_ARG
+#endif
+
+    // ---- 1. this lane's 16-pixel row segment of the three planes ----
+    uint32_t R[4], G[4], B[4];
+    {
+        const int y = min(mcu_y * 16 + row, H - 1);                   // edge replication, ref :101
+        const unsigned rowoff = (unsigned)y * (unsigned)W;            // W, H <= 65535 (launcher): fits 32 bits
+        if (ALIGNED) {
+            const unsigned off = rowoff + (unsigned)mcu_x * 16u;
+            const uint4 vr = *reinterpret_cast<const uint4*>(pr + off);
+            const uint4 vg = *reinterpret_cast<const uint4*>(pg + off);
+            const uint4 vb = *reinterpret_cast<const uint4*>(pb + off);
+            R[0] = vr.x; R[1] = vr.y; R[2] = vr.z; R[3] = vr.w;
+            G[0] = vg.x; G[1] = vg.y; G[2] = vg.z; G[3] = vg.w;
+            B[0] = vb.x; B[1] = vb.y; B[2] = vb.z; B[3] = vb.w;
+        } else {
+#pragma unroll
+            for (int w4 = 0; w4 < 4; ++w4) {
+                uint32_t ar = 0, ag = 0, ab = 0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int x = min(mcu_x * 16 + w4 * 4 + k, W - 1);   // ref :104
+                    ar |= (uint32_t)pr[rowoff + x] << (8 * k);
+                    ag |= (uint32_t)pg[rowoff + x] << (8 * k);
+                    ab |= (uint32_t)pb[rowoff + x] << (8 * k);
+                }
+                R[w4] = ar; G[w4] = ag; B[w4] = ab;
+            }
+        }
+    }
+
+#ifdef JPEZY_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long tr_t1 = __builtin_amdgcn_s_memrealtime();
+#endif
+    // ---- 2'. luma samples (integers held as floats in ys[], also for the rare levels 2 and 3); packed to f16 (exact:
+    //          |Y| <= 128), scaled by 2^-12 (the constant operands carry 2^12 so that both of their f16 limbs are normal
+    //          numbers) and exchanged through LDS into the B-operand layout of v_mfma_f32_16x16x32_f16 ----
+    float ys[16], cs[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    {
+        luma8(R, G, B, ys);
+        luma8(R + 2, G + 2, B + 2, ys + 8);
+        typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+        uint32_t hp[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            h2_t v = __builtin_bit_cast(h2_t, __builtin_amdgcn_cvt_pkrtz(ys[2 * q], ys[2 * q + 1]));
+            v = v * h2_t{ (_Float16)0x1p-12f, (_Float16)0x1p-12f };
+            hp[q] = __builtin_bit_cast(uint32_t, v);
+        }
+        char* xt = reinterpret_cast<char*>(lds) + m * XM_PITCH + ((row >> 3) * 2) * XB_PITCH + (row & 7) * 16;
+        *reinterpret_cast<uint4*>(xt) = make_uint4(hp[0], hp[1], hp[2], hp[3]);                 // row of the left block
+        *reinterpret_cast<uint4*>(xt + XB_PITCH) = make_uint4(hp[4], hp[5], hp[6], hp[7]);      // row of the right block
+    }
+    __builtin_amdgcn_sched_barrier(0);   // keep the phases apart: the scheduler otherwise overlaps them and needs >80 VGPRs
+    // ---- 2b. chroma samples (top-left pixel of every 2x2, ref :134-142): the odd-row lane takes its even neighbour's
+    //         pixels (DPP row_shr:4) and computes Cr, the even-row lane Cb.  Only the samples survive, so the raw
+    //         pixel registers die here. ----
+    if (!GRAY) {
+        const bool odd = (row & 1) != 0;
+        uint32_t R2[4], G2[4], B2[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            R2[k] = (uint32_t)__builtin_amdgcn_update_dpp((int)R[k], (int)R[k], 0x114, 0xF, 0xA, false);
+            G2[k] = (uint32_t)__builtin_amdgcn_update_dpp((int)G[k], (int)G[k], 0x114, 0xF, 0xA, false);
+            B2[k] = (uint32_t)__builtin_amdgcn_update_dpp((int)B[k], (int)B[k], 0x114, 0xF, 0xA, false);
+        }
+        // (Cb, Cr) = (-.1687 R - .3313 G + .5 B), (.5 R - .4187 G - .0813 B)   (ref :249-256)
+        const float k1 = odd ? 0.5f : -0.1687f, k2 = odd ? -0.4187f : -0.3313f, k3 = odd ? -0.0813f : 0.5f;
+        float cv[8], e[8];
+        chroma_px2<0, 2>(R2[0], G2[0], B2[0], R2[0], G2[0], B2[0], k1, k2, k3, cv[0], cv[1], e[0], e[1]);
+        chroma_px2<0, 2>(R2[1], G2[1], B2[1], R2[1], G2[1], B2[1], k1, k2, k3, cv[2], cv[3], e[2], e[3]);
+        __builtin_amdgcn_sched_barrier(0);
+        chroma_px2<0, 2>(R2[2], G2[2], B2[2], R2[2], G2[2], B2[2], k1, k2, k3, cv[4], cv[5], e[4], e[5]);
+        chroma_px2<0, 2>(R2[3], G2[3], B2[3], R2[3], G2[3], B2[3], k1, k2, k3, cv[6], cv[7], e[6], e[7]);
+        constexpr float TH = 0.5f - CHROMA_EPS;
+#ifdef JPEZY_ABL_NOCFLAG
+        if (false) {
+#else
+        if (wave_any(absmax8(e) > TH)) {
+#endif
+            bool f;
+            f = __builtin_fabsf(e[0]) > TH; if (wave_any(f)) { if (f) cv[0] = chroma_px_ref<0>(R2[0], G2[0], B2[0], odd); }
+            f = __builtin_fabsf(e[1]) > TH; if (wave_any(f)) { if (f) cv[1] = chroma_px_ref<2>(R2[0], G2[0], B2[0], odd); }
+            f = __builtin_fabsf(e[2]) > TH; if (wave_any(f)) { if (f) cv[2] = chroma_px_ref<0>(R2[1], G2[1], B2[1], odd); }
+            f = __builtin_fabsf(e[3]) > TH; if (wave_any(f)) { if (f) cv[3] = chroma_px_ref<2>(R2[1], G2[1], B2[1], odd); }
+            f = __builtin_fabsf(e[4]) > TH; if (wave_any(f)) { if (f) cv[4] = chroma_px_ref<0>(R2[2], G2[2], B2[2], odd); }
+            f = __builtin_fabsf(e[5]) > TH; if (wave_any(f)) { if (f) cv[5] = chroma_px_ref<2>(R2[2], G2[2], B2[2], odd); }
+            f = __builtin_fabsf(e[6]) > TH; if (wave_any(f)) { if (f) cv[6] = chroma_px_ref<0>(R2[3], G2[3], B2[3], odd); }
+            f = __builtin_fabsf(e[7]) > TH; if (wave_any(f)) { if (f) cv[7] = chroma_px_ref<2>(R2[3], G2[3], B2[3], odd); }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) cs[k] = cv[k];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    wave_sync();
+
+    // ---- 3'+4'. the sixteen luma blocks of the quad as ONE matrix product on the matrix pipe:
+    //   t[p][n] = sum_k G[p][k] * x[k][n],  p = zig-zag position, k = 8 y + x, n = 4 m + 2 by + bx the block,
+    //   G[p][k] = cos_i(y) cos_j(x) cu cv / (4 Q) (DeviceTables::mfma_a: two f16 limbs, rows in zig-zag order, quantiser folded
+    //   in; row 0 is all ones so that the DC comes out as the exact sample sum for the table lookup).
+    // 4 row tiles x 2 K steps x 2 limbs = 16 v_mfma_f32_16x16x32_f16; lane (g = lane >> 4, n = lane & 15) receives
+    // t[16 T + 4 g + r][n], r = 0..3: four consecutive zig-zag positions per tile -- one 8-byte store into the staging area.
+    const int cq = row, j = cq & 7;
+    const unsigned ju = (unsigned)j;
+    const int n_blk = lane & 15, g4 = lane >> 4;
+    typedef _Float16 h8_t __attribute__((ext_vector_type(8)));
+    typedef float f4_t __attribute__((ext_vector_type(4)));
+    h8_t bfrag[2];
+    {
+        const char* xr = reinterpret_cast<const char*>(lds) + (n_blk >> 2) * XM_PITCH + (n_blk & 3) * XB_PITCH + g4 * 16;
+        bfrag[0] = __builtin_bit_cast(h8_t, *reinterpret_cast<const uint4*>(xr));          // block row g (K step 0)
+        bfrag[1] = __builtin_bit_cast(h8_t, *reinterpret_cast<const uint4*>(xr + 64));     // block row g + 4 (K step 1)
+    }
+    wave_sync();   // exchange tile consumed; the slice is reused (chroma tile | staging)
+    char* stage = reinterpret_cast<char*>(lds) + REGA_BYTES;
+    const int bx = cq >> 3;
+    char* sbase = stage + (m * BPM + bx) * STG_BLK;
+    const F32Column* lcol = &tab->f32col[0][ju];
+    const uint32_t zz_lo = lcol->zz_lo, zz_hi = lcol->zz_hi;
+    const signed char* dcq_l = p.dcq_luma;
+    const signed char* dcq_c = p.dcq_chroma;
+    {
+        f4_t acc[4];
+#pragma unroll
+        for (int T = 0; T < 4; ++T) acc[T] = f4_t{ 0.f, 0.f, 0.f, 0.f };
+#pragma unroll
+        for (int hs = 0; hs < 4; ++hs) {            // limb (low first: the small terms are accumulated first), K step
+#pragma unroll
+            for (int T = 0; T < 4; ++T) {
+                const h8_t afrag = __builtin_bit_cast(h8_t, atab[(hs * 4 + T) * 64 + lane]);
+                acc[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(afrag, bfrag[hs & 1], acc[T], 0, 0, 0);
+            }
+        }
+        const int lblk = (n_blk >> 2) * BPM + (n_blk & 3);                       // block index inside the quad's staging area
+        const bool live_n = quad_x * 4 + (n_blk >> 2) < p.mcu_cols;
+        // the block's quantised DC from the exact table: the sample sum (row 0 of G is ones: exact) is this lane's acc[0][0]
+        int dcv = 0;
+        if (g4 == 0) {
+            const unsigned si = (unsigned)(__builtin_fminf(__builtin_fmaxf(acc[0][0], -8192.f), 8192.f) + 8192.f);
+            dcv = dcq_l[si];
+        }
+        bool cand = false;
+        int q[16];
+#pragma unroll
+        for (int T = 0; T < 4; ++T) {
+            float d[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float t = acc[T][r];
+                q[4 * T + r] = (int)t;
+                d[r] = __builtin_fabsf(t - __builtin_rintf(t));
+            }
+            if (T == 0 && g4 == 0) d[0] = 1.f;                                  // the DC never uses the guard band
+            const float dmin = __builtin_fminf(__builtin_fminf(d[0], d[1]), __builtin_fminf(d[2], d[3]));
+            cand = cand || dmin < tab->mfma_delta[T][g4];
+        }
+        if (g4 == 0) q[0] = dcv;
+#ifdef JPEZY_DUMP_T
+        if (live_n && dump_quad)
+#pragma unroll
+            for (int T = 0; T < 4; ++T)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dump_quad[lblk * 64 + (int)c_zz[16 * T + 4 * g4 + r]] = acc[T][r];
+#endif
+        if (FORCE == 0 && wave_any(cand)) {
+            if (cand && live_n) {
+#pragma unroll
+                for (int T = 0; T < 4; ++T)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float t = acc[T][r];
+                        const int pz = 16 * T + 4 * g4 + r;
+                        if (__builtin_fabsf(t - __builtin_rintf(t)) < tab->mfma_delta[T][g4] && __builtin_fabsf(t) > 0.5f && pz != 0) {
+                            const unsigned slot = atomicAdd(&queue[0], 1u);
+                            if (slot < (unsigned)QUEUE2_CAP)
+                                reinterpret_cast<unsigned short*>(queue + 1)[slot] = (unsigned short)((lblk << 6) | (int)c_zz[pz]);
+                        }
+                    }
+            }
+        }
+#pragma unroll
+        for (int T = 0; T < 4; ++T) {
+            const uint32_t lo = ((uint32_t)q[4 * T] & 0xFFFFu) | ((uint32_t)q[4 * T + 1] << 16);
+            const uint32_t hi = ((uint32_t)q[4 * T + 2] & 0xFFFFu) | ((uint32_t)q[4 * T + 3] << 16);
+            *reinterpret_cast<uint2*>(stage + lblk * STG_BLK + 32 * T + 8 * g4) = make_uint2(lo, hi);
+        }
+    }
+
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- 5. chroma row pass, transpose, column pass ----
+    if (!GRAY) {
+        const bool odd = (row & 1) != 0;
+        float cX[8];
+        fdct8f(cs, cX);
+        float4* dst = reinterpret_cast<float4*>(ldsf + m * C_MCU + (odd ? C_COMP : 0) + (row >> 1) * C_PITCH);
+        dst[0] = make_float4(cX[0], cX[1], cX[2], cX[3]);
+        dst[1] = make_float4(cX[4], cX[5], cX[6], cX[7]);
+        wave_sync();
+
+        float Fc[8];
+        int dc_c;
+        {
+            float col[8];
+            const float* src = ldsf + m * C_MCU + (cq >> 3) * C_COMP + j;
+#pragma unroll
+            for (int rr = 0; rr < 8; ++rr) col[rr] = src[rr * C_PITCH];
+            dc_c = dc_lookup(col, dcq_c);
+            fdct8f(col, Fc);
+        }
+        float ks[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ks[i] = lcol[8].ks[i];
+        quant_block_column(Fc, ks, lcol[8].delta1, j, dc_c, live, sbase, zz_lo, zz_hi, 4 * STG_BLK, m * BPM + 4 + bx, queue, FORCE != 0 DUMP_ARG, QUEUE2_CAP);
+    }
+    wave_sync();
+
+    // ---- 5b. levels 2 and 3 for the queued coefficients (FORCE 1/2: every coefficient of the quad) ----
+    const unsigned nq = queue[0];
+    if (FORCE == 3 || (FORCE == 0 && nq > (unsigned)QUEUE2_CAP)) {
+        // More guard-band hits than the queue holds (adversarial patterns; FORCE 3 exercises it): every lane evaluates
+        // the 24 coefficients of its three block columns in the reference's order by itself.  The integer samples go
+        // to LDS as bytes (1.5 KB in the dead chroma tile); a lane walks its block row by row, keeps the eight running
+        // sums of its column (i = 0..7) and adds (pic * cos[j][x]) * cos[i][y] for x = 0..7 to each -- for every i
+        // exactly the reference's sequence (ref :146-166).  ~3,500 FP64 operations per lane, 7 us per wave, against
+        // ~1 ms for the cooperative path on all 1536 coefficients.
+        signed char* smp = reinterpret_cast<signed char*>(lds);
+        {
+            uint32_t w4[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                w4[k] = ((uint32_t)(int)ys[4 * k] & 0xFFu) | (((uint32_t)(int)ys[4 * k + 1] & 0xFFu) << 8) |
+                        (((uint32_t)(int)ys[4 * k + 2] & 0xFFu) << 16) | (((uint32_t)(int)ys[4 * k + 3] & 0xFFu) << 24);
+            const int by = row >> 3, y = row & 7;
+            uint32_t* d0 = reinterpret_cast<uint32_t*>(smp + ((m * 4 + by * 2) * 64 + y * 8));
+            d0[0] = w4[0]; d0[1] = w4[1];
+            d0[16] = w4[2]; d0[17] = w4[3];                      // the right block, 64 bytes further
+            if (!GRAY) {
+#pragma unroll
+                for (int k = 0; k < 2; ++k)
+                    w4[k] = ((uint32_t)(int)cs[4 * k] & 0xFFu) | (((uint32_t)(int)cs[4 * k + 1] & 0xFFu) << 8) |
+                            (((uint32_t)(int)cs[4 * k + 2] & 0xFFu) << 16) | (((uint32_t)(int)cs[4 * k + 3] & 0xFFu) << 24);
+                uint32_t* dc = reinterpret_cast<uint32_t*>(smp + 1024 + ((m * 2 + (row & 1)) * 64 + (row >> 1) * 8));
+                dc[0] = w4[0]; dc[1] = w4[1];
+            }
+        }
+        wave_sync();
+        const double cu = j ? 1.0 : JPEZY_S;
+#pragma unroll 1
+        for (int bc = 0; bc < (GRAY ? 2 : 3); ++bc) {
+            // block column bc of this lane: 0 top luma block, 1 bottom luma block, 2 chroma block (Cb / Cr by cq >> 3)
+            const int blk = m * BPM + (bc < 2 ? bc * 2 + bx : 4 + bx);
+            const signed char* src = bc < 2 ? smp + (m * 4 + bc * 2 + bx) * 64 : smp + 1024 + (m * 2 + bx) * 64;
+            const int tbl = bc < 2 ? 0 : 1;
+            double S[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+#pragma unroll 1
+            for (int y = 0; y < 8; ++y) {
+                // x is not unrolled: this path must not raise the kernel's register count (it is never the hot one)
+#pragma unroll 1
+                for (int x = 0; x < 8; ++x) {
+                    const double px = (double)(int)src[y * 8 + x] * c_cos[j * 8 + x];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) S[i] += px * c_cos[i * 8 + y];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const double cv = i ? 1.0 : JPEZY_S;
+                const int dct = (int)(S[i] * cu * cv / 4);
+                const int qv = dct / tab->qt[tbl][i * 8 + j];
+                *reinterpret_cast<int16_t*>(stage + blk * STG_BLK + 2 * (int)c_zzinv[i * 8 + j]) = (int16_t)qv;
+            }
+        }
+        if (lane == 0) atomicAdd(p.fallback_count + (qidx & (COUNTER_SHARDS - 1)), (unsigned long long)(4 * BPM * 64));
+        wave_sync();
+    } else {
+        const bool all = FORCE != 0;
+        const unsigned total = all ? (unsigned)(4 * BPM * 64) : nq;
+        if (total) {
+            const int valid_mcus = min(4, p.mcu_cols - quad_x * 4);
+            unsigned done = 0;
+#pragma unroll 1
+            for (unsigned e = 0; e < total; ++e) {
+                const unsigned code = all ? e : reinterpret_cast<const unsigned short*>(queue + 1)[e];
+                const int blk = __builtin_amdgcn_readfirstlane((int)(code >> 6)), nat = __builtin_amdgcn_readfirstlane((int)(code & 63));
+                const int em = blk / BPM, eb = blk - em * BPM;
+                if (em >= valid_mcus) continue;
+                const int ei = nat >> 3, ej = nat & 7;
+                const int comp = eb < 4 ? 0 : eb - 3, tbl = comp ? 1 : 0;
+                // the 8 lanes that hold the block's rows: luma block (by,bx): rows by*8+y, samples ys[8bx..]; chroma:
+                // Cb on even-row lanes, Cr on odd-row lanes, samples cs[]
+                const int by = (eb >> 1) & 1, bx = eb & 1;
+                const int first = comp ? (comp == 2 ? 4 : 0) + em : by * 32 + em;
+                const int stride = comp ? 8 : 4;
+                const bool part = (m == em) && (comp ? ((row & 1) == (comp == 2)) : ((row >> 3) == by));
+                const int yrow = comp ? (row >> 1) : (row & 7);
+                float w[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) w[k] = comp ? cs[k] : (bx ? ys[8 + k] : ys[k]);
+                const int qv = resolve_coef<FORCE>(w, part, yrow, first, stride, ei, ej, tab->qt[tbl][nat], tab->qinv[tbl][nat]);
+                if (lane == 0) *reinterpret_cast<int16_t*>(stage + blk * STG_BLK + 2 * (int)c_zzinv[nat]) = (int16_t)qv;
+                ++done;
+            }
+            if (lane == 0 && done) atomicAdd(p.fallback_count + (qidx & (COUNTER_SHARDS - 1)), (unsigned long long)done);
+            wave_sync();
+        }
+    }
+
+#ifdef JPEZY_TRACE
+    const unsigned long long tr_t2 = __builtin_amdgcn_s_memrealtime();
+#endif
+    // ---- 6. coalesced store of the quad's coefficients ----
+    {
+        const int valid_chunks = min(4, p.mcu_cols - quad_x * 4) * BPM * 8;         // 16-byte chunks
+        int16_t* gbase = p.coeffs + (size_t)frame * p.coeffs_per_frame +
+                         ((size_t)mcu_y * p.mcu_cols + (size_t)quad_x * 4) * (BPM * 64);
+        uint4* g4 = reinterpret_cast<uint4*>(gbase);
+#pragma unroll
+        for (int k = 0; k < BPM * 128 * 4 / 1024; ++k) {
+            const int c = k * 64 + lane;
+            if (c < valid_chunks) {
+                // streamed out, never re-read by this kernel: a non-temporal store leaves less dirty data in the L2s
+                // for the end-of-kernel write-back (measured: 2 us per 4096^2 frame)
+                const uint4 v = *reinterpret_cast<const uint4*>(stage + (c >> 3) * STG_BLK + (c & 7) * 16);
+                typedef unsigned v4u __attribute__((ext_vector_type(4)));
+                __builtin_nontemporal_store(v4u{v.x, v.y, v.z, v.w}, reinterpret_cast<v4u*>(g4 + c));
+            }
+        }
+    }
+#ifdef JPEZY_TRACE
+    if (frame == 0 && qidx < 65536u) {
+#if JPEZY_TRACE > 1
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        const unsigned long long tr_t3 = __builtin_amdgcn_s_memrealtime();
+        const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+        if (lane == 0) {
+            p.trace[qidx * 4 + 0] = tr_t0;
+            p.trace[qidx * 4 + 1] = ((tr_t1 - tr_t0) << 32) | (tr_t2 - tr_t0);
+            p.trace[qidx * 4 + 2] = tr_t3 - tr_t0;
+            p.trace[qidx * 4 + 3] = ((unsigned long long)xcc << 32) | hw;
+        }
+    }
+#endif
+}
+
+
 }  // namespace f32
 
 template <bool GRAY, bool ALIGNED>
@@ -698,6 +1102,32 @@ static void enc_f32_launch2(const EncParams& p, int force, dim3 grid, hipStream_
         hipLaunchKernelGGL((f32::fdct_quant_f32_kernel<GRAY, ALIGNED, 3>), grid, dim3(64 * WPB), 0, s, p);
     else
         hipLaunchKernelGGL((f32::fdct_quant_f32_kernel<GRAY, ALIGNED, 0>), grid, dim3(64 * WPB), 0, s, p);
+}
+
+template <bool GRAY, bool ALIGNED>
+static void enc_mfma_launch2(const EncParams& p, int force, dim3 grid, hipStream_t s)
+{
+    if (force == 1)
+        hipLaunchKernelGGL((f32::fdct_quant_mfma_kernel<GRAY, ALIGNED, 1>), grid, dim3(64 * f32::WPB2), 0, s, p);
+    else if (force == 2)
+        hipLaunchKernelGGL((f32::fdct_quant_mfma_kernel<GRAY, ALIGNED, 2>), grid, dim3(64 * f32::WPB2), 0, s, p);
+    else if (force == 3)
+        hipLaunchKernelGGL((f32::fdct_quant_mfma_kernel<GRAY, ALIGNED, 3>), grid, dim3(64 * f32::WPB2), 0, s, p);
+    else
+        hipLaunchKernelGGL((f32::fdct_quant_mfma_kernel<GRAY, ALIGNED, 0>), grid, dim3(64 * f32::WPB2), 0, s, p);
+}
+
+hipError_t launch_fdct_quant_mfma(const EncParams& p, bool gray, int force, hipStream_t stream)
+{
+    const long quads = (long)p.mcu_rows * p.quads_per_row;
+    if (quads <= 0 || p.n_frames <= 0) return hipSuccess;
+    if (p.n_frames > 65535) return hipErrorInvalidValue;
+    const dim3 grid((unsigned)((quads + f32::WPB2 - 1) / f32::WPB2), (unsigned)p.n_frames);
+    const bool al = (p.W % 16 == 0) && (p.plane_stride % 16 == 0) &&
+                    (((uintptr_t)p.r | (uintptr_t)p.g | (uintptr_t)p.b) % 16 == 0);
+    if (gray) { if (al) enc_mfma_launch2<true, true>(p, force, grid, stream); else enc_mfma_launch2<true, false>(p, force, grid, stream); }
+    else      { if (al) enc_mfma_launch2<false, true>(p, force, grid, stream); else enc_mfma_launch2<false, false>(p, force, grid, stream); }
+    return hipGetLastError();
 }
 
 hipError_t launch_fdct_quant_f32(const EncParams& p, bool gray, int force, hipStream_t stream)

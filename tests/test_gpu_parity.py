@@ -23,10 +23,11 @@ def J():
     return jpezy_amd
 
 
-@pytest.fixture(scope="module", params=[0, 1], ids=["enc-f64", "enc-f32"])
+@pytest.fixture(scope="module", params=[0, 1, 2], ids=["enc-f64", "enc-f32", "enc-mfma"])
 def ctx(J, request):
-    """every test runs with both encode kernel variants (0: FP64 butterflies, 1: FP32 first level + FP64 second
-    level + reference-order third level); the decode kernel is the same in both."""
+    """every test runs with all encode kernel variants (0: FP64 butterflies, 1: FP32 first level + FP64 second
+    level + reference-order third level, 2: variant 1 with the luma transforms on the matrix pipe); the decode kernel is
+    the same in all of them."""
     c = J.Context(0)
     c.set_variant(request.param)
     c.variant = request.param

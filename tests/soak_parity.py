@@ -189,6 +189,8 @@ def main():
         import torch
         import jpezy_amd as J
         ctx = J.Context(0)
+        if os.environ.get("JPEZY_SOAK_VARIANT"):      # encode kernel variant under test (default: the library's default, 1)
+            ctx.set_variant(int(os.environ["JPEZY_SOAK_VARIANT"]))
         dev = torch.device("cuda:0")
         case_no = -1
         while pending:

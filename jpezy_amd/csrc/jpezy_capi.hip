@@ -112,6 +112,7 @@ struct jpezy_ctx {
     // GPU entropy coder (jpezy_entropy.hip): code tables + scratch
     jpezy_dev::entropy::CodeTables* d_codes = nullptr;
     DevBuf e_bits, e_off, e_tmp, e_small, e_U, e_cnt, e_ffoff, e_out, e_coef;
+    DevBuf e_tt, e_fft;            // tile totals (256 blocks / 256 chunks) of the two two-level prefix sums
     DevBuf e_status;               // per-frame error flags of the device-resident entropy path: zero between calls (cleared by their consumer)
     uint8_t* e_pinned = nullptr;   // pinned host staging of the stuffed streams
     size_t e_pinned_cap = 0;
@@ -292,7 +293,7 @@ void jpezy_ctx_destroy(jpezy_ctx* c)
     c->scratch.release();
     if (c->d_codes) (void)hipFree(c->d_codes);
     if (c->e_pinned) (void)hipHostFree(c->e_pinned);
-    for (DevBuf* b : { &c->e_bits, &c->e_off, &c->e_tmp, &c->e_small, &c->e_U, &c->e_cnt, &c->e_ffoff, &c->e_out, &c->e_coef, &c->e_hdr, &c->e_status,
+    for (DevBuf* b : { &c->e_bits, &c->e_off, &c->e_tmp, &c->e_small, &c->e_U, &c->e_cnt, &c->e_ffoff, &c->e_out, &c->e_coef, &c->e_hdr, &c->e_status, &c->e_tt, &c->e_fft,
                        &c->dump_t, &c->h_scan, &c->h_U, &c->h_cnt, &c->h_off, &c->h_state, &c->h_setup, &c->h_small, &c->h_dc }) b->release();
     delete c;
 }
@@ -695,9 +696,12 @@ int entropy_chunk(jpezy_ctx* c, const int16_t* d_coeffs, int W, int H, int gray,
     job.bpm = gray ? 4 : 6;
     job.n_frames = F;
 
-    if (int rc = c->e_bits.reserve(N * sizeof(uint32_t))) return rc;
-    if (int rc = c->e_off.reserve((N + 1) * sizeof(unsigned long long))) return rc;
-    if (int rc = c->e_tmp.reserve(E::scan_tmp_elems(N) * sizeof(unsigned long long))) return rc;
+    const size_t nt = E::tiles256(N);
+    if (int rc = c->e_bits.reserve(N * sizeof(uint32_t))) return rc;                         // tile-local bit offsets
+    if (int rc = c->e_tt.reserve(nt * sizeof(uint32_t))) return rc;                          // tile totals
+    if (int rc = c->e_off.reserve((nt + 1) * sizeof(unsigned long long))) return rc;         // their prefix sums
+    if (int rc = c->e_tmp.reserve(E::scan_tmp_elems(nt) * sizeof(unsigned long long))) return rc;
+    const E::Offsets bitoff{ (const unsigned long long*)c->e_off.p, (const uint32_t*)c->e_bits.p, N };
     // small arrays: [F] status u32 | [F] bit totals | [F] stream bytes | [F] 0xFF totals
     const size_t small_words = (size_t)F * 8;
     if (int rc = c->e_small.reserve(small_words * sizeof(unsigned long long))) return rc;
@@ -708,9 +712,9 @@ int entropy_chunk(jpezy_ctx* c, const int16_t* d_coeffs, int W, int H, int gray,
 
     // 1. code lengths, bit offsets
     HIP_TRY(hipMemsetAsync(d_status, 0, sizeof(unsigned) * F, s));
-    HIP_TRY(E::launch_block_bits(job, (uint32_t*)c->e_bits.p, d_status, s));
-    HIP_TRY(E::launch_scan_u32((const uint32_t*)c->e_bits.p, (unsigned long long*)c->e_off.p, N, (unsigned long long*)c->e_tmp.p, s));
-    HIP_TRY(E::launch_frame_totals((const unsigned long long*)c->e_off.p, nblk, F, d_tot, s));
+    HIP_TRY(E::launch_block_bits(job, (uint32_t*)c->e_bits.p, (uint32_t*)c->e_tt.p, d_status, s));
+    HIP_TRY(E::launch_scan_u32((const uint32_t*)c->e_tt.p, (unsigned long long*)c->e_off.p, nt, (unsigned long long*)c->e_tmp.p, s));
+    HIP_TRY(E::launch_frame_totals(bitoff, nblk, F, d_tot, s));
     std::vector<unsigned long long> tot(F), nbytes(F), fftot(F);
     std::vector<unsigned> status(F);
     HIP_TRY(hipMemcpyAsync(tot.data(), d_tot, sizeof(unsigned long long) * F, hipMemcpyDeviceToHost, s));
@@ -728,16 +732,18 @@ int entropy_chunk(jpezy_ctx* c, const int16_t* d_coeffs, int W, int H, int gray,
     if (int rc = c->e_U.reserve(u_stride * F)) return rc;
     HIP_TRY(hipMemsetAsync(c->e_U.p, 0, u_stride * F, s));
     HIP_TRY(hipMemcpyAsync(d_bytes, nbytes.data(), sizeof(unsigned long long) * F, hipMemcpyHostToDevice, s));
-    HIP_TRY(E::launch_emit(job, (const unsigned long long*)c->e_off.p, (uint32_t*)c->e_U.p, u_stride / 4, s));
+    HIP_TRY(E::launch_emit(job, bitoff, (uint32_t*)c->e_U.p, u_stride / 4, s));
 
     // 3. byte stuffing
-    const size_t nchunks = u_stride / chunk * F;
+    const size_t nchunks = u_stride / chunk * F, nct = E::tiles256(nchunks);
     if (int rc = c->e_cnt.reserve(nchunks * sizeof(uint32_t))) return rc;
-    if (int rc = c->e_ffoff.reserve((nchunks + 1) * sizeof(unsigned long long))) return rc;
-    if (int rc = c->e_tmp.reserve(E::scan_tmp_elems(nchunks > N ? nchunks : N) * sizeof(unsigned long long))) return rc;
-    HIP_TRY(E::launch_ff_count((const uint32_t*)c->e_U.p, u_stride / 4, d_bytes, F, (uint32_t*)c->e_cnt.p, s));
-    HIP_TRY(E::launch_scan_u32((const uint32_t*)c->e_cnt.p, (unsigned long long*)c->e_ffoff.p, nchunks, (unsigned long long*)c->e_tmp.p, s));
-    HIP_TRY(E::launch_frame_totals((const unsigned long long*)c->e_ffoff.p, u_stride / chunk, F, d_fftot, s));
+    if (int rc = c->e_fft.reserve(nct * sizeof(uint32_t))) return rc;
+    if (int rc = c->e_ffoff.reserve((nct + 1) * sizeof(unsigned long long))) return rc;
+    if (int rc = c->e_tmp.reserve(E::scan_tmp_elems(nct > nt ? nct : nt) * sizeof(unsigned long long))) return rc;
+    const E::Offsets ffoff{ (const unsigned long long*)c->e_ffoff.p, (const uint32_t*)c->e_cnt.p, nchunks };
+    HIP_TRY(E::launch_ff_count((const uint32_t*)c->e_U.p, u_stride / 4, d_bytes, F, (uint32_t*)c->e_cnt.p, (uint32_t*)c->e_fft.p, s));
+    HIP_TRY(E::launch_scan_u32((const uint32_t*)c->e_fft.p, (unsigned long long*)c->e_ffoff.p, nct, (unsigned long long*)c->e_tmp.p, s));
+    HIP_TRY(E::launch_frame_totals(ffoff, u_stride / chunk, F, d_fftot, s));
     HIP_TRY(hipMemcpyAsync(fftot.data(), d_fftot, sizeof(unsigned long long) * F, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     unsigned long long max_out = 0;
@@ -745,8 +751,7 @@ int entropy_chunk(jpezy_ctx* c, const int16_t* d_coeffs, int W, int H, int gray,
         if (nbytes[f] + fftot[f] > max_out) max_out = nbytes[f] + fftot[f];
     const size_t o_stride = ((size_t)max_out + 2 + 63) / 64 * 64;
     if (int rc = c->e_out.reserve(o_stride * F)) return rc;
-    HIP_TRY(E::launch_stuff((const uint32_t*)c->e_U.p, u_stride / 4, d_bytes, F, (const unsigned long long*)c->e_ffoff.p,
-                            (uint8_t*)c->e_out.p, o_stride, s));
+    HIP_TRY(E::launch_stuff((const uint32_t*)c->e_U.p, u_stride / 4, d_bytes, F, ffoff, (uint8_t*)c->e_out.p, o_stride, s));
 
     // 4. header + entropy-coded segment + EOI into the caller's buffers.  One device-to-host copy of all streams into a
     //    pinned staging buffer (per-frame copies into pageable memory cost more than the kernels for small frames).
@@ -815,13 +820,18 @@ int jpezy_write_jpeg_gpu_dev(jpezy_ctx* c, const int16_t* d_coeffs, int W, int H
         job.blocks_per_frame = (unsigned)nblk;
         job.bpm = gray ? 4 : 6;
         job.n_frames = F;
+        const size_t nt = E::tiles256(N), nct = E::tiles256(nchunks);
         if (int rc = c->e_bits.reserve(N * sizeof(uint32_t))) return rc;
-        if (int rc = c->e_off.reserve((N + 1) * sizeof(unsigned long long))) return rc;
-        if (int rc = c->e_tmp.reserve(E::scan_tmp_elems(nchunks > N ? nchunks : N) * sizeof(unsigned long long))) return rc;
+        if (int rc = c->e_tt.reserve(nt * sizeof(uint32_t))) return rc;
+        if (int rc = c->e_off.reserve((nt + 1) * sizeof(unsigned long long))) return rc;
+        if (int rc = c->e_tmp.reserve(E::scan_tmp_elems(nct > nt ? nct : nt) * sizeof(unsigned long long))) return rc;
         if (int rc = c->e_small.reserve((size_t)F * 8 * sizeof(unsigned long long))) return rc;
         if (int rc = c->e_U.reserve(u_stride * F)) return rc;
         if (int rc = c->e_cnt.reserve(nchunks * sizeof(uint32_t))) return rc;
-        if (int rc = c->e_ffoff.reserve((nchunks + 1) * sizeof(unsigned long long))) return rc;
+        if (int rc = c->e_fft.reserve(nct * sizeof(uint32_t))) return rc;
+        if (int rc = c->e_ffoff.reserve((nct + 1) * sizeof(unsigned long long))) return rc;
+        const E::Offsets bitoff{ (const unsigned long long*)c->e_off.p, (const uint32_t*)c->e_bits.p, N };
+        const E::Offsets ffoff{ (const unsigned long long*)c->e_ffoff.p, (const uint32_t*)c->e_cnt.p, nchunks };
         if (c->e_status.cap < sizeof(unsigned) * (size_t)F) {      // grown (first call, never inside a capture): zero it once;
             if (int rc = c->e_status.reserve(sizeof(unsigned) * (size_t)F)) return rc;   // from then on plan_header_kernel clears what it reads
             HIP_TRY(hipMemsetAsync(c->e_status.p, 0, c->e_status.cap, s));
@@ -829,17 +839,16 @@ int jpezy_write_jpeg_gpu_dev(jpezy_ctx* c, const int16_t* d_coeffs, int W, int H
         unsigned* d_status = (unsigned*)c->e_status.p;
         unsigned long long* d_bytes = (unsigned long long*)c->e_small.p + F;
         uint8_t* out = d_out + (size_t)f0 * out_stride;
-        HIP_TRY(E::launch_block_bits(job, (uint32_t*)c->e_bits.p, d_status, s));
-        HIP_TRY(E::launch_scan_u32((const uint32_t*)c->e_bits.p, (unsigned long long*)c->e_off.p, N, (unsigned long long*)c->e_tmp.p, s));
+        HIP_TRY(E::launch_block_bits(job, (uint32_t*)c->e_bits.p, (uint32_t*)c->e_tt.p, d_status, s));
+        HIP_TRY(E::launch_scan_u32((const uint32_t*)c->e_tt.p, (unsigned long long*)c->e_off.p, nt, (unsigned long long*)c->e_tmp.p, s));
         // clears what the later kernels touch of the worst-case buffer (not a memset of all of it) and publishes d_bytes
-        HIP_TRY(E::launch_zero_streams((uint32_t*)c->e_U.p, u_stride / 4, (const unsigned long long*)c->e_off.p, nblk, d_bytes, F, s));
-        HIP_TRY(E::launch_emit(job, (const unsigned long long*)c->e_off.p, (uint32_t*)c->e_U.p, u_stride / 4, s));
-        HIP_TRY(E::launch_ff_count((const uint32_t*)c->e_U.p, u_stride / 4, d_bytes, F, (uint32_t*)c->e_cnt.p, s));
-        HIP_TRY(E::launch_scan_u32((const uint32_t*)c->e_cnt.p, (unsigned long long*)c->e_ffoff.p, nchunks, (unsigned long long*)c->e_tmp.p, s));
-        HIP_TRY(E::launch_plan_and_header(d_bytes, (const unsigned long long*)c->e_ffoff.p, u_stride / chunk, d_status, F,
-                                          (const uint8_t*)c->e_hdr.p, hdr_len, out, out_stride, d_sizes + f0, s));
-        HIP_TRY(E::launch_stuff((const uint32_t*)c->e_U.p, u_stride / 4, d_bytes, F, (const unsigned long long*)c->e_ffoff.p, out + hdr_len,
-                                out_stride, s));
+        HIP_TRY(E::launch_zero_streams((uint32_t*)c->e_U.p, u_stride / 4, bitoff, nblk, d_bytes, F, s));
+        HIP_TRY(E::launch_emit(job, bitoff, (uint32_t*)c->e_U.p, u_stride / 4, s));
+        HIP_TRY(E::launch_ff_count((const uint32_t*)c->e_U.p, u_stride / 4, d_bytes, F, (uint32_t*)c->e_cnt.p, (uint32_t*)c->e_fft.p, s));
+        HIP_TRY(E::launch_scan_u32((const uint32_t*)c->e_fft.p, (unsigned long long*)c->e_ffoff.p, nct, (unsigned long long*)c->e_tmp.p, s));
+        HIP_TRY(E::launch_plan_and_header(d_bytes, ffoff, u_stride / chunk, d_status, F, (const uint8_t*)c->e_hdr.p, hdr_len, out, out_stride,
+                                          d_sizes + f0, s));
+        HIP_TRY(E::launch_stuff((const uint32_t*)c->e_U.p, u_stride / 4, d_bytes, F, ffoff, out + hdr_len, out_stride, s));
     }
     return JPEZY_OK;
 }

@@ -38,6 +38,29 @@ __device__ __forceinline__ void load_tables(LdsTables& L, const CodeTables* T)
     __syncthreads();
 }
 
+// exclusive prefix sum of one value per thread over a 256-thread workgroup; *total = the workgroup's sum (all threads)
+__device__ __forceinline__ uint32_t wg256_exclusive_scan(uint32_t v, uint32_t* total)
+{
+    __shared__ uint32_t wsum[4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint32_t inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += o;
+    }
+    if (lane == 63) wsum[wv] = inc;
+    __syncthreads();
+    uint32_t woff = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (k < wv) woff += wsum[k];
+        tot += wsum[k];
+    }
+    *total = tot;
+    return woff + inc - v;
+}
+
 // MSB-first writer into 32-bit big-endian words of a zeroed buffer
 struct BitWriter {
     static constexpr bool writes = true;
@@ -221,7 +244,7 @@ __device__ __forceinline__ BlockRef stage_and_locate(const Job& job, char* tile,
     return r;
 }
 
-__global__ __launch_bounds__(WG) void block_bits_kernel(Job job, uint32_t* bits, unsigned* status)
+__global__ __launch_bounds__(WG) void block_bits_kernel(Job job, uint32_t* loc, uint32_t* tile_total, unsigned* status)
 {
     __shared__ LdsTables L;
     __shared__ __attribute__((aligned(16))) char tile[WG * TILE_PITCH];
@@ -229,15 +252,21 @@ __global__ __launch_bounds__(WG) void block_bits_kernel(Job job, uint32_t* bits,
     const size_t n_total = (size_t)job.blocks_per_frame * job.n_frames;
     const size_t g = (size_t)blockIdx.x * WG + threadIdx.x;
     const BlockRef r = stage_and_locate(job, tile, g, n_total);
-    if (g >= n_total) return;
-    NoWriter w;
-    bool err = false;
-    const unsigned n = code_block(r.z, r.pred, L.dc[r.table], L.ac[r.table], w, err);
-    if (err) atomicOr(status + g / job.blocks_per_frame, 1u);
-    bits[g] = n;
+    unsigned n = 0;
+    if (g < n_total) {
+        NoWriter w;
+        bool err = false;
+        n = code_block(r.z, r.pred, L.dc[r.table], L.ac[r.table], w, err);
+        if (err) atomicOr(status + g / job.blocks_per_frame, 1u);
+    }
+    // the bit offsets inside this workgroup's 256 blocks are formed here; only the 256-block totals go through a scan
+    uint32_t total;
+    const uint32_t off = wg256_exclusive_scan(n, &total);
+    if (g < n_total) loc[g] = off;
+    if (threadIdx.x == 0) tile_total[blockIdx.x] = total;
 }
 
-__global__ __launch_bounds__(WG) void emit_kernel(Job job, const unsigned long long* bitoff, uint32_t* U, size_t u_stride_words)
+__global__ __launch_bounds__(WG) void emit_kernel(Job job, Offsets bitoff, uint32_t* U, size_t u_stride_words)
 {
     __shared__ LdsTables L;
     __shared__ __attribute__((aligned(16))) char tile[WG * TILE_PITCH];
@@ -248,14 +277,14 @@ __global__ __launch_bounds__(WG) void emit_kernel(Job job, const unsigned long l
     if (g >= n_total) return;
     const size_t frame = g / job.blocks_per_frame;
     BitWriter w;
-    w.init(U + frame * u_stride_words, bitoff[g] - bitoff[frame * job.blocks_per_frame]);
+    w.init(U + frame * u_stride_words, bitoff.at(g) - bitoff.at(frame * job.blocks_per_frame));
     bool err = false;
     (void)code_block(r.z, r.pred, L.dc[r.table], L.ac[r.table], w, err);
     w.finish();
 #if JPEZY_PAD_BIT   // alternative frozen choice (include/jpezy_constants.h): one pad bits in the frame's last byte; a
                     // padded 0xFF is then stuffed like any other by the ff_count / stuff kernels
     if (g + 1 == (frame + 1) * job.blocks_per_frame) {
-        const unsigned long long end = bitoff[g + 1] - bitoff[frame * job.blocks_per_frame];
+        const unsigned long long end = bitoff.at(g + 1) - bitoff.at(frame * job.blocks_per_frame);
         const unsigned pad = (unsigned)((8 - (end & 7)) & 7);
         if (pad) {
             const unsigned bit_in_word = (unsigned)(end & 31);            // MSB-first inside a big-endian word
@@ -299,7 +328,10 @@ __global__ __launch_bounds__(SCAN_T) void scan_local_kernel(const TIn* in, unsig
         if (base + k < n) out[base + k] = run;
         run += v[k];
     }
-    if (threadIdx.x == SCAN_T - 1) totals[blockIdx.x] = run;
+    if (threadIdx.x == SCAN_T - 1) {
+        totals[blockIdx.x] = run;
+        if (gridDim.x == 1) out[n] = run;          // a single workgroup: the scan is complete, no second launch
+    }
 }
 
 __global__ __launch_bounds__(SCAN_T) void scan_add_kernel(unsigned long long* out, const unsigned long long* offs, size_t n,
@@ -357,6 +389,7 @@ static hipError_t scan_exclusive(const TIn* in, unsigned long long* out, size_t 
     unsigned long long* raw = tmp;             // [nb] workgroup totals
     unsigned long long* scanned = tmp + nb;    // [nb + 1]
     hipLaunchKernelGGL((scan_local_kernel<TIn>), dim3((unsigned)nb), dim3(SCAN_T), 0, s, in, out, raw, n);
+    if (nb == 1) return hipGetLastError();
     if (nb <= SCAN_FINISH_MAX_WGS) {
         hipLaunchKernelGGL(scan_finish_kernel, dim3((unsigned)nb), dim3(SCAN_T), 0, s, out, raw, n, nb);
         return hipGetLastError();
@@ -368,10 +401,10 @@ static hipError_t scan_exclusive(const TIn* in, unsigned long long* out, size_t 
 }
 
 // frame totals: dst[f] = off[(f+1)*per] - off[f*per]
-__global__ void frame_totals_kernel(const unsigned long long* off, size_t per, int n_frames, unsigned long long* dst)
+__global__ void frame_totals_kernel(Offsets off, size_t per, int n_frames, unsigned long long* dst)
 {
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
-    if (f < n_frames) dst[f] = off[(size_t)(f + 1) * per] - off[(size_t)f * per];
+    if (f < n_frames) dst[f] = off.at((size_t)(f + 1) * per) - off.at((size_t)f * per);
 }
 
 // ---- byte stuffing ----
@@ -386,22 +419,36 @@ __device__ __forceinline__ unsigned count_ff(uint32_t x)
 }
 
 __global__ __launch_bounds__(256) void ff_count_kernel(const uint32_t* U, size_t u_stride_words, const unsigned long long* frame_bytes,
-                                                      int n_frames, uint32_t* counts)
+                                                      int n_frames, uint32_t* loc, uint32_t* tile_total)
 {
     const size_t chunks_per_frame = u_stride_words * 4 / CHUNK;
+    const size_t n_total = chunks_per_frame * n_frames;
     const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= chunks_per_frame * n_frames) return;
-    const size_t frame = g / chunks_per_frame, c = g - frame * chunks_per_frame;
     unsigned n = 0;
-    if ((unsigned long long)c * CHUNK < frame_bytes[frame]) {          // bytes past the end of the stream are zero
-        const uint4* p = reinterpret_cast<const uint4*>(U + frame * u_stride_words) + c * (CHUNK / 16);
+    bool used = false;
+    if (g < n_total) {
+        const size_t frame = g / chunks_per_frame, c = g - frame * chunks_per_frame;
+        // the first chunk of a frame is always "used": its offset is read as the frame's base even when the frame failed
+        used = c == 0 || (unsigned long long)c * CHUNK < frame_bytes[frame];
+        if ((unsigned long long)c * CHUNK < frame_bytes[frame]) {          // bytes past the end of the stream are zero
+            const uint4* p = reinterpret_cast<const uint4*>(U + frame * u_stride_words) + c * (CHUNK / 16);
 #pragma unroll
-        for (int k = 0; k < CHUNK / 16; ++k) {
-            const uint4 v = p[k];
-            n += count_ff(v.x) + count_ff(v.y) + count_ff(v.z) + count_ff(v.w);
+            for (int k = 0; k < CHUNK / 16; ++k) {
+                const uint4 v = p[k];
+                n += count_ff(v.x) + count_ff(v.y) + count_ff(v.z) + count_ff(v.w);
+            }
         }
     }
-    counts[g] = n;
+    // the stream buffer is sized for the worst case: most tiles lie wholly behind the end of their frame's stream; their
+    // chunk offsets are never read, only their (zero) total enters the scan
+    if (!__syncthreads_or(used)) {
+        if (threadIdx.x == 0) tile_total[blockIdx.x] = 0;
+        return;
+    }
+    uint32_t total;
+    const uint32_t off = wg256_exclusive_scan(n, &total);
+    if (g < n_total) loc[g] = off;
+    if (threadIdx.x == 0) tile_total[blockIdx.x] = total;
 }
 
 // Copy U to the output inserting 0x00 after every 0xFF.  A workgroup takes 256 consecutive chunks of one frame: its output
@@ -412,7 +459,7 @@ __global__ __launch_bounds__(256) void ff_count_kernel(const uint32_t* U, size_t
 // instruction -- cost 31 us per 4096x4096 frame.
 constexpr int STUFF_WG = 256;
 __global__ __launch_bounds__(STUFF_WG) void stuff_kernel(const uint32_t* U, size_t u_stride_words, const unsigned long long* frame_bytes,
-                                                        int n_frames, const unsigned long long* ff_before, uint8_t* out, size_t out_stride)
+                                                        int n_frames, Offsets ff_before, uint8_t* out, size_t out_stride)
 {
     __shared__ uint32_t buf[STUFF_WG * CHUNK * 2 / 4 + 4];
     uint8_t* const lb = reinterpret_cast<uint8_t*>(buf);
@@ -421,14 +468,14 @@ __global__ __launch_bounds__(STUFF_WG) void stuff_kernel(const uint32_t* U, size
     const size_t c0 = (size_t)blockIdx.x * STUFF_WG;
     const unsigned long long nbytes = frame_bytes[frame];
     if ((unsigned long long)c0 * CHUNK >= nbytes) return;                       // workgroup-uniform
-    const unsigned long long* ffb = ff_before + frame * chunks_per_frame;        // + c: 0xFF bytes of this and earlier frames before chunk c
-    const unsigned long long ff0 = ffb[c0];
-    uint8_t* const P = out + frame * out_stride + c0 * CHUNK + (ff0 - ffb[0]);   // first output byte of the workgroup
+    const size_t fb = frame * chunks_per_frame;                                   // ff_before.at(fb + c): 0xFF bytes of this and earlier frames before chunk c
+    const unsigned long long ff0 = ff_before.at(fb + c0);
+    uint8_t* const P = out + frame * out_stride + c0 * CHUNK + (ff0 - ff_before.at(fb));   // first output byte of the workgroup
     const unsigned shift = (unsigned)(reinterpret_cast<uintptr_t>(P) & 3u);
     const size_t c = c0 + threadIdx.x;
     if ((unsigned long long)c * CHUNK < nbytes) {
         const int n = (int)((nbytes - (unsigned long long)c * CHUNK) < (unsigned long long)CHUNK ? (nbytes - (unsigned long long)c * CHUNK) : CHUNK);
-        uint8_t* dst = lb + shift + threadIdx.x * CHUNK + (unsigned)(ffb[c] - ff0);
+        uint8_t* dst = lb + shift + threadIdx.x * CHUNK + (unsigned)(ff_before.at(fb + c) - ff0);
         const uint4* src = reinterpret_cast<const uint4*>(reinterpret_cast<const uint8_t*>(U + frame * u_stride_words) + c * CHUNK);
 #pragma unroll 1
         for (int k = 0; k < CHUNK / 16; ++k) {
@@ -449,7 +496,7 @@ __global__ __launch_bounds__(STUFF_WG) void stuff_kernel(const uint32_t* U, size
     const unsigned long long last_chunk = (nbytes + CHUNK - 1) / CHUNK;          // chunks of the frame that hold data
     const size_t ce = c0 + STUFF_WG < last_chunk ? c0 + STUFF_WG : (size_t)last_chunk;
     const unsigned long long src_end = (unsigned long long)ce * CHUNK < nbytes ? (unsigned long long)ce * CHUNK : nbytes;
-    const unsigned total = (unsigned)(src_end - (unsigned long long)c0 * CHUNK) + (unsigned)(ffb[ce] - ff0);
+    const unsigned total = (unsigned)(src_end - (unsigned long long)c0 * CHUNK) + (unsigned)(ff_before.at(fb + ce) - ff0);
     uint32_t* const A = reinterpret_cast<uint32_t*>(P - shift);                  // 4-byte aligned
     const unsigned end = shift + total, nwords = (end + 3) / 4;
     for (unsigned w = threadIdx.x; w < nwords; w += STUFF_WG) {
@@ -464,11 +511,11 @@ __global__ __launch_bounds__(STUFF_WG) void stuff_kernel(const uint32_t* U, size
 }
 
 // ---- host-side driver ----
-hipError_t launch_block_bits(const Job& job, uint32_t* bits, unsigned* status, hipStream_t s)
+hipError_t launch_block_bits(const Job& job, uint32_t* loc, uint32_t* tile_total, unsigned* status, hipStream_t s)
 {
     const size_t n = (size_t)job.blocks_per_frame * job.n_frames;
     if (!n) return hipSuccess;
-    hipLaunchKernelGGL(block_bits_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, job, bits, status);
+    hipLaunchKernelGGL(block_bits_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, job, loc, tile_total, status);
     return hipGetLastError();
 }
 
@@ -484,13 +531,13 @@ hipError_t launch_scan_u64(const unsigned long long* in, unsigned long long* out
     return e != hipSuccess ? e : hipGetLastError();
 }
 
-hipError_t launch_frame_totals(const unsigned long long* off, size_t per, int n_frames, unsigned long long* dst, hipStream_t s)
+hipError_t launch_frame_totals(Offsets off, size_t per, int n_frames, unsigned long long* dst, hipStream_t s)
 {
     hipLaunchKernelGGL(frame_totals_kernel, dim3((unsigned)((n_frames + 63) / 64)), dim3(64), 0, s, off, per, n_frames, dst);
     return hipGetLastError();
 }
 
-hipError_t launch_emit(const Job& job, const unsigned long long* bitoff, uint32_t* U, size_t u_stride_words, hipStream_t s)
+hipError_t launch_emit(const Job& job, Offsets bitoff, uint32_t* U, size_t u_stride_words, hipStream_t s)
 {
     const size_t n = (size_t)job.blocks_per_frame * job.n_frames;
     if (!n) return hipSuccess;
@@ -499,16 +546,17 @@ hipError_t launch_emit(const Job& job, const unsigned long long* bitoff, uint32_
 }
 
 hipError_t launch_ff_count(const uint32_t* U, size_t u_stride_words, const unsigned long long* frame_bytes, int n_frames,
-                           uint32_t* counts, hipStream_t s)
+                           uint32_t* loc, uint32_t* tile_total, hipStream_t s)
 {
     const size_t n = u_stride_words * 4 / CHUNK * n_frames;
     if (!n) return hipSuccess;
-    hipLaunchKernelGGL(ff_count_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, U, u_stride_words, frame_bytes, n_frames, counts);
+    hipLaunchKernelGGL(ff_count_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, U, u_stride_words, frame_bytes, n_frames, loc,
+                       tile_total);
     return hipGetLastError();
 }
 
 hipError_t launch_stuff(const uint32_t* U, size_t u_stride_words, const unsigned long long* frame_bytes, int n_frames,
-                        const unsigned long long* ff_before, uint8_t* out, size_t out_stride, hipStream_t s)
+                        Offsets ff_before, uint8_t* out, size_t out_stride, hipStream_t s)
 {
     const size_t chunks = u_stride_words * 4 / CHUNK;
     if (!chunks || n_frames <= 0) return hipSuccess;
@@ -526,22 +574,24 @@ size_t chunk_bytes() { return CHUNK; }
 // plus one chunk.  4 KB per workgroup; the workgroups past the end leave at once.  The frame's stream length
 // bytes[f] = ceil(bits / 8) is formed here from the scanned offsets (workgroup 0 of the frame publishes it for the kernels
 // that follow) instead of in a launch of its own.
-__global__ __launch_bounds__(256) void zero_streams_kernel(uint32_t* U, size_t u_stride_words, const unsigned long long* off, size_t per,
+__global__ __launch_bounds__(256) void zero_streams_kernel(uint32_t* U, size_t u_stride_words, Offsets off, size_t per,
                                                           unsigned long long* bytes)
 {
     const size_t frame = blockIdx.y;
-    const unsigned long long nb = (off[(frame + 1) * per] - off[frame * per] + 7) / 8;
+    const unsigned long long nb = (off.at((frame + 1) * per) - off.at(frame * per) + 7) / 8;
     if (blockIdx.x == 0 && threadIdx.x == 0) bytes[frame] = nb;
-    const unsigned long long need = (nb + 2 * CHUNK - 1) / CHUNK * CHUNK;
-    const size_t o = ((size_t)blockIdx.x * 256 + threadIdx.x) * 16;
-    if (o >= need || o >= u_stride_words * 4) return;
-    *reinterpret_cast<uint4*>(reinterpret_cast<char*>(U + frame * u_stride_words) + o) = make_uint4(0, 0, 0, 0);
+    unsigned long long need = (nb + 2 * CHUNK - 1) / CHUNK * CHUNK;
+    if (need > u_stride_words * 4) need = u_stride_words * 4;
+    // grid-stride over 4 KB pieces: the grid is sized for a typical stream (ZERO_WGS workgroups = 4 MB per pass), not for the
+    // worst case of 208 bytes per block -- 20,000 workgroups that leave at once cost 8 us per 4096^2 frame
+    for (unsigned long long o = ((unsigned long long)blockIdx.x * 256 + threadIdx.x) * 16; o < need; o += (unsigned long long)gridDim.x * 4096)
+        *reinterpret_cast<uint4*>(reinterpret_cast<char*>(U + frame * u_stride_words) + o) = make_uint4(0, 0, 0, 0);
 }
 
 // One workgroup per frame, after the 0xFF scan: thread 0 decides whether the frame fits, writes its size and its EOI marker
 // and disables the copy kernel for a frame that failed (bytes[f] = 0); then the workgroup copies the header.  The frame's
 // error flag is cleared here -- by its only consumer -- so that no launch is spent on zeroing it before the next call.
-__global__ __launch_bounds__(256) void plan_header_kernel(unsigned long long* bytes, const unsigned long long* ffoff, size_t chunks_per_frame,
+__global__ __launch_bounds__(256) void plan_header_kernel(unsigned long long* bytes, Offsets ffoff, size_t chunks_per_frame,
                                                          unsigned* status, const uint8_t* hdr, size_t hdr_len, uint8_t* out,
                                                          size_t out_stride, long long* sizes)
 {
@@ -549,7 +599,7 @@ __global__ __launch_bounds__(256) void plan_header_kernel(unsigned long long* by
     const size_t f = blockIdx.x;
     uint8_t* dst = out + f * out_stride;
     if (threadIdx.x == 0) {
-        const unsigned long long body = bytes[f] + (ffoff[(f + 1) * chunks_per_frame] - ffoff[f * chunks_per_frame]);
+        const unsigned long long body = bytes[f] + (ffoff.at((f + 1) * chunks_per_frame) - ffoff.at(f * chunks_per_frame));
         const unsigned long long total = hdr_len + body + 2;
         const unsigned st = status[f];
         status[f] = 0;
@@ -568,16 +618,19 @@ __global__ __launch_bounds__(256) void plan_header_kernel(unsigned long long* by
         for (size_t i = threadIdx.x; i < hdr_len; i += 256) dst[i] = hdr[i];
 }
 
-hipError_t launch_zero_streams(uint32_t* U, size_t u_stride_words, const unsigned long long* off, size_t per, unsigned long long* bytes,
+hipError_t launch_zero_streams(uint32_t* U, size_t u_stride_words, Offsets off, size_t per, unsigned long long* bytes,
                                int n_frames, hipStream_t s)
 {
-    const size_t wgs = (u_stride_words * 4 + 4095) / 4096;
+    size_t wgs = (u_stride_words * 4 + 4095) / 4096;
     if (!wgs || n_frames <= 0) return hipSuccess;
+    constexpr size_t ZERO_WGS = 1024;
+    if (wgs > ZERO_WGS) wgs = ZERO_WGS;
+    if (n_frames > 1 && wgs > 64) wgs = 64;           // batches: the frames fill the chip
     hipLaunchKernelGGL(zero_streams_kernel, dim3((unsigned)wgs, (unsigned)n_frames), dim3(256), 0, s, U, u_stride_words, off, per, bytes);
     return hipGetLastError();
 }
 
-hipError_t launch_plan_and_header(unsigned long long* bytes, const unsigned long long* ffoff, size_t chunks_per_frame, unsigned* status,
+hipError_t launch_plan_and_header(unsigned long long* bytes, Offsets ffoff, size_t chunks_per_frame, unsigned* status,
                                   int n_frames, const uint8_t* hdr, size_t hdr_len, uint8_t* out, size_t out_stride, long long* sizes,
                                   hipStream_t s)
 {

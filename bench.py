@@ -400,11 +400,13 @@ def run_rank(args):
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
+        import datetime
+        tmo = datetime.timedelta(seconds=args.dist_timeout)      # a collective that hangs raises instead of stalling the job
         if args.rehearse_on_one_gpu:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=tmo)
             red_dev = torch.device("cpu")
         else:
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, timeout=tmo)
 
     W, H, gray, fps, direction, desc = WORKLOADS[args.workload]
     with_entropy = direction == "encode+entropy"
@@ -588,7 +590,11 @@ def run_rank(args):
         graph = None
         del pr, pg, pb, co
         torch.cuda.empty_cache()
-        batch = run_batch(args, torch, dist, J, ctx, dev, rank, world, world > 1, args.rehearse_on_one_gpu)
+        try:
+            batch = run_batch(args, torch, dist, J, ctx, dev, rank, world, world > 1, args.rehearse_on_one_gpu)
+        except Exception as e:      # the batch object must never cost the job its headline line
+            batch = {"error": f"{type(e).__name__}: {e}"[:400]} if rank == 0 else None
+            print(f"bench.py rank {rank}: batch measurement failed: {e}", file=sys.stderr)
 
     if rank == 0:
         px_per_step = plane * fps
@@ -679,6 +685,7 @@ def parse_args(argv=None):
     ap.add_argument("--batch-frames", type=int, default=None,
                     help=f"frames of the configs[3] batch (default {BATCH_FRAMES}; 16 in --rehearse-on-one-gpu)")
     ap.add_argument("--batch-chunk", type=int, default=64, help="frames per launch / per transfer of the batch pipeline")
+    ap.add_argument("--dist-timeout", type=int, default=300, help="seconds after which a hanging collective raises (N > 1)")
     ap.add_argument("--streams", type=int, default=1,
                     help="frames in flight: step i is launched on stream i %% S (forked from and joined to the timed stream "
                          "inside the captured graph; every step has its own ring buffers).  Default 1: launches back to back")

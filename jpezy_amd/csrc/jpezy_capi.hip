@@ -113,6 +113,7 @@ struct jpezy_ctx {
     jpezy_dev::entropy::CodeTables* d_codes = nullptr;
     DevBuf e_bits, e_off, e_tmp, e_small, e_U, e_cnt, e_ffoff, e_out, e_coef;
     DevBuf e_tt, e_fft;            // tile totals (256 blocks / 256 chunks) of the two two-level prefix sums
+    DevBuf e_S, e_base, e_ft;      // one-pass coder: tile streams, frame-relative tile bit offsets, first tile per 16 KB of output
     DevBuf e_status;               // per-frame error flags of the device-resident entropy path: zero between calls (cleared by their consumer)
     uint8_t* e_pinned = nullptr;   // pinned host staging of the stuffed streams
     size_t e_pinned_cap = 0;
@@ -293,7 +294,7 @@ void jpezy_ctx_destroy(jpezy_ctx* c)
     c->scratch.release();
     if (c->d_codes) (void)hipFree(c->d_codes);
     if (c->e_pinned) (void)hipHostFree(c->e_pinned);
-    for (DevBuf* b : { &c->e_bits, &c->e_off, &c->e_tmp, &c->e_small, &c->e_U, &c->e_cnt, &c->e_ffoff, &c->e_out, &c->e_coef, &c->e_hdr, &c->e_status, &c->e_tt, &c->e_fft,
+    for (DevBuf* b : { &c->e_bits, &c->e_off, &c->e_tmp, &c->e_small, &c->e_U, &c->e_cnt, &c->e_ffoff, &c->e_out, &c->e_coef, &c->e_hdr, &c->e_status, &c->e_tt, &c->e_fft, &c->e_S, &c->e_base, &c->e_ft,
                        &c->dump_t, &c->h_scan, &c->h_U, &c->h_cnt, &c->h_off, &c->h_state, &c->h_setup, &c->h_small, &c->h_dc }) b->release();
     delete c;
 }
@@ -687,7 +688,7 @@ int entropy_chunk(jpezy_ctx* c, const int16_t* d_coeffs, int W, int H, int gray,
     namespace E = jpezy_dev::entropy;
     hipStream_t s = c->stream;
     const size_t nmcu = (size_t)jpezy_mcu_cols(W) * jpezy_mcu_rows(H);
-    const size_t nblk = nmcu * 6, N = nblk * (size_t)F;
+    const size_t nblk = nmcu * 6;
     E::Job job;
     job.coeffs = d_coeffs;
     job.coeffs_per_frame = jpezy_coeff_count(W, H, gray);
@@ -696,52 +697,49 @@ int entropy_chunk(jpezy_ctx* c, const int16_t* d_coeffs, int W, int H, int gray,
     job.bpm = gray ? 4 : 6;
     job.n_frames = F;
 
-    const size_t nt = E::tiles256(N);
-    if (int rc = c->e_bits.reserve(N * sizeof(uint32_t))) return rc;                         // tile-local bit offsets
-    if (int rc = c->e_tt.reserve(nt * sizeof(uint32_t))) return rc;                          // tile totals
-    if (int rc = c->e_off.reserve((nt + 1) * sizeof(unsigned long long))) return rc;         // their prefix sums
-    if (int rc = c->e_tmp.reserve(E::scan_tmp_elems(nt) * sizeof(unsigned long long))) return rc;
-    const E::Offsets bitoff{ (const unsigned long long*)c->e_off.p, (const uint32_t*)c->e_bits.p, N };
+    // every block is coded once, into the stream of its tile (256 coded blocks of a frame); worst case 208 bytes per block
+    const size_t tpf = E::tiles256(nblk), nt = tpf * (size_t)F, piece = E::assemble_piece_bytes();
+    const size_t ft_stride = (nblk * 208 + 8 + piece - 1) / piece;
+    if (int rc = c->e_tt.reserve(nt * sizeof(uint32_t))) return rc;                          // tile totals (bits)
+    if (int rc = c->e_S.reserve(nt * E::tile_stream_bytes())) return rc;                     // tile streams
+    if (int rc = c->e_base.reserve((tpf + 1) * F * sizeof(unsigned long long))) return rc;   // frame-relative tile offsets
+    if (int rc = c->e_ft.reserve(ft_stride * F * sizeof(uint32_t))) return rc;
     // small arrays: [F] status u32 | [F] bit totals | [F] stream bytes | [F] 0xFF totals
     const size_t small_words = (size_t)F * 8;
     if (int rc = c->e_small.reserve(small_words * sizeof(unsigned long long))) return rc;
     unsigned* d_status = (unsigned*)c->e_small.p;
-    unsigned long long* d_tot = (unsigned long long*)c->e_small.p + F;
-    unsigned long long* d_bytes = d_tot + F;
+    unsigned long long* d_bytes = (unsigned long long*)c->e_small.p + 2 * F;
     unsigned long long* d_fftot = d_bytes + F;
 
-    // 1. code lengths, bit offsets
+    // 1. codes, tile offsets, stream lengths
     HIP_TRY(hipMemsetAsync(d_status, 0, sizeof(unsigned) * F, s));
-    HIP_TRY(E::launch_block_bits(job, (uint32_t*)c->e_bits.p, (uint32_t*)c->e_tt.p, d_status, s));
-    HIP_TRY(E::launch_scan_u32((const uint32_t*)c->e_tt.p, (unsigned long long*)c->e_off.p, nt, (unsigned long long*)c->e_tmp.p, s));
-    HIP_TRY(E::launch_frame_totals(bitoff, nblk, F, d_tot, s));
-    std::vector<unsigned long long> tot(F), nbytes(F), fftot(F);
+    HIP_TRY(E::launch_code_tiles(job, (uint32_t*)c->e_S.p, (uint32_t*)c->e_tt.p, d_status, s));
+    HIP_TRY(E::launch_tile_bases((const uint32_t*)c->e_tt.p, (unsigned)tpf, F, (unsigned long long*)c->e_base.p, d_bytes,
+                                 (uint32_t*)c->e_ft.p, (unsigned)ft_stride, s));
+    std::vector<unsigned long long> nbytes(F), fftot(F);
     std::vector<unsigned> status(F);
-    HIP_TRY(hipMemcpyAsync(tot.data(), d_tot, sizeof(unsigned long long) * F, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(nbytes.data(), d_bytes, sizeof(unsigned long long) * F, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(status.data(), d_status, sizeof(unsigned) * F, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
 
-    // 2. unstuffed streams, one per frame, at a common stride
+    // 2. unstuffed streams, one per frame, at a common stride (whole 16 KB pieces), with their 0xFF bytes counted
     unsigned long long max_bytes = 0;
-    for (int f = 0; f < F; ++f) {
-        nbytes[f] = (tot[f] + 7) / 8;                 // the last byte is padded with zero bits (U is zeroed)
+    for (int f = 0; f < F; ++f)
         if (nbytes[f] > max_bytes) max_bytes = nbytes[f];
-    }
     const size_t chunk = E::chunk_bytes();
-    const size_t u_stride = ((size_t)max_bytes + 8 + chunk - 1) / chunk * chunk;
+    const size_t u_stride = ((size_t)max_bytes + 8 + piece - 1) / piece * piece;
     if (int rc = c->e_U.reserve(u_stride * F)) return rc;
-    HIP_TRY(hipMemsetAsync(c->e_U.p, 0, u_stride * F, s));
-    HIP_TRY(hipMemcpyAsync(d_bytes, nbytes.data(), sizeof(unsigned long long) * F, hipMemcpyHostToDevice, s));
-    HIP_TRY(E::launch_emit(job, bitoff, (uint32_t*)c->e_U.p, u_stride / 4, s));
-
-    // 3. byte stuffing
     const size_t nchunks = u_stride / chunk * F, nct = E::tiles256(nchunks);
     if (int rc = c->e_cnt.reserve(nchunks * sizeof(uint32_t))) return rc;
     if (int rc = c->e_fft.reserve(nct * sizeof(uint32_t))) return rc;
     if (int rc = c->e_ffoff.reserve((nct + 1) * sizeof(unsigned long long))) return rc;
-    if (int rc = c->e_tmp.reserve(E::scan_tmp_elems(nct > nt ? nct : nt) * sizeof(unsigned long long))) return rc;
+    if (int rc = c->e_tmp.reserve(E::scan_tmp_elems(nct) * sizeof(unsigned long long))) return rc;
     const E::Offsets ffoff{ (const unsigned long long*)c->e_ffoff.p, (const uint32_t*)c->e_cnt.p, nchunks };
-    HIP_TRY(E::launch_ff_count((const uint32_t*)c->e_U.p, u_stride / 4, d_bytes, F, (uint32_t*)c->e_cnt.p, (uint32_t*)c->e_fft.p, s));
+    HIP_TRY(E::launch_assemble((const uint32_t*)c->e_S.p, (const unsigned long long*)c->e_base.p, d_bytes, (const uint32_t*)c->e_ft.p,
+                               (unsigned)ft_stride, (unsigned)tpf, F, (uint32_t*)c->e_U.p, u_stride / 4, (uint32_t*)c->e_cnt.p,
+                               (uint32_t*)c->e_fft.p, s));
+
+    // 3. byte stuffing
     HIP_TRY(E::launch_scan_u32((const uint32_t*)c->e_fft.p, (unsigned long long*)c->e_ffoff.p, nct, (unsigned long long*)c->e_tmp.p, s));
     HIP_TRY(E::launch_frame_totals(ffoff, u_stride / chunk, F, d_fftot, s));
     HIP_TRY(hipMemcpyAsync(fftot.data(), d_fftot, sizeof(unsigned long long) * F, hipMemcpyDeviceToHost, s));
@@ -805,8 +803,11 @@ int jpezy_write_jpeg_gpu_dev(jpezy_ctx* c, const int16_t* d_coeffs, int W, int H
     const size_t nmcu = (size_t)jpezy_mcu_cols(W) * jpezy_mcu_rows(H);
     const size_t nblk = nmcu * 6;
     const size_t chunk = E::chunk_bytes();
-    // worst case per block: 64 x (16-bit code + 10 value bits) = 208 bytes
-    const size_t u_stride = (nblk * 208 + 8 + chunk - 1) / chunk * chunk;
+    // worst case per block: 64 x (16-bit code + 10 value bits) = 208 bytes; whole 16 KB pieces (one workgroup of the
+    // assembling / stuffing kernels each)
+    const size_t piece = E::assemble_piece_bytes();
+    const size_t u_stride = (nblk * 208 + 8 + piece - 1) / piece * piece;
+    static const bool two_pass = std::getenv("JPEZY_ENTROPY_TWO_PASS") != nullptr;   // development: the round-1 pipeline, for A/B timing
     // frames per pass: worst-case streams below ~1 GiB, and at most 65535 (the frame index is a grid dimension)
     const int per = (int)std::max<size_t>(1, std::min<size_t>(std::min<size_t>((size_t)n_frames, 65535), ((size_t)1 << 30) / u_stride));
     const size_t cpf = jpezy_coeff_count(W, H, gray);
@@ -820,17 +821,15 @@ int jpezy_write_jpeg_gpu_dev(jpezy_ctx* c, const int16_t* d_coeffs, int W, int H
         job.blocks_per_frame = (unsigned)nblk;
         job.bpm = gray ? 4 : 6;
         job.n_frames = F;
-        const size_t nt = E::tiles256(N), nct = E::tiles256(nchunks);
-        if (int rc = c->e_bits.reserve(N * sizeof(uint32_t))) return rc;
+        const size_t tpf = E::tiles256(nblk);                       // tiles of one frame (one-pass coder: tiles never straddle frames)
+        const size_t nt = two_pass ? E::tiles256(N) : tpf * F, nct = E::tiles256(nchunks);
         if (int rc = c->e_tt.reserve(nt * sizeof(uint32_t))) return rc;
-        if (int rc = c->e_off.reserve((nt + 1) * sizeof(unsigned long long))) return rc;
         if (int rc = c->e_tmp.reserve(E::scan_tmp_elems(nct > nt ? nct : nt) * sizeof(unsigned long long))) return rc;
         if (int rc = c->e_small.reserve((size_t)F * 8 * sizeof(unsigned long long))) return rc;
         if (int rc = c->e_U.reserve(u_stride * F)) return rc;
         if (int rc = c->e_cnt.reserve(nchunks * sizeof(uint32_t))) return rc;
         if (int rc = c->e_fft.reserve(nct * sizeof(uint32_t))) return rc;
         if (int rc = c->e_ffoff.reserve((nct + 1) * sizeof(unsigned long long))) return rc;
-        const E::Offsets bitoff{ (const unsigned long long*)c->e_off.p, (const uint32_t*)c->e_bits.p, N };
         const E::Offsets ffoff{ (const unsigned long long*)c->e_ffoff.p, (const uint32_t*)c->e_cnt.p, nchunks };
         if (c->e_status.cap < sizeof(unsigned) * (size_t)F) {      // grown (first call, never inside a capture): zero it once;
             if (int rc = c->e_status.reserve(sizeof(unsigned) * (size_t)F)) return rc;   // from then on plan_header_kernel clears what it reads
@@ -839,12 +838,28 @@ int jpezy_write_jpeg_gpu_dev(jpezy_ctx* c, const int16_t* d_coeffs, int W, int H
         unsigned* d_status = (unsigned*)c->e_status.p;
         unsigned long long* d_bytes = (unsigned long long*)c->e_small.p + F;
         uint8_t* out = d_out + (size_t)f0 * out_stride;
-        HIP_TRY(E::launch_block_bits(job, (uint32_t*)c->e_bits.p, (uint32_t*)c->e_tt.p, d_status, s));
-        HIP_TRY(E::launch_scan_u32((const uint32_t*)c->e_tt.p, (unsigned long long*)c->e_off.p, nt, (unsigned long long*)c->e_tmp.p, s));
-        // clears what the later kernels touch of the worst-case buffer (not a memset of all of it) and publishes d_bytes
-        HIP_TRY(E::launch_zero_streams((uint32_t*)c->e_U.p, u_stride / 4, bitoff, nblk, d_bytes, F, s));
-        HIP_TRY(E::launch_emit(job, bitoff, (uint32_t*)c->e_U.p, u_stride / 4, s));
-        HIP_TRY(E::launch_ff_count((const uint32_t*)c->e_U.p, u_stride / 4, d_bytes, F, (uint32_t*)c->e_cnt.p, (uint32_t*)c->e_fft.p, s));
+        if (!two_pass) {
+            // every block coded once into its tile's stream; tile offsets; streams assembled and their 0xFF bytes counted
+            if (int rc = c->e_S.reserve(tpf * F * E::tile_stream_bytes())) return rc;
+            if (int rc = c->e_base.reserve((tpf + 1) * F * sizeof(unsigned long long))) return rc;
+            if (int rc = c->e_ft.reserve(u_stride / piece * F * sizeof(uint32_t))) return rc;
+            HIP_TRY(E::launch_code_tiles(job, (uint32_t*)c->e_S.p, (uint32_t*)c->e_tt.p, d_status, s));
+            HIP_TRY(E::launch_tile_bases((const uint32_t*)c->e_tt.p, (unsigned)tpf, F, (unsigned long long*)c->e_base.p, d_bytes,
+                                         (uint32_t*)c->e_ft.p, (unsigned)(u_stride / piece), s));
+            HIP_TRY(E::launch_assemble((const uint32_t*)c->e_S.p, (const unsigned long long*)c->e_base.p, d_bytes, (const uint32_t*)c->e_ft.p,
+                                       (unsigned)(u_stride / piece), (unsigned)tpf, F, (uint32_t*)c->e_U.p, u_stride / 4,
+                                       (uint32_t*)c->e_cnt.p, (uint32_t*)c->e_fft.p, s));
+        } else {
+            if (int rc = c->e_bits.reserve(N * sizeof(uint32_t))) return rc;
+            if (int rc = c->e_off.reserve((nt + 1) * sizeof(unsigned long long))) return rc;
+            const E::Offsets bitoff{ (const unsigned long long*)c->e_off.p, (const uint32_t*)c->e_bits.p, N };
+            HIP_TRY(E::launch_block_bits(job, (uint32_t*)c->e_bits.p, (uint32_t*)c->e_tt.p, d_status, s));
+            HIP_TRY(E::launch_scan_u32((const uint32_t*)c->e_tt.p, (unsigned long long*)c->e_off.p, nt, (unsigned long long*)c->e_tmp.p, s));
+            // clears what the later kernels touch of the worst-case buffer (not a memset of all of it) and publishes d_bytes
+            HIP_TRY(E::launch_zero_streams((uint32_t*)c->e_U.p, u_stride / 4, bitoff, nblk, d_bytes, F, s));
+            HIP_TRY(E::launch_emit(job, bitoff, (uint32_t*)c->e_U.p, u_stride / 4, s));
+            HIP_TRY(E::launch_ff_count((const uint32_t*)c->e_U.p, u_stride / 4, d_bytes, F, (uint32_t*)c->e_cnt.p, (uint32_t*)c->e_fft.p, s));
+        }
         HIP_TRY(E::launch_scan_u32((const uint32_t*)c->e_fft.p, (unsigned long long*)c->e_ffoff.p, nct, (unsigned long long*)c->e_tmp.p, s));
         HIP_TRY(E::launch_plan_and_header(d_bytes, ffoff, u_stride / chunk, d_status, F, (const uint8_t*)c->e_hdr.p, hdr_len, out, out_stride,
                                           d_sizes + f0, s));

@@ -65,5 +65,20 @@ hipError_t launch_plan_and_header(unsigned long long* bytes, Offsets ffoff, size
                                   int n_frames, const uint8_t* hdr, size_t hdr_len, uint8_t* out, size_t out_stride, long long* sizes,
                                   hipStream_t s);
 
+// ---- one coding pass (see jpezy_entropy.hip): every block is coded once, workgroup by workgroup ("tile" = 256 coded
+// blocks of one frame), into tile streams S[frame][tile][tile_stream_bytes()]; launch_tile_bases turns the tile totals into
+// frame-relative bit offsets base[frame][tiles + 1], bytes[frame] and the first tile of every assemble_piece_bytes() of
+// output; launch_assemble forms the unstuffed streams U (stride a multiple of assemble_piece_bytes()) and the 0xFF counts
+// per 64-byte chunk in the two-level form launch_stuff / launch_plan_and_header read.
+size_t tile_stream_bytes();
+size_t assemble_piece_bytes();
+hipError_t launch_code_tiles(const Job& job, uint32_t* S, uint32_t* tile_total, unsigned* status, hipStream_t s);
+hipError_t launch_tile_bases(const uint32_t* tile_total, unsigned tiles_per_frame, int n_frames, unsigned long long* base,
+                             unsigned long long* bytes, uint32_t* first_tile, unsigned ft_stride, hipStream_t s);
+// u_stride_words * 4 / assemble_piece_bytes() pieces per frame, at most ft_stride (first_tile's frame stride)
+hipError_t launch_assemble(const uint32_t* S, const unsigned long long* base, const unsigned long long* bytes, const uint32_t* first_tile,
+                           unsigned ft_stride, unsigned tiles_per_frame, int n_frames, uint32_t* U, size_t u_stride_words, uint32_t* loc,
+                           uint32_t* ff_tile_total, hipStream_t s);
+
 }  // namespace entropy
 }  // namespace jpezy_dev

@@ -90,11 +90,13 @@ struct BitWriter {
     {
         if (nacc > 0) atomicOr(wp, __builtin_bswap32((uint32_t)(acc << (32 - nacc))));
     }
+    __device__ __forceinline__ void next_unread(int) {}
 };
 
 struct NoWriter {
     static constexpr bool writes = false;
     __device__ __forceinline__ void put(uint32_t, int) {}
+    __device__ __forceinline__ void next_unread(int) {}
 };
 
 // codes of one block (ref :174-225).  z: 64 zig-zag coefficients in LDS (nullptr: an all-zero block), pred: DC of the
@@ -113,6 +115,9 @@ template <class W>
 __device__ __forceinline__ void code_ac(uint32_t m, int base, const int16_t* z, int& prev, const uint32_t* ac, uint32_t zrl, W& w,
                                         unsigned& len, unsigned& bad)
 {
+#if defined(JPEZY_ENT_ABL) && JPEZY_ENT_ABL == 2
+    m = 0;
+#endif
     int lz = __builtin_clz(m | 1u);
     int vnext = z[base + lz];
 #pragma unroll 1
@@ -121,6 +126,7 @@ __device__ __forceinline__ void code_ac(uint32_t m, int base, const int16_t* z, 
         m &= 0x7FFFFFFFu >> lz;
         lz = __builtin_clz(m | 1u);             // 31 when nothing is left: a harmless in-bounds read
         vnext = z[base + lz];
+        w.next_unread(m ? base + lz + 1 : base + 32);   // everything below has been read (the in-place writer's licence)
         int run = n - prev - 1;
         prev = n;
         const unsigned a = (unsigned)(v < 0 ? -v : v);
@@ -182,12 +188,13 @@ __device__ __forceinline__ unsigned code_block(const int16_t* z, int pred, const
         code_ac(mhi, 0, z, prev, ac, zrl, w, len, bad);
         code_ac(mlo, 32, z, prev, ac, zrl, w, len, bad);
     }
+    w.next_unread(64);
     if (prev != 63) {                    // the block ends in zeros (or has no AC coefficient at all): EOB
         const uint32_t e = ac[0x00];
         w.put(e >> 8, (int)(e & 0xFF));
         len += e & 0xFF;
     }
-    if (bad) { err = true; return 0; }
+    if (bad) err = true;                 // coded as the largest size: lengths and stream stay consistent, the frame is flagged
     return len;
 }
 
@@ -293,6 +300,319 @@ __global__ __launch_bounds__(WG) void emit_kernel(Job job, Offsets bitoff, uint3
         }
     }
 #endif
+}
+
+constexpr int CHUNK = 64;   // bytes of the unstuffed stream U per thread of the 0xFF counting / stuffing kernels
+
+__device__ __forceinline__ unsigned count_ff(uint32_t x)
+{
+    const uint32_t z = ~x;                                             // 0xFF bytes of x are zero bytes of z
+    uint32_t y = (z & 0x7F7F7F7Fu) + 0x7F7F7F7Fu;
+    y = ~(y | z | 0x7F7F7F7Fu);                                         // 0x80 exactly in the zero bytes of z
+    return (unsigned)__builtin_popcount(y);
+}
+
+// ---- one coding pass (round 2): code_tiles -> tile_bases -> assemble ----
+// The two-pass form above codes every block twice (lengths, then bits at the scanned offset).  Here a lane codes its block
+// ONCE, into its own LDS row, in place: the row holds the block's 64 coefficients from byte 16 on, the private stream grows
+// from byte 0, and a word is only written where every coefficient under it has already been read (RowWriter::limit, fed by
+// code_ac's next_unread) -- on ordinary content the codes are far shorter than the coefficients they replace.  A block whose
+// stream would overtake its unread coefficients or exceed 140 bytes is counted only and re-coded afterwards straight from
+// global memory (DirectWriter; high-quality tables on noise).  After the workgroup's scan over the 256 lengths each lane
+// shift-copies its words to the tile's stream in global memory.  No atomics and no zeroed buffer: a word belongs to the lane
+// whose segment contains the word's first bit; complete words are plain stores; the owner of a partial last word pulls
+// the missing bits from the first word of the following lanes' rows (blocks shorter than 32 bits are consumed whole).
+// Tile streams are MSB-first uint32 words, zero padded to a word.  assemble_kernel then forms the frame's unstuffed stream
+// U output-driven (one thread per 64-byte chunk: funnel shifts across tile borders, byte order swapped on the way out) and
+// counts the 0xFF bytes of its chunk while it has them -- what ff_count_kernel did in a launch of its own.
+constexpr int ROW = 144, ROW_DATA = 16, ROW_LAST_WORD = 34;      // private stream: words 0..34; word 35 (bytes 140..143): its length
+constexpr unsigned TILE_STREAM_WORDS = 256 * 208 / 4;            // worst case of 208 bytes per block
+
+struct RowWriter {
+    static constexpr bool writes = true;
+    unsigned long long acc;
+    int nacc, wj, limit, ovf;
+    uint32_t* row;
+    __device__ __forceinline__ void init(uint32_t* r)
+    {
+        row = r; acc = 0; nacc = 0; wj = 0; ovf = 0;
+        limit = 3;                       // bytes 0..15 are free from the start
+    }
+    // positions below `pos` have been read: word j (bytes 4j..4j+3) covers coefficients below 2j - 6
+    __device__ __forceinline__ void next_unread(int pos)
+    {
+        const int l = (pos + 6) >> 1;
+        limit = l > ROW_LAST_WORD ? ROW_LAST_WORD : l;
+    }
+    // one predicated store; everything else is arithmetic (nested branches here cost more than the coding itself)
+    __device__ __forceinline__ void word(uint32_t v, bool due)
+    {
+        if (due && wj <= limit) row[wj] = v;
+        ovf |= (int)(due && wj > limit);
+        wj += (int)due;
+    }
+    __device__ __forceinline__ void put(uint32_t bits, int n)   // n <= 26
+    {
+        acc = (acc << n) | bits;
+        nacc += n;
+        const bool due = nacc >= 32;
+        nacc -= due ? 32 : 0;
+        word((uint32_t)(acc >> nacc), due);
+    }
+    __device__ __forceinline__ void finish()
+    {
+        word((uint32_t)(acc << (32 - nacc)), nacc > 0);          // left aligned, zero padded (nacc < 32)
+    }
+};
+
+// second coding pass of the rare block that did not fit its row: bits straight to the tile stream at their final place
+struct DirectWriter {
+    static constexpr bool writes = true;
+    unsigned long long acc;
+    int nacc;
+    unsigned w;
+    uint32_t* S;
+    bool skip;                           // the first word starts in an earlier lane's segment: not ours to store
+    __device__ __forceinline__ void init(uint32_t* tile_stream, unsigned bitoff)
+    {
+        S = tile_stream; w = bitoff >> 5; nacc = (int)(bitoff & 31u); acc = 0; skip = nacc != 0;
+    }
+    __device__ __forceinline__ void next_unread(int) {}
+    __device__ __forceinline__ void put(uint32_t bits, int n)
+    {
+        acc = (acc << n) | bits;
+        nacc += n;
+        if (nacc >= 32) {
+            nacc -= 32;
+            if (!skip) S[w] = (uint32_t)(acc >> nacc);
+            skip = false;
+            ++w;
+        }
+    }
+};
+
+__global__ __launch_bounds__(WG) void code_tiles_kernel(Job job, uint32_t* S, uint32_t* tile_total, unsigned* status)
+{
+    __shared__ LdsTables L;
+    __shared__ __attribute__((aligned(16))) char tile[WG * ROW];
+    load_tables(L, job.tables);
+    const unsigned tid = threadIdx.x, frame = blockIdx.y;
+    const unsigned nblk = job.blocks_per_frame, g0 = blockIdx.x * (unsigned)WG;
+    const unsigned nb = nblk - g0 < (unsigned)WG ? nblk - g0 : (unsigned)WG;          // coded blocks of this tile
+    const int16_t* fc = job.coeffs + (size_t)frame * job.coeffs_per_frame;
+    // the tile's stored blocks are contiguous in memory; row = the lane that codes the block
+    if (job.bpm == 6) {
+        const uint4* src = reinterpret_cast<const uint4*>(fc + (size_t)g0 * 64);
+        for (unsigned c = tid; c < nb * 8u; c += WG)
+            *reinterpret_cast<uint4*>(tile + (c >> 3) * ROW + ROW_DATA + (c & 7u) * 16u) = src[c];
+    } else {    // gray: 6 coded blocks per MCU, 4 stored ones
+        const unsigned g1 = g0 + nb - 1, m0 = g0 / 6u, i0 = g0 - m0 * 6u, m1 = g1 / 6u, i1 = g1 - m1 * 6u;
+        const unsigned s0 = i0 < 4 ? m0 * 4u + i0 : (m0 + 1) * 4u, s1 = i1 < 4 ? m1 * 4u + i1 : m1 * 4u + 3u;   // s1 + 1 >= s0
+        const unsigned nchunks = (s1 + 1 - s0) * 8u;
+        const uint4* src = reinterpret_cast<const uint4*>(fc + (size_t)s0 * 64);
+        for (unsigned c = tid; c < nchunks; c += WG) {
+            const unsigned sb = s0 + (c >> 3), r = (sb >> 2) * 6u + (sb & 3u) - g0;
+            *reinterpret_cast<uint4*>(tile + r * ROW + ROW_DATA + (c & 7u) * 16u) = src[c];
+        }
+    }
+    __syncthreads();
+
+    const bool valid = tid < nb;
+    uint32_t* const row = reinterpret_cast<uint32_t*>(tile + tid * ROW);
+    unsigned n = 0;
+    bool ovf = false;
+    int pred = 0, table = 0;
+    const int16_t* zg = nullptr;          // the block in global memory; nullptr: a zero chroma block of gray mode
+    if (valid) {
+        const unsigned g = g0 + tid, mcu = g / 6u, i = g - mcu * 6u;
+        table = i < 4 ? 0 : 1;
+        if (!(i >= 4 && job.bpm == 4)) {
+            zg = fc + ((size_t)mcu * job.bpm + i) * 64;
+            // predictor: previous block of the same component in scan order, from global memory (it may be another tile's)
+            if (i >= 1 && i <= 3) pred = zg[-64];
+            else if (mcu != 0) pred = i == 0 ? zg[-(job.bpm - 3) * 64] : zg[-job.bpm * 64];
+        }
+        RowWriter w;
+        w.init(row);
+        bool err = false;
+        n = code_block(zg ? reinterpret_cast<const int16_t*>(tile + tid * ROW + ROW_DATA) : nullptr, pred, L.dc[table], L.ac[table], w, err);
+        w.finish();
+        ovf = w.ovf != 0;
+        if (err) atomicOr(status + frame, 1u);
+    }
+    row[ROW_LAST_WORD + 1] = n;            // where the owner of a partial word finds the length of the lanes after it
+    uint32_t total;
+    const uint32_t o = wg256_exclusive_scan(n, &total);      // (barrier inside: rows and lengths are visible)
+    const size_t t_index = (size_t)frame * gridDim.x + blockIdx.x;
+    if (tid == 0) tile_total[t_index] = total;
+    if (!valid) return;
+#if defined(JPEZY_ENT_ABL) && JPEZY_ENT_ABL == 1
+    return;
+#endif
+
+    uint32_t* const Sg = S + t_index * TILE_STREAM_WORDS;
+    const unsigned sh = o & 31u, w0 = o >> 5, end = o + n;
+    uint32_t tail = 0;
+    unsigned tail_word = 0, tail_fill = 0;                   // tail_fill != 0: this lane owns a partial last word
+    if (!ovf) {
+        const unsigned nwp = (n + 31u) >> 5;
+        unsigned k = sh ? 1u : 0u;
+        uint32_t prev = sh ? row[0] : 0u;
+        for (; ((w0 + k + 1u) << 5) <= end; ++k) {
+            const uint32_t cur = k < nwp ? row[k] : 0u;
+            Sg[w0 + k] = __builtin_amdgcn_alignbit(prev, cur, sh);
+            prev = cur;
+        }
+        if (((w0 + k) << 5) < end) {
+            const uint32_t cur = k < nwp ? row[k] : 0u;
+            tail_word = w0 + k;
+            tail_fill = end - (tail_word << 5);
+            tail = __builtin_amdgcn_alignbit(prev, cur, sh) & ~(0xFFFFFFFFu >> tail_fill);
+        }
+    } else {
+        DirectWriter w;
+        w.init(Sg, o);
+        bool err = false;
+        (void)code_block(zg, pred, L.dc[table], L.ac[table], w, err);
+        if (w.nacc > 0 && !w.skip) {
+            tail_word = w.w;
+            tail_fill = (unsigned)w.nacc;
+            tail = (uint32_t)(w.acc << (32 - w.nacc));
+        }
+    }
+    if (tail_fill) {
+        unsigned fill = tail_fill;
+        for (unsigned j = tid + 1; fill < 32u && j < nb; ++j) {
+            const uint32_t* rj = reinterpret_cast<const uint32_t*>(tile + j * ROW);
+            tail |= rj[0] >> fill;           // a stream shorter than a word is zero padded: nothing but its own bits
+            fill += rj[ROW_LAST_WORD + 1];
+        }
+        Sg[tail_word] = tail;
+    }
+}
+
+// One workgroup per frame: exclusive prefix sums of the frame's tile totals (bits, frame relative, uint64), the frame's
+// stream length in bytes, and for every 16 KB piece of the unstuffed stream the tile its first bit lies in.
+constexpr unsigned ASM_BITS = 256u * (unsigned)CHUNK * 8u;          // bits of U one assemble workgroup writes (131072)
+__global__ __launch_bounds__(256) void tile_bases_kernel(const uint32_t* tile_total, unsigned tpf, unsigned long long* base,
+                                                        unsigned long long* bytes, uint32_t* first_tile, unsigned ft_stride)
+{
+    const unsigned f = blockIdx.x, tid = threadIdx.x;
+    const uint32_t* tt = tile_total + (size_t)f * tpf;
+    unsigned long long* B = base + (size_t)f * (tpf + 1);
+    uint32_t* ft = first_tile + (size_t)f * ft_stride;
+    unsigned long long carry = 0;
+    for (unsigned b0 = 0; b0 < tpf; b0 += 2048u) {
+        uint32_t v[8], s = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const unsigned t = b0 + tid * 8u + k;
+            v[k] = t < tpf ? tt[t] : 0u;
+            s += v[k];
+        }
+        uint32_t total;
+        unsigned long long run = carry + wg256_exclusive_scan(s, &total);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const unsigned t = b0 + tid * 8u + k;
+            if (t < tpf) {
+                B[t] = run;
+                // pieces whose first bit lies in [run, run + v[k])
+                for (unsigned long long w = (run + ASM_BITS - 1) / ASM_BITS; w * ASM_BITS < run + v[k] && w < ft_stride; ++w) ft[w] = t;
+            }
+            run += v[k];
+        }
+        carry += total;
+        __syncthreads();                 // the scan's LDS is reused by the next batch
+    }
+    if (tid == 0) {
+        B[tpf] = carry;
+        bytes[f] = (carry + 7) >> 3;
+    }
+}
+
+constexpr int ASM_WIN = 96;             // tiles a workgroup's 131072 bits can touch: a tile holds at least 256 x 6 bits
+// One thread per 64-byte chunk of U.  A chunk (512 bits) lies in one tile or straddles the border of two (a tile holds at
+// least 1536 bits; only a frame's last tile may be shorter, and nothing follows it): all 17 + 16 source words are requested
+// at once, words past the end of a tile's stream read as zero (the streams are zero padded to a word), and every output
+// word is one funnel shift per tile.  Dependent memory round trips per workgroup: {stream length, first tile} -> window of
+// tile offsets -> stream words.
+__global__ __launch_bounds__(256) void assemble_kernel(const uint32_t* S, const unsigned long long* base, const unsigned long long* bytes,
+                                                      const uint32_t* first_tile, unsigned tpf, unsigned ft_stride, uint32_t* U,
+                                                      size_t u_stride_words, uint32_t* loc, uint32_t* ff_tile_total)
+{
+    __shared__ unsigned long long wb[ASM_WIN + 2];
+    const unsigned frame = blockIdx.y, tid = threadIdx.x;
+    const size_t chunks_per_frame = u_stride_words * 4 / CHUNK;       // a multiple of 256 (launcher)
+    const size_t ff_tile = (size_t)frame * (chunks_per_frame / 256) + blockIdx.x;
+    const unsigned long long nbytes = bytes[frame];
+    const unsigned t0 = first_tile[(size_t)frame * ft_stride + blockIdx.x];   // (garbage past the stream's end: clamped below, unused)
+    const unsigned long long c0 = (unsigned long long)blockIdx.x * 256u, c = c0 + tid;
+    // the first chunk of a frame is always "used": its offset is read as the frame's base
+    if (blockIdx.x != 0 && c0 * CHUNK > nbytes) {     // (== : the one-past-the-end chunk, whose offset stuff_kernel reads)
+        if (tid == 0) ff_tile_total[ff_tile] = 0;
+        return;
+    }
+    const unsigned long long* B = base + (size_t)frame * (tpf + 1);
+    for (unsigned i = tid; i < (unsigned)ASM_WIN + 2u; i += 256u) wb[i] = B[t0 + i < tpf ? t0 + i : tpf];
+    __syncthreads();
+    unsigned n_ff = 0;
+    if (c * CHUNK < nbytes) {
+        const unsigned long long p = c * (CHUNK * 8ull);
+        int lo = 0, hi = ASM_WIN;                                   // wb[lo] <= p; first wb[hi] > p or the window's end
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (wb[mid] <= p) lo = mid; else hi = mid;
+        }
+        const int t = lo;
+        const unsigned long long eA = wb[t + 1];
+        const unsigned tA = t0 + (unsigned)t < tpf ? t0 + (unsigned)t : tpf - 1;
+        const uint32_t* srcA = S + ((size_t)frame * tpf + tA) * TILE_STREAM_WORDS;
+        const unsigned long long qA = p - wb[t];
+        const unsigned LA = (unsigned)(eA - wb[t]), aA = (unsigned)(qA >> 5), sA = (unsigned)(qA & 31u);
+        uint32_t wa[17];
+#pragma unroll
+        for (int k = 0; k < 17; ++k) wa[k] = qA < LA && ((aA + k) << 5) < LA ? srcA[aA + k] : 0u;
+        // the next tile starts inside this chunk, at chunk bit dB = 32 * kb + rb
+        const bool two = p + CHUNK * 8 > eA && tA + 1 < tpf;
+        const unsigned dB = two ? (unsigned)(eA - p) : 0u, kb = dB >> 5, rb = dB & 31u;
+        const unsigned LB = two ? (unsigned)(wb[t + 2] - eA) : 0u;
+        const uint32_t* srcB = S + ((size_t)frame * tpf + (two ? tA + 1 : tA)) * TILE_STREAM_WORDS;
+        uint32_t wn[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) wn[k] = two && (unsigned)k >= kb && (((unsigned)k - kb) << 5) < LB ? srcB[(unsigned)k - kb] : 0u;
+        uint32_t out[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            uint32_t v = sA ? __builtin_amdgcn_alignbit(wa[k], wa[k + 1], 32u - sA) : wa[k];
+            v |= __builtin_amdgcn_alignbit(k > 0 ? wn[k - 1] : 0u, wn[k], rb);
+            out[k] = v;
+        }
+#if JPEZY_PAD_BIT   // alternative frozen choice (include/jpezy_constants.h): one pad bits in the frame's last byte; a padded
+                    // 0xFF is then stuffed like any other
+        {
+            const unsigned long long T = B[tpf];
+            const unsigned pad = (unsigned)((8 - (T & 7)) & 7);
+            if (pad && T > p && T < p + CHUNK * 8) {
+                const unsigned kk = (unsigned)((T - p) >> 5), keep = (unsigned)((T - p) & 31u);
+#pragma unroll
+                for (int k = 0; k < 16; ++k)
+                    if ((unsigned)k == kk) out[k] |= ((1u << pad) - 1u) << (32u - keep - pad);
+            }
+        }
+#endif
+        uint4* dst = reinterpret_cast<uint4*>(U + (size_t)frame * u_stride_words) + c * (CHUNK / 16);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) n_ff += count_ff(out[k]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            dst[k] = make_uint4(__builtin_bswap32(out[4 * k]), __builtin_bswap32(out[4 * k + 1]), __builtin_bswap32(out[4 * k + 2]),
+                                __builtin_bswap32(out[4 * k + 3]));
+    }
+    uint32_t total;
+    const uint32_t off = wg256_exclusive_scan(n_ff, &total);
+    if (c < chunks_per_frame) loc[(size_t)frame * chunks_per_frame + c] = off;
+    if (tid == 0) ff_tile_total[ff_tile] = total;
 }
 
 // ---- exclusive prefix sums: 2048 elements per workgroup, recursive over the workgroup totals ----
@@ -408,15 +728,6 @@ __global__ void frame_totals_kernel(Offsets off, size_t per, int n_frames, unsig
 }
 
 // ---- byte stuffing ----
-constexpr int CHUNK = 64;   // bytes of U per thread
-
-__device__ __forceinline__ unsigned count_ff(uint32_t x)
-{
-    const uint32_t z = ~x;                                             // 0xFF bytes of x are zero bytes of z
-    uint32_t y = (z & 0x7F7F7F7Fu) + 0x7F7F7F7Fu;
-    y = ~(y | z | 0x7F7F7F7Fu);                                         // 0x80 exactly in the zero bytes of z
-    return (unsigned)__builtin_popcount(y);
-}
 
 __global__ __launch_bounds__(256) void ff_count_kernel(const uint32_t* U, size_t u_stride_words, const unsigned long long* frame_bytes,
                                                       int n_frames, uint32_t* loc, uint32_t* tile_total)
@@ -429,7 +740,7 @@ __global__ __launch_bounds__(256) void ff_count_kernel(const uint32_t* U, size_t
     if (g < n_total) {
         const size_t frame = g / chunks_per_frame, c = g - frame * chunks_per_frame;
         // the first chunk of a frame is always "used": its offset is read as the frame's base even when the frame failed
-        used = c == 0 || (unsigned long long)c * CHUNK < frame_bytes[frame];
+        used = c == 0 || (unsigned long long)c * CHUNK <= frame_bytes[frame];   // <=: stuff_kernel reads the offset of the one-past-the-end chunk
         if ((unsigned long long)c * CHUNK < frame_bytes[frame]) {          // bytes past the end of the stream are zero
             const uint4* p = reinterpret_cast<const uint4*>(U + frame * u_stride_words) + c * (CHUNK / 16);
 #pragma unroll
@@ -637,6 +948,39 @@ hipError_t launch_plan_and_header(unsigned long long* bytes, Offsets ffoff, size
     if (n_frames <= 0) return hipSuccess;
     hipLaunchKernelGGL(plan_header_kernel, dim3((unsigned)n_frames), dim3(256), 0, s, bytes, ffoff, chunks_per_frame, status, hdr, hdr_len,
                        out, out_stride, sizes);
+    return hipGetLastError();
+}
+
+size_t tile_stream_bytes() { return (size_t)TILE_STREAM_WORDS * 4; }
+size_t assemble_piece_bytes() { return (size_t)256 * CHUNK; }
+
+hipError_t launch_code_tiles(const Job& job, uint32_t* S, uint32_t* tile_total, unsigned* status, hipStream_t s)
+{
+    if (!job.blocks_per_frame || job.n_frames <= 0) return hipSuccess;
+    if (job.n_frames > 65535) return hipErrorInvalidValue;                       // the frame index is a grid dimension
+    hipLaunchKernelGGL(code_tiles_kernel, dim3((unsigned)tiles256(job.blocks_per_frame), (unsigned)job.n_frames), dim3(WG), 0, s, job, S,
+                       tile_total, status);
+    return hipGetLastError();
+}
+
+hipError_t launch_tile_bases(const uint32_t* tile_total, unsigned tiles_per_frame, int n_frames, unsigned long long* base,
+                             unsigned long long* bytes, uint32_t* first_tile, unsigned ft_stride, hipStream_t s)
+{
+    if (!tiles_per_frame || n_frames <= 0) return hipSuccess;
+    hipLaunchKernelGGL(tile_bases_kernel, dim3((unsigned)n_frames), dim3(256), 0, s, tile_total, tiles_per_frame, base, bytes, first_tile,
+                       ft_stride);
+    return hipGetLastError();
+}
+
+hipError_t launch_assemble(const uint32_t* S, const unsigned long long* base, const unsigned long long* bytes, const uint32_t* first_tile,
+                           unsigned ft_stride, unsigned tiles_per_frame, int n_frames, uint32_t* U, size_t u_stride_words, uint32_t* loc,
+                           uint32_t* ff_tile_total, hipStream_t s)
+{
+    const size_t pieces = u_stride_words * 4 / assemble_piece_bytes();
+    if (!pieces || n_frames <= 0) return hipSuccess;
+    if (u_stride_words * 4 % assemble_piece_bytes() || n_frames > 65535 || pieces > ft_stride) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(assemble_kernel, dim3((unsigned)pieces, (unsigned)n_frames), dim3(256), 0, s, S, base, bytes, first_tile,
+                       tiles_per_frame, ft_stride, U, u_stride_words, loc, ff_tile_total);
     return hipGetLastError();
 }
 

@@ -111,7 +111,7 @@ struct jpezy_ctx {
     DevBuf in[3], out, scratch;    // staging for the host-buffer entry points; scratch: samples of the generic decoder
     // GPU entropy coder (jpezy_entropy.hip): code tables + scratch
     jpezy_dev::entropy::CodeTables* d_codes = nullptr;
-    DevBuf e_bits, e_off, e_tmp, e_small, e_U, e_cnt, e_ffoff, e_out, e_coef;
+    DevBuf e_tmp, e_small, e_U, e_cnt, e_out, e_coef;
     DevBuf e_tt, e_fft;            // tile totals (256 blocks / 256 chunks) of the two two-level prefix sums
     DevBuf e_S, e_base, e_ft;      // one-pass coder: tile streams, frame-relative tile bit offsets, first tile per 16 KB of output
     DevBuf e_status;               // per-frame error flags of the device-resident entropy path: zero between calls (cleared by their consumer)
@@ -294,7 +294,7 @@ void jpezy_ctx_destroy(jpezy_ctx* c)
     c->scratch.release();
     if (c->d_codes) (void)hipFree(c->d_codes);
     if (c->e_pinned) (void)hipHostFree(c->e_pinned);
-    for (DevBuf* b : { &c->e_bits, &c->e_off, &c->e_tmp, &c->e_small, &c->e_U, &c->e_cnt, &c->e_ffoff, &c->e_out, &c->e_coef, &c->e_hdr, &c->e_status, &c->e_tt, &c->e_fft, &c->e_S, &c->e_base, &c->e_ft,
+    for (DevBuf* b : { &c->e_tmp, &c->e_small, &c->e_U, &c->e_cnt, &c->e_out, &c->e_coef, &c->e_hdr, &c->e_status, &c->e_tt, &c->e_fft, &c->e_S, &c->e_base, &c->e_ft,
                        &c->dump_t, &c->h_scan, &c->h_U, &c->h_cnt, &c->h_off, &c->h_state, &c->h_setup, &c->h_small, &c->h_dc }) b->release();
     delete c;
 }
@@ -715,7 +715,7 @@ int entropy_chunk(jpezy_ctx* c, const int16_t* d_coeffs, int W, int H, int gray,
     HIP_TRY(hipMemsetAsync(d_status, 0, sizeof(unsigned) * F, s));
     HIP_TRY(E::launch_code_tiles(job, (uint32_t*)c->e_S.p, (uint32_t*)c->e_tt.p, d_status, s));
     HIP_TRY(E::launch_tile_bases((const uint32_t*)c->e_tt.p, (unsigned)tpf, F, (unsigned long long*)c->e_base.p, d_bytes,
-                                 (uint32_t*)c->e_ft.p, (unsigned)ft_stride, s));
+                                 (uint32_t*)c->e_ft.p, (unsigned)ft_stride, d_status, nullptr, s));
     std::vector<unsigned long long> nbytes(F), fftot(F);
     std::vector<unsigned> status(F);
     HIP_TRY(hipMemcpyAsync(nbytes.data(), d_bytes, sizeof(unsigned long long) * F, hipMemcpyDeviceToHost, s));
@@ -732,16 +732,12 @@ int entropy_chunk(jpezy_ctx* c, const int16_t* d_coeffs, int W, int H, int gray,
     const size_t nchunks = u_stride / chunk * F, nct = E::tiles256(nchunks);
     if (int rc = c->e_cnt.reserve(nchunks * sizeof(uint32_t))) return rc;
     if (int rc = c->e_fft.reserve(nct * sizeof(uint32_t))) return rc;
-    if (int rc = c->e_ffoff.reserve((nct + 1) * sizeof(unsigned long long))) return rc;
-    if (int rc = c->e_tmp.reserve(E::scan_tmp_elems(nct) * sizeof(unsigned long long))) return rc;
-    const E::Offsets ffoff{ (const unsigned long long*)c->e_ffoff.p, (const uint32_t*)c->e_cnt.p, nchunks };
     HIP_TRY(E::launch_assemble((const uint32_t*)c->e_S.p, (const unsigned long long*)c->e_base.p, d_bytes, (const uint32_t*)c->e_ft.p,
                                (unsigned)ft_stride, (unsigned)tpf, F, (uint32_t*)c->e_U.p, u_stride / 4, (uint32_t*)c->e_cnt.p,
                                (uint32_t*)c->e_fft.p, s));
 
     // 3. byte stuffing
-    HIP_TRY(E::launch_scan_u32((const uint32_t*)c->e_fft.p, (unsigned long long*)c->e_ffoff.p, nct, (unsigned long long*)c->e_tmp.p, s));
-    HIP_TRY(E::launch_frame_totals(ffoff, u_stride / chunk, F, d_fftot, s));
+    HIP_TRY(E::launch_ff_frame_totals((const uint32_t*)c->e_fft.p, u_stride / 4, F, d_fftot, s));
     HIP_TRY(hipMemcpyAsync(fftot.data(), d_fftot, sizeof(unsigned long long) * F, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     unsigned long long max_out = 0;
@@ -749,7 +745,8 @@ int entropy_chunk(jpezy_ctx* c, const int16_t* d_coeffs, int W, int H, int gray,
         if (nbytes[f] + fftot[f] > max_out) max_out = nbytes[f] + fftot[f];
     const size_t o_stride = ((size_t)max_out + 2 + 63) / 64 * 64;
     if (int rc = c->e_out.reserve(o_stride * F)) return rc;
-    HIP_TRY(E::launch_stuff((const uint32_t*)c->e_U.p, u_stride / 4, d_bytes, F, ffoff, (uint8_t*)c->e_out.p, o_stride, s));
+    HIP_TRY(E::launch_stuff((const uint32_t*)c->e_U.p, u_stride / 4, d_bytes, F, (const uint32_t*)c->e_cnt.p, (const uint32_t*)c->e_fft.p,
+                            (uint8_t*)c->e_out.p, o_stride, E::FilePlan{}, s));
 
     // 4. header + entropy-coded segment + EOI into the caller's buffers.  One device-to-host copy of all streams into a
     //    pinned staging buffer (per-frame copies into pageable memory cost more than the kernels for small frames).
@@ -807,13 +804,13 @@ int jpezy_write_jpeg_gpu_dev(jpezy_ctx* c, const int16_t* d_coeffs, int W, int H
     // assembling / stuffing kernels each)
     const size_t piece = E::assemble_piece_bytes();
     const size_t u_stride = (nblk * 208 + 8 + piece - 1) / piece * piece;
-    static const bool two_pass = std::getenv("JPEZY_ENTROPY_TWO_PASS") != nullptr;   // development: the round-1 pipeline, for A/B timing
     // frames per pass: worst-case streams below ~1 GiB, and at most 65535 (the frame index is a grid dimension)
     const int per = (int)std::max<size_t>(1, std::min<size_t>(std::min<size_t>((size_t)n_frames, 65535), ((size_t)1 << 30) / u_stride));
     const size_t cpf = jpezy_coeff_count(W, H, gray);
+    const size_t tpf = E::tiles256(nblk);                           // tiles of one frame (a tile never straddles frames)
     for (int f0 = 0; f0 < n_frames; f0 += per) {
         const int F = std::min(per, n_frames - f0);
-        const size_t N = nblk * (size_t)F, nchunks = u_stride / chunk * F;
+        const size_t nchunks = u_stride / chunk * F, nt = tpf * F, nct = E::tiles256(nchunks);
         E::Job job;
         job.coeffs = d_coeffs + (size_t)f0 * cpf;
         job.coeffs_per_frame = cpf;
@@ -821,49 +818,36 @@ int jpezy_write_jpeg_gpu_dev(jpezy_ctx* c, const int16_t* d_coeffs, int W, int H
         job.blocks_per_frame = (unsigned)nblk;
         job.bpm = gray ? 4 : 6;
         job.n_frames = F;
-        const size_t tpf = E::tiles256(nblk);                       // tiles of one frame (one-pass coder: tiles never straddle frames)
-        const size_t nt = two_pass ? E::tiles256(N) : tpf * F, nct = E::tiles256(nchunks);
         if (int rc = c->e_tt.reserve(nt * sizeof(uint32_t))) return rc;
-        if (int rc = c->e_tmp.reserve(E::scan_tmp_elems(nct > nt ? nct : nt) * sizeof(unsigned long long))) return rc;
+        if (int rc = c->e_S.reserve(nt * E::tile_stream_bytes())) return rc;
+        if (int rc = c->e_base.reserve((tpf + 1) * F * sizeof(unsigned long long))) return rc;
+        if (int rc = c->e_ft.reserve(u_stride / piece * F * sizeof(uint32_t))) return rc;
         if (int rc = c->e_small.reserve((size_t)F * 8 * sizeof(unsigned long long))) return rc;
         if (int rc = c->e_U.reserve(u_stride * F)) return rc;
         if (int rc = c->e_cnt.reserve(nchunks * sizeof(uint32_t))) return rc;
         if (int rc = c->e_fft.reserve(nct * sizeof(uint32_t))) return rc;
-        if (int rc = c->e_ffoff.reserve((nct + 1) * sizeof(unsigned long long))) return rc;
-        const E::Offsets ffoff{ (const unsigned long long*)c->e_ffoff.p, (const uint32_t*)c->e_cnt.p, nchunks };
         if (c->e_status.cap < sizeof(unsigned) * (size_t)F) {      // grown (first call, never inside a capture): zero it once;
-            if (int rc = c->e_status.reserve(sizeof(unsigned) * (size_t)F)) return rc;   // from then on plan_header_kernel clears what it reads
+            if (int rc = c->e_status.reserve(sizeof(unsigned) * (size_t)F)) return rc;   // from then on tile_bases_kernel clears what it latches
             HIP_TRY(hipMemsetAsync(c->e_status.p, 0, c->e_status.cap, s));
         }
         unsigned* d_status = (unsigned*)c->e_status.p;
+        unsigned* d_latched = (unsigned*)c->e_small.p;
         unsigned long long* d_bytes = (unsigned long long*)c->e_small.p + F;
-        uint8_t* out = d_out + (size_t)f0 * out_stride;
-        if (!two_pass) {
-            // every block coded once into its tile's stream; tile offsets; streams assembled and their 0xFF bytes counted
-            if (int rc = c->e_S.reserve(tpf * F * E::tile_stream_bytes())) return rc;
-            if (int rc = c->e_base.reserve((tpf + 1) * F * sizeof(unsigned long long))) return rc;
-            if (int rc = c->e_ft.reserve(u_stride / piece * F * sizeof(uint32_t))) return rc;
-            HIP_TRY(E::launch_code_tiles(job, (uint32_t*)c->e_S.p, (uint32_t*)c->e_tt.p, d_status, s));
-            HIP_TRY(E::launch_tile_bases((const uint32_t*)c->e_tt.p, (unsigned)tpf, F, (unsigned long long*)c->e_base.p, d_bytes,
-                                         (uint32_t*)c->e_ft.p, (unsigned)(u_stride / piece), s));
-            HIP_TRY(E::launch_assemble((const uint32_t*)c->e_S.p, (const unsigned long long*)c->e_base.p, d_bytes, (const uint32_t*)c->e_ft.p,
-                                       (unsigned)(u_stride / piece), (unsigned)tpf, F, (uint32_t*)c->e_U.p, u_stride / 4,
-                                       (uint32_t*)c->e_cnt.p, (uint32_t*)c->e_fft.p, s));
-        } else {
-            if (int rc = c->e_bits.reserve(N * sizeof(uint32_t))) return rc;
-            if (int rc = c->e_off.reserve((nt + 1) * sizeof(unsigned long long))) return rc;
-            const E::Offsets bitoff{ (const unsigned long long*)c->e_off.p, (const uint32_t*)c->e_bits.p, N };
-            HIP_TRY(E::launch_block_bits(job, (uint32_t*)c->e_bits.p, (uint32_t*)c->e_tt.p, d_status, s));
-            HIP_TRY(E::launch_scan_u32((const uint32_t*)c->e_tt.p, (unsigned long long*)c->e_off.p, nt, (unsigned long long*)c->e_tmp.p, s));
-            // clears what the later kernels touch of the worst-case buffer (not a memset of all of it) and publishes d_bytes
-            HIP_TRY(E::launch_zero_streams((uint32_t*)c->e_U.p, u_stride / 4, bitoff, nblk, d_bytes, F, s));
-            HIP_TRY(E::launch_emit(job, bitoff, (uint32_t*)c->e_U.p, u_stride / 4, s));
-            HIP_TRY(E::launch_ff_count((const uint32_t*)c->e_U.p, u_stride / 4, d_bytes, F, (uint32_t*)c->e_cnt.p, (uint32_t*)c->e_fft.p, s));
-        }
-        HIP_TRY(E::launch_scan_u32((const uint32_t*)c->e_fft.p, (unsigned long long*)c->e_ffoff.p, nct, (unsigned long long*)c->e_tmp.p, s));
-        HIP_TRY(E::launch_plan_and_header(d_bytes, ffoff, u_stride / chunk, d_status, F, (const uint8_t*)c->e_hdr.p, hdr_len, out, out_stride,
-                                          d_sizes + f0, s));
-        HIP_TRY(E::launch_stuff((const uint32_t*)c->e_U.p, u_stride / 4, d_bytes, F, ffoff, out + hdr_len, out_stride, s));
+        // every block coded once into its tile's stream; tile offsets; streams assembled and their 0xFF bytes counted; the
+        // 0xFF offsets; files written (header, stuffed stream, EOI, size or verdict)
+        HIP_TRY(E::launch_code_tiles(job, (uint32_t*)c->e_S.p, (uint32_t*)c->e_tt.p, d_status, s));
+        HIP_TRY(E::launch_tile_bases((const uint32_t*)c->e_tt.p, (unsigned)tpf, F, (unsigned long long*)c->e_base.p, d_bytes,
+                                     (uint32_t*)c->e_ft.p, (unsigned)(u_stride / piece), d_status, d_latched, s));
+        HIP_TRY(E::launch_assemble((const uint32_t*)c->e_S.p, (const unsigned long long*)c->e_base.p, d_bytes, (const uint32_t*)c->e_ft.p,
+                                   (unsigned)(u_stride / piece), (unsigned)tpf, F, (uint32_t*)c->e_U.p, u_stride / 4,
+                                   (uint32_t*)c->e_cnt.p, (uint32_t*)c->e_fft.p, s));
+        E::FilePlan plan;
+        plan.hdr = (const uint8_t*)c->e_hdr.p;
+        plan.hdr_len = hdr_len;
+        plan.latched = d_latched;
+        plan.sizes = d_sizes + f0;
+        HIP_TRY(E::launch_stuff((const uint32_t*)c->e_U.p, u_stride / 4, d_bytes, F, (const uint32_t*)c->e_cnt.p, (const uint32_t*)c->e_fft.p,
+                                d_out + (size_t)f0 * out_stride, out_stride, plan, s));
     }
     return JPEZY_OK;
 }

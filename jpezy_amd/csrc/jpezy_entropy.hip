@@ -6,15 +6,18 @@
 // What is serial in the reference is the bit cursor and pre_DC[3].  Neither is a true dependency:
 //   * pre_DC of a block is the DC of the previous block of the same component, which is simply read;
 //   * the bit cursor is an exclusive prefix sum of the blocks' code lengths.
-// Pipeline for a chunk of frames (all launches on one stream, two host syncs to learn sizes):
-//   1. block_bits_kernel   one lane per coded block: length in bits of its codes        (reads 3 B/px... of coefficients)
-//   2. scan                exclusive prefix sum over all blocks -> bit offset of every block (uint64)
-//   3. emit_kernel         one lane per block: codes again, written at the block's bit offset into the unstuffed
-//                          stream U (32-bit big-endian words; a block's first and last word are shared with its
-//                          neighbours and merged with atomicOr, U is zeroed first)
-//   4. ff_count_kernel     0xFF bytes per 64-byte chunk of U;  5. scan;  6. stuff_kernel copies U to the output
-//                          inserting 0x00 after every 0xFF.
-// The JFIF header and EOI are written by the host wrapper (jpezy_capi.hip).
+// Pipeline for a chunk of frames (all launches on one stream; "tile" = the 256 coded blocks of one workgroup):
+//   1. code_tiles_kernel   one lane per coded block, every block coded ONCE: private stream in the lane's LDS row, scan of the
+//                          256 lengths, shift-copy into the tile's stream (global scratch S, MSB-first words)
+//   2. tile_bases_kernel   one workgroup per frame: prefix sums of the tile totals (bit offsets), stream length, the first
+//                          tile of every 16 KB of output; latches and clears the frame's error flag
+//   3. assemble_kernel     one thread per 64-byte chunk of the unstuffed stream U: funnel shifts out of one or two tile
+//                          streams, and the chunk's 0xFF count (tile-local offsets + tile totals)
+//   4. scan                of the 0xFF tile totals (one workgroup for a few thousand)
+//   5. stuff_kernel        copies U to the output inserting 0x00 after every 0xFF; in the device-resident form it also
+//                          decides fit / size, writes EOI and copies the JFIF header (workgroup 0 of each frame)
+// (Round 1 and the first half of round 2 coded every block twice -- lengths, scan, then bits at the scanned offset with
+// atomicOr into a zeroed buffer -- in 22, then 9 launches: 174 / 100 us per 4096x4096 frame; see DESIGN.md.)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -60,44 +63,6 @@ __device__ __forceinline__ uint32_t wg256_exclusive_scan(uint32_t v, uint32_t* t
     *total = tot;
     return woff + inc - v;
 }
-
-// MSB-first writer into 32-bit big-endian words of a zeroed buffer
-struct BitWriter {
-    static constexpr bool writes = true;
-    unsigned long long acc;
-    int nacc;
-    uint32_t* wp;
-    bool first;
-    __device__ __forceinline__ void init(uint32_t* base, unsigned long long bitoff)
-    {
-        wp = base + (bitoff >> 5);
-        nacc = (int)(bitoff & 31);
-        acc = 0;
-        first = true;
-    }
-    __device__ __forceinline__ void put(uint32_t bits, int n)   // n <= 26
-    {
-        acc = (acc << n) | bits;
-        nacc += n;
-        if (nacc >= 32) {
-            nacc -= 32;
-            const uint32_t w = __builtin_bswap32((uint32_t)(acc >> nacc));
-            if (first) { atomicOr(wp, w); first = false; } else *wp = w;
-            ++wp;
-        }
-    }
-    __device__ __forceinline__ void finish()
-    {
-        if (nacc > 0) atomicOr(wp, __builtin_bswap32((uint32_t)(acc << (32 - nacc))));
-    }
-    __device__ __forceinline__ void next_unread(int) {}
-};
-
-struct NoWriter {
-    static constexpr bool writes = false;
-    __device__ __forceinline__ void put(uint32_t, int) {}
-    __device__ __forceinline__ void next_unread(int) {}
-};
 
 // codes of one block (ref :174-225).  z: 64 zig-zag coefficients in LDS (nullptr: an all-zero block), pred: DC of the
 // previous block of the component.  Returns the length in bits; err is set for values outside the Annex-K tables (the
@@ -198,110 +163,6 @@ __device__ __forceinline__ unsigned code_block(const int16_t* z, int pred, const
     return len;
 }
 
-// Workgroup tile: the coefficients of the 256 coded blocks of a workgroup are contiguous in memory (also across
-// frames, and in gray mode, where 6 coded blocks per MCU map to 4 stored ones); they are copied to LDS with coalesced
-// 16-byte loads and every lane then walks its own block there (144-byte pitch: conflict-free ds_read_b128).
-constexpr int WG = 256, TILE_PITCH = 144;
-
-struct BlockRef {
-    const int16_t* z;     // in LDS, or nullptr for an all-zero block
-    int pred;             // DC of the previous block of the component (ref :180-181: pre_DC[cs], zero-initialised)
-    int table;            // 0 luma, 1 chroma
-};
-
-// stored-block index (over all frames) of coded block g; -1 for the zero chroma blocks of gray mode
-__device__ __forceinline__ long long stored_index(const Job& job, size_t g, unsigned& mcu, unsigned& i)
-{
-    const size_t frame = g / job.blocks_per_frame;
-    const unsigned b = (unsigned)(g - frame * job.blocks_per_frame);
-    mcu = b / 6u;
-    i = b - mcu * 6u;
-    if (i >= 4 && job.bpm == 4) return -1;
-    return (long long)(frame * (job.coeffs_per_frame / 64) + (size_t)mcu * job.bpm + i);
-}
-
-__device__ __forceinline__ BlockRef stage_and_locate(const Job& job, char* tile, size_t g, size_t n_total)
-{
-    // first / last stored block this workgroup needs
-    const size_t g0 = (size_t)blockIdx.x * WG, g1 = (g0 + WG < n_total ? g0 + WG : n_total) - 1;
-    unsigned m0, i0, m1, i1;
-    long long s0 = stored_index(job, g0, m0, i0), s1 = stored_index(job, g1, m1, i1);
-    if (s0 < 0) s0 = (long long)((g0 / job.blocks_per_frame) * (job.coeffs_per_frame / 64) + (size_t)(m0 + 1) * job.bpm);   // next MCU's Y0
-    if (s1 < 0) s1 = (long long)((g1 / job.blocks_per_frame) * (job.coeffs_per_frame / 64) + (size_t)m1 * job.bpm + 3);     // this MCU's Y3
-    const long long nchunks = (s1 - s0 + 1) * 8;                       // 16-byte chunks
-    const uint4* src = reinterpret_cast<const uint4*>(job.coeffs + (size_t)s0 * 64);
-    for (long long c = threadIdx.x; c < nchunks; c += WG)
-        *reinterpret_cast<uint4*>(tile + (c >> 3) * TILE_PITCH + (c & 7) * 16) = src[c];
-    __syncthreads();
-
-    BlockRef r;
-    r.z = nullptr; r.pred = 0; r.table = 0;
-    if (g >= n_total) return r;
-    unsigned mcu, i;
-    const long long si = stored_index(job, g, mcu, i);
-    r.table = i < 4 ? 0 : 1;
-    if (si < 0) return r;
-    r.z = reinterpret_cast<const int16_t*>(tile + (si - s0) * TILE_PITCH);
-    // predictor: previous block of the same component in the frame's scan order, read from global memory (it may
-    // belong to the previous workgroup)
-    const int16_t* zg = job.coeffs + (size_t)si * 64;
-    if (i >= 1 && i <= 3) r.pred = zg[-64];                                // previous Y block of the same MCU
-    else if (mcu == 0) r.pred = 0;
-    else r.pred = i == 0 ? zg[-(job.bpm - 3) * 64] : zg[-job.bpm * 64];    // Y3 / same chroma block of the previous MCU
-    return r;
-}
-
-__global__ __launch_bounds__(WG) void block_bits_kernel(Job job, uint32_t* loc, uint32_t* tile_total, unsigned* status)
-{
-    __shared__ LdsTables L;
-    __shared__ __attribute__((aligned(16))) char tile[WG * TILE_PITCH];
-    load_tables(L, job.tables);
-    const size_t n_total = (size_t)job.blocks_per_frame * job.n_frames;
-    const size_t g = (size_t)blockIdx.x * WG + threadIdx.x;
-    const BlockRef r = stage_and_locate(job, tile, g, n_total);
-    unsigned n = 0;
-    if (g < n_total) {
-        NoWriter w;
-        bool err = false;
-        n = code_block(r.z, r.pred, L.dc[r.table], L.ac[r.table], w, err);
-        if (err) atomicOr(status + g / job.blocks_per_frame, 1u);
-    }
-    // the bit offsets inside this workgroup's 256 blocks are formed here; only the 256-block totals go through a scan
-    uint32_t total;
-    const uint32_t off = wg256_exclusive_scan(n, &total);
-    if (g < n_total) loc[g] = off;
-    if (threadIdx.x == 0) tile_total[blockIdx.x] = total;
-}
-
-__global__ __launch_bounds__(WG) void emit_kernel(Job job, Offsets bitoff, uint32_t* U, size_t u_stride_words)
-{
-    __shared__ LdsTables L;
-    __shared__ __attribute__((aligned(16))) char tile[WG * TILE_PITCH];
-    load_tables(L, job.tables);
-    const size_t n_total = (size_t)job.blocks_per_frame * job.n_frames;
-    const size_t g = (size_t)blockIdx.x * WG + threadIdx.x;
-    const BlockRef r = stage_and_locate(job, tile, g, n_total);
-    if (g >= n_total) return;
-    const size_t frame = g / job.blocks_per_frame;
-    BitWriter w;
-    w.init(U + frame * u_stride_words, bitoff.at(g) - bitoff.at(frame * job.blocks_per_frame));
-    bool err = false;
-    (void)code_block(r.z, r.pred, L.dc[r.table], L.ac[r.table], w, err);
-    w.finish();
-#if JPEZY_PAD_BIT   // alternative frozen choice (include/jpezy_constants.h): one pad bits in the frame's last byte; a
-                    // padded 0xFF is then stuffed like any other by the ff_count / stuff kernels
-    if (g + 1 == (frame + 1) * job.blocks_per_frame) {
-        const unsigned long long end = bitoff.at(g + 1) - bitoff.at(frame * job.blocks_per_frame);
-        const unsigned pad = (unsigned)((8 - (end & 7)) & 7);
-        if (pad) {
-            const unsigned bit_in_word = (unsigned)(end & 31);            // MSB-first inside a big-endian word
-            const uint32_t mask = ((1u << pad) - 1u) << (32 - bit_in_word - pad);
-            atomicOr(U + frame * u_stride_words + (size_t)(end >> 5), __builtin_bswap32(mask));
-        }
-    }
-#endif
-}
-
 constexpr int CHUNK = 64;   // bytes of the unstuffed stream U per thread of the 0xFF counting / stuffing kernels
 
 __device__ __forceinline__ unsigned count_ff(uint32_t x)
@@ -325,6 +186,7 @@ __device__ __forceinline__ unsigned count_ff(uint32_t x)
 // Tile streams are MSB-first uint32 words, zero padded to a word.  assemble_kernel then forms the frame's unstuffed stream
 // U output-driven (one thread per 64-byte chunk: funnel shifts across tile borders, byte order swapped on the way out) and
 // counts the 0xFF bytes of its chunk while it has them -- what ff_count_kernel did in a launch of its own.
+constexpr int WG = 256;                                          // coded blocks per workgroup ("tile")
 constexpr int ROW = 144, ROW_DATA = 16, ROW_LAST_WORD = 34;      // private stream: words 0..34; word 35 (bytes 140..143): its length
 constexpr unsigned TILE_STREAM_WORDS = 256 * 208 / 4;            // worst case of 208 bytes per block
 
@@ -495,7 +357,8 @@ __global__ __launch_bounds__(WG) void code_tiles_kernel(Job job, uint32_t* S, ui
 // stream length in bytes, and for every 16 KB piece of the unstuffed stream the tile its first bit lies in.
 constexpr unsigned ASM_BITS = 256u * (unsigned)CHUNK * 8u;          // bits of U one assemble workgroup writes (131072)
 __global__ __launch_bounds__(256) void tile_bases_kernel(const uint32_t* tile_total, unsigned tpf, unsigned long long* base,
-                                                        unsigned long long* bytes, uint32_t* first_tile, unsigned ft_stride)
+                                                        unsigned long long* bytes, uint32_t* first_tile, unsigned ft_stride,
+                                                        unsigned* status, unsigned* latched)
 {
     const unsigned f = blockIdx.x, tid = threadIdx.x;
     const uint32_t* tt = tile_total + (size_t)f * tpf;
@@ -528,6 +391,12 @@ __global__ __launch_bounds__(256) void tile_bases_kernel(const uint32_t* tile_to
     if (tid == 0) {
         B[tpf] = carry;
         bytes[f] = (carry + 7) >> 3;
+        // device-resident form: the frame's error flag (set by code_tiles_kernel) is consumed here -- after every writer, before
+        // every reader -- and left clear for the next call: no launch is spent on zeroing it
+        if (latched) {
+            latched[f] = status[f];
+            status[f] = 0;
+        }
     }
 }
 
@@ -699,12 +568,59 @@ __global__ __launch_bounds__(SCAN_T) void scan_finish_kernel(unsigned long long*
     if (blockIdx.x == nb - 1 && threadIdx.x == 0) out[n] = o + totals[nb - 1];
 }
 
+// a few thousand elements: one workgroup walks them in batches of 2048 with a running carry -- one launch instead of two
+// (a dependent launch costs ~4.7 us on this chip, a batch well under one)
+constexpr size_t SCAN_ONE_WG_MAX = 16 * SCAN_N;
+template <typename TIn>
+__global__ __launch_bounds__(SCAN_T) void scan_one_wg_kernel(const TIn* in, unsigned long long* out, size_t n)
+{
+    __shared__ unsigned long long wsum[SCAN_T / 64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    unsigned long long carry = 0;
+    for (size_t b0 = 0; b0 < n; b0 += SCAN_N) {
+        const size_t base = b0 + (size_t)threadIdx.x * SCAN_E;
+        unsigned long long v[SCAN_E], s = 0;
+#pragma unroll
+        for (int k = 0; k < SCAN_E; ++k) {
+            v[k] = base + k < n ? (unsigned long long)in[base + k] : 0ull;
+            s += v[k];
+        }
+        unsigned long long inc = s;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned long long o = __shfl_up(inc, d, 64);
+            if (lane >= d) inc += o;
+        }
+        if (lane == 63) wsum[wv] = inc;
+        __syncthreads();
+        unsigned long long woff = 0, tot = 0;
+#pragma unroll
+        for (int k = 0; k < SCAN_T / 64; ++k) {
+            if (k < wv) woff += wsum[k];
+            tot += wsum[k];
+        }
+        unsigned long long run = carry + woff + inc - s;
+#pragma unroll
+        for (int k = 0; k < SCAN_E; ++k) {
+            if (base + k < n) out[base + k] = run;
+            run += v[k];
+        }
+        carry += tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[n] = carry;
+}
+
 constexpr size_t SCAN_FINISH_MAX_WGS = 4096;   // beyond it (n > 8.4 M) the totals are scanned recursively as before
 
 template <typename TIn>
 static hipError_t scan_exclusive(const TIn* in, unsigned long long* out, size_t n, unsigned long long* tmp, hipStream_t s)
 {
     if (n == 0) return hipMemsetAsync(out, 0, sizeof(unsigned long long), s);
+    if (n <= SCAN_ONE_WG_MAX) {
+        hipLaunchKernelGGL((scan_one_wg_kernel<TIn>), dim3(1), dim3(SCAN_T), 0, s, in, out, n);
+        return hipGetLastError();
+    }
     const size_t nb = (n + SCAN_N - 1) / SCAN_N;
     unsigned long long* raw = tmp;             // [nb] workgroup totals
     unsigned long long* scanned = tmp + nb;    // [nb + 1]
@@ -720,47 +636,7 @@ static hipError_t scan_exclusive(const TIn* in, unsigned long long* out, size_t 
     return hipMemcpyAsync(out + n, scanned + nb, sizeof(unsigned long long), hipMemcpyDeviceToDevice, s);
 }
 
-// frame totals: dst[f] = off[(f+1)*per] - off[f*per]
-__global__ void frame_totals_kernel(Offsets off, size_t per, int n_frames, unsigned long long* dst)
-{
-    const int f = blockIdx.x * blockDim.x + threadIdx.x;
-    if (f < n_frames) dst[f] = off.at((size_t)(f + 1) * per) - off.at((size_t)f * per);
-}
-
 // ---- byte stuffing ----
-
-__global__ __launch_bounds__(256) void ff_count_kernel(const uint32_t* U, size_t u_stride_words, const unsigned long long* frame_bytes,
-                                                      int n_frames, uint32_t* loc, uint32_t* tile_total)
-{
-    const size_t chunks_per_frame = u_stride_words * 4 / CHUNK;
-    const size_t n_total = chunks_per_frame * n_frames;
-    const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    unsigned n = 0;
-    bool used = false;
-    if (g < n_total) {
-        const size_t frame = g / chunks_per_frame, c = g - frame * chunks_per_frame;
-        // the first chunk of a frame is always "used": its offset is read as the frame's base even when the frame failed
-        used = c == 0 || (unsigned long long)c * CHUNK <= frame_bytes[frame];   // <=: stuff_kernel reads the offset of the one-past-the-end chunk
-        if ((unsigned long long)c * CHUNK < frame_bytes[frame]) {          // bytes past the end of the stream are zero
-            const uint4* p = reinterpret_cast<const uint4*>(U + frame * u_stride_words) + c * (CHUNK / 16);
-#pragma unroll
-            for (int k = 0; k < CHUNK / 16; ++k) {
-                const uint4 v = p[k];
-                n += count_ff(v.x) + count_ff(v.y) + count_ff(v.z) + count_ff(v.w);
-            }
-        }
-    }
-    // the stream buffer is sized for the worst case: most tiles lie wholly behind the end of their frame's stream; their
-    // chunk offsets are never read, only their (zero) total enters the scan
-    if (!__syncthreads_or(used)) {
-        if (threadIdx.x == 0) tile_total[blockIdx.x] = 0;
-        return;
-    }
-    uint32_t total;
-    const uint32_t off = wg256_exclusive_scan(n, &total);
-    if (g < n_total) loc[g] = off;
-    if (threadIdx.x == 0) tile_total[blockIdx.x] = total;
-}
 
 // Copy U to the output inserting 0x00 after every 0xFF.  A workgroup takes 256 consecutive chunks of one frame: its output
 // is one contiguous byte range (start = chunk offset + 0xFF bytes before it).  Every thread expands its 64 bytes into LDS
@@ -769,24 +645,68 @@ __global__ __launch_bounds__(256) void ff_count_kernel(const uint32_t* U, size_t
 // neighbouring workgroups complete).  Byte stores straight to global memory -- 64 lanes, 64 different cache lines per
 // instruction -- cost 31 us per 4096x4096 frame.
 constexpr int STUFF_WG = 256;
+// plan.hdr != nullptr (device-resident form): the frame's file is header + stuffed stream + EOI at out + frame * out_stride;
+// every workgroup works out whether the frame failed (a coefficient outside the tables: JPEZY_E_FORMAT = -5) or does not fit
+// (JPEZY_E_NOSPACE = -6) and leaves at once if so; workgroup 0 of the frame reports the size, writes EOI and copies the header.
 __global__ __launch_bounds__(STUFF_WG) void stuff_kernel(const uint32_t* U, size_t u_stride_words, const unsigned long long* frame_bytes,
-                                                        int n_frames, Offsets ff_before, uint8_t* out, size_t out_stride)
+                                                        const uint32_t* ff_loc, const uint32_t* ff_tile_total, uint8_t* out, size_t out_stride,
+                                                        FilePlan plan)
 {
     __shared__ uint32_t buf[STUFF_WG * CHUNK * 2 / 4 + 4];
+    __shared__ unsigned long long red[2][STUFF_WG / 64];
     uint8_t* const lb = reinterpret_cast<uint8_t*>(buf);
-    const size_t chunks_per_frame = u_stride_words * 4 / CHUNK;
+    const size_t chunks_per_frame = u_stride_words * 4 / CHUNK, pieces = chunks_per_frame / STUFF_WG;
     const size_t frame = blockIdx.y;
     const size_t c0 = (size_t)blockIdx.x * STUFF_WG;
     const unsigned long long nbytes = frame_bytes[frame];
     if ((unsigned long long)c0 * CHUNK >= nbytes) return;                       // workgroup-uniform
-    const size_t fb = frame * chunks_per_frame;                                   // ff_before.at(fb + c): 0xFF bytes of this and earlier frames before chunk c
-    const unsigned long long ff0 = ff_before.at(fb + c0);
-    uint8_t* const P = out + frame * out_stride + c0 * CHUNK + (ff0 - ff_before.at(fb));   // first output byte of the workgroup
+    // 0xFF bytes of the frame before this workgroup's chunks, and in the whole frame: the workgroup adds up the tile totals
+    // itself (a few hundred 4-byte values out of the L2) -- a scan launched in between costs more than all of these sums
+    const uint32_t* ft = ff_tile_total + frame * pieces;
+    const size_t used = (size_t)(nbytes / ((unsigned long long)STUFF_WG * CHUNK)) + 1 < pieces ? (size_t)(nbytes / ((unsigned long long)STUFF_WG * CHUNK)) + 1 : pieces;
+    unsigned long long pre = 0, all = 0;
+    for (size_t x = threadIdx.x; x < used; x += STUFF_WG) {
+        const uint32_t v = ft[x];
+        all += v;
+        pre += x < blockIdx.x ? v : 0u;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        pre += __shfl_xor(pre, d, 64);
+        all += __shfl_xor(all, d, 64);
+    }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = pre; red[1][threadIdx.x >> 6] = all; }
+    __syncthreads();
+    pre = all = 0;
+#pragma unroll
+    for (int k = 0; k < STUFF_WG / 64; ++k) { pre += red[0][k]; all += red[1][k]; }
+    if (plan.hdr) {
+        const unsigned long long body = nbytes + all;
+        const unsigned long long total = plan.hdr_len + body + 2;
+        const unsigned st = plan.latched[frame];
+        const bool failed = st != 0 || total > out_stride;
+        if (blockIdx.x == 0) {
+            uint8_t* file = out + frame * out_stride;
+            if (threadIdx.x == 0) {
+                plan.sizes[frame] = st ? -5 : failed ? -6 : (long long)total;
+                if (!failed) {
+                    file[plan.hdr_len + body] = 0xFF;
+                    file[plan.hdr_len + body + 1] = 0xD9;
+                }
+            }
+            if (!failed)
+                for (size_t i = threadIdx.x; i < plan.hdr_len; i += STUFF_WG) file[i] = plan.hdr[i];
+        }
+        if (failed) return;                                                      // workgroup-uniform
+        out += plan.hdr_len;
+    }
+    const uint32_t* loc = ff_loc + frame * chunks_per_frame;                      // 0xFF bytes before a chunk inside its 256-chunk tile
+    uint8_t* const P = out + frame * out_stride + c0 * CHUNK + pre;              // first output byte of the workgroup
     const unsigned shift = (unsigned)(reinterpret_cast<uintptr_t>(P) & 3u);
     const size_t c = c0 + threadIdx.x;
     if ((unsigned long long)c * CHUNK < nbytes) {
         const int n = (int)((nbytes - (unsigned long long)c * CHUNK) < (unsigned long long)CHUNK ? (nbytes - (unsigned long long)c * CHUNK) : CHUNK);
-        uint8_t* dst = lb + shift + threadIdx.x * CHUNK + (unsigned)(ff_before.at(fb + c) - ff0);
+        uint8_t* dst = lb + shift + threadIdx.x * CHUNK + loc[c];
         const uint4* src = reinterpret_cast<const uint4*>(reinterpret_cast<const uint8_t*>(U + frame * u_stride_words) + c * CHUNK);
 #pragma unroll 1
         for (int k = 0; k < CHUNK / 16; ++k) {
@@ -807,7 +727,7 @@ __global__ __launch_bounds__(STUFF_WG) void stuff_kernel(const uint32_t* U, size
     const unsigned long long last_chunk = (nbytes + CHUNK - 1) / CHUNK;          // chunks of the frame that hold data
     const size_t ce = c0 + STUFF_WG < last_chunk ? c0 + STUFF_WG : (size_t)last_chunk;
     const unsigned long long src_end = (unsigned long long)ce * CHUNK < nbytes ? (unsigned long long)ce * CHUNK : nbytes;
-    const unsigned total = (unsigned)(src_end - (unsigned long long)c0 * CHUNK) + (unsigned)(ff_before.at(fb + ce) - ff0);
+    const unsigned total = (unsigned)(src_end - (unsigned long long)c0 * CHUNK) + (ce < c0 + STUFF_WG ? loc[ce] : ft[blockIdx.x]);
     uint32_t* const A = reinterpret_cast<uint32_t*>(P - shift);                  // 4-byte aligned
     const unsigned end = shift + total, nwords = (end + 3) / 4;
     for (unsigned w = threadIdx.x; w < nwords; w += STUFF_WG) {
@@ -818,18 +738,9 @@ __global__ __launch_bounds__(STUFF_WG) void stuff_kernel(const uint32_t* U, size
             for (unsigned k = lo < shift ? shift : lo; k < (hi < end ? hi : end); ++k) reinterpret_cast<uint8_t*>(A)[k] = lb[k];
         }
     }
-    (void)n_frames;
 }
 
 // ---- host-side driver ----
-hipError_t launch_block_bits(const Job& job, uint32_t* loc, uint32_t* tile_total, unsigned* status, hipStream_t s)
-{
-    const size_t n = (size_t)job.blocks_per_frame * job.n_frames;
-    if (!n) return hipSuccess;
-    hipLaunchKernelGGL(block_bits_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, job, loc, tile_total, status);
-    return hipGetLastError();
-}
-
 hipError_t launch_scan_u32(const uint32_t* in, unsigned long long* out, size_t n, unsigned long long* tmp, hipStream_t s)
 {
     hipError_t e = scan_exclusive<uint32_t>(in, out, n, tmp, s);
@@ -842,114 +753,38 @@ hipError_t launch_scan_u64(const unsigned long long* in, unsigned long long* out
     return e != hipSuccess ? e : hipGetLastError();
 }
 
-hipError_t launch_frame_totals(Offsets off, size_t per, int n_frames, unsigned long long* dst, hipStream_t s)
-{
-    hipLaunchKernelGGL(frame_totals_kernel, dim3((unsigned)((n_frames + 63) / 64)), dim3(64), 0, s, off, per, n_frames, dst);
-    return hipGetLastError();
-}
-
-hipError_t launch_emit(const Job& job, Offsets bitoff, uint32_t* U, size_t u_stride_words, hipStream_t s)
-{
-    const size_t n = (size_t)job.blocks_per_frame * job.n_frames;
-    if (!n) return hipSuccess;
-    hipLaunchKernelGGL(emit_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, job, bitoff, U, u_stride_words);
-    return hipGetLastError();
-}
-
-hipError_t launch_ff_count(const uint32_t* U, size_t u_stride_words, const unsigned long long* frame_bytes, int n_frames,
-                           uint32_t* loc, uint32_t* tile_total, hipStream_t s)
-{
-    const size_t n = u_stride_words * 4 / CHUNK * n_frames;
-    if (!n) return hipSuccess;
-    hipLaunchKernelGGL(ff_count_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, U, u_stride_words, frame_bytes, n_frames, loc,
-                       tile_total);
-    return hipGetLastError();
-}
-
 hipError_t launch_stuff(const uint32_t* U, size_t u_stride_words, const unsigned long long* frame_bytes, int n_frames,
-                        Offsets ff_before, uint8_t* out, size_t out_stride, hipStream_t s)
+                        const uint32_t* ff_loc, const uint32_t* ff_tile_total, uint8_t* out, size_t out_stride, FilePlan plan, hipStream_t s)
 {
     const size_t chunks = u_stride_words * 4 / CHUNK;
     if (!chunks || n_frames <= 0) return hipSuccess;
-    if (n_frames > 65535) return hipErrorInvalidValue;                           // the frame index is a grid dimension
-    hipLaunchKernelGGL(stuff_kernel, dim3((unsigned)((chunks + STUFF_WG - 1) / STUFF_WG), (unsigned)n_frames), dim3(STUFF_WG), 0, s, U,
-                       u_stride_words, frame_bytes, n_frames, ff_before, out, out_stride);
+    if (n_frames > 65535 || chunks % STUFF_WG) return hipErrorInvalidValue;      // the frame index is a grid dimension
+    hipLaunchKernelGGL(stuff_kernel, dim3((unsigned)(chunks / STUFF_WG), (unsigned)n_frames), dim3(STUFF_WG), 0, s, U, u_stride_words,
+                       frame_bytes, ff_loc, ff_tile_total, out, out_stride, plan);
+    return hipGetLastError();
+}
+
+// dst[f] = 0xFF bytes of frame f's unstuffed stream (the host-delivered form sizes its output from it)
+__global__ __launch_bounds__(256) void ff_frame_totals_kernel(const uint32_t* ff_tile_total, size_t pieces, unsigned long long* dst)
+{
+    __shared__ unsigned long long red[4];
+    unsigned long long sum = 0;
+    for (size_t x = threadIdx.x; x < pieces; x += 256) sum += ff_tile_total[blockIdx.x * pieces + x];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) dst[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+hipError_t launch_ff_frame_totals(const uint32_t* ff_tile_total, size_t u_stride_words, int n_frames, unsigned long long* dst, hipStream_t s)
+{
+    if (n_frames <= 0) return hipSuccess;
+    hipLaunchKernelGGL(ff_frame_totals_kernel, dim3((unsigned)n_frames), dim3(256), 0, s, ff_tile_total, u_stride_words * 4 / assemble_piece_bytes(), dst);
     return hipGetLastError();
 }
 
 size_t chunk_bytes() { return CHUNK; }
-
-// ---- fully device-side variant: sizes stay on the device, no host sync ----
-// U is sized for the worst case (208 bytes per block: 82 MB for a 4096x4096 frame, 5 MB of it used on noise, far less on
-// pictures); only what emit_kernel and the byte-stuffing kernels touch is cleared: the stream rounded up to a whole chunk,
-// plus one chunk.  4 KB per workgroup; the workgroups past the end leave at once.  The frame's stream length
-// bytes[f] = ceil(bits / 8) is formed here from the scanned offsets (workgroup 0 of the frame publishes it for the kernels
-// that follow) instead of in a launch of its own.
-__global__ __launch_bounds__(256) void zero_streams_kernel(uint32_t* U, size_t u_stride_words, Offsets off, size_t per,
-                                                          unsigned long long* bytes)
-{
-    const size_t frame = blockIdx.y;
-    const unsigned long long nb = (off.at((frame + 1) * per) - off.at(frame * per) + 7) / 8;
-    if (blockIdx.x == 0 && threadIdx.x == 0) bytes[frame] = nb;
-    unsigned long long need = (nb + 2 * CHUNK - 1) / CHUNK * CHUNK;
-    if (need > u_stride_words * 4) need = u_stride_words * 4;
-    // grid-stride over 4 KB pieces: the grid is sized for a typical stream (ZERO_WGS workgroups = 4 MB per pass), not for the
-    // worst case of 208 bytes per block -- 20,000 workgroups that leave at once cost 8 us per 4096^2 frame
-    for (unsigned long long o = ((unsigned long long)blockIdx.x * 256 + threadIdx.x) * 16; o < need; o += (unsigned long long)gridDim.x * 4096)
-        *reinterpret_cast<uint4*>(reinterpret_cast<char*>(U + frame * u_stride_words) + o) = make_uint4(0, 0, 0, 0);
-}
-
-// One workgroup per frame, after the 0xFF scan: thread 0 decides whether the frame fits, writes its size and its EOI marker
-// and disables the copy kernel for a frame that failed (bytes[f] = 0); then the workgroup copies the header.  The frame's
-// error flag is cleared here -- by its only consumer -- so that no launch is spent on zeroing it before the next call.
-__global__ __launch_bounds__(256) void plan_header_kernel(unsigned long long* bytes, Offsets ffoff, size_t chunks_per_frame,
-                                                         unsigned* status, const uint8_t* hdr, size_t hdr_len, uint8_t* out,
-                                                         size_t out_stride, long long* sizes)
-{
-    __shared__ int ok;
-    const size_t f = blockIdx.x;
-    uint8_t* dst = out + f * out_stride;
-    if (threadIdx.x == 0) {
-        const unsigned long long body = bytes[f] + (ffoff.at((f + 1) * chunks_per_frame) - ffoff.at(f * chunks_per_frame));
-        const unsigned long long total = hdr_len + body + 2;
-        const unsigned st = status[f];
-        status[f] = 0;
-        ok = 0;
-        if (st) { sizes[f] = -5; bytes[f] = 0; }                              // JPEZY_E_FORMAT
-        else if (total > out_stride) { sizes[f] = -6; bytes[f] = 0; }         // JPEZY_E_NOSPACE
-        else {
-            dst[hdr_len + body] = 0xFF;
-            dst[hdr_len + body + 1] = 0xD9;
-            sizes[f] = (long long)total;
-            ok = 1;
-        }
-    }
-    __syncthreads();
-    if (ok)
-        for (size_t i = threadIdx.x; i < hdr_len; i += 256) dst[i] = hdr[i];
-}
-
-hipError_t launch_zero_streams(uint32_t* U, size_t u_stride_words, Offsets off, size_t per, unsigned long long* bytes,
-                               int n_frames, hipStream_t s)
-{
-    size_t wgs = (u_stride_words * 4 + 4095) / 4096;
-    if (!wgs || n_frames <= 0) return hipSuccess;
-    constexpr size_t ZERO_WGS = 1024;
-    if (wgs > ZERO_WGS) wgs = ZERO_WGS;
-    if (n_frames > 1 && wgs > 64) wgs = 64;           // batches: the frames fill the chip
-    hipLaunchKernelGGL(zero_streams_kernel, dim3((unsigned)wgs, (unsigned)n_frames), dim3(256), 0, s, U, u_stride_words, off, per, bytes);
-    return hipGetLastError();
-}
-
-hipError_t launch_plan_and_header(unsigned long long* bytes, Offsets ffoff, size_t chunks_per_frame, unsigned* status,
-                                  int n_frames, const uint8_t* hdr, size_t hdr_len, uint8_t* out, size_t out_stride, long long* sizes,
-                                  hipStream_t s)
-{
-    if (n_frames <= 0) return hipSuccess;
-    hipLaunchKernelGGL(plan_header_kernel, dim3((unsigned)n_frames), dim3(256), 0, s, bytes, ffoff, chunks_per_frame, status, hdr, hdr_len,
-                       out, out_stride, sizes);
-    return hipGetLastError();
-}
 
 size_t tile_stream_bytes() { return (size_t)TILE_STREAM_WORDS * 4; }
 size_t assemble_piece_bytes() { return (size_t)256 * CHUNK; }
@@ -964,11 +799,12 @@ hipError_t launch_code_tiles(const Job& job, uint32_t* S, uint32_t* tile_total, 
 }
 
 hipError_t launch_tile_bases(const uint32_t* tile_total, unsigned tiles_per_frame, int n_frames, unsigned long long* base,
-                             unsigned long long* bytes, uint32_t* first_tile, unsigned ft_stride, hipStream_t s)
+                             unsigned long long* bytes, uint32_t* first_tile, unsigned ft_stride, unsigned* status, unsigned* latched,
+                             hipStream_t s)
 {
     if (!tiles_per_frame || n_frames <= 0) return hipSuccess;
     hipLaunchKernelGGL(tile_bases_kernel, dim3((unsigned)n_frames), dim3(256), 0, s, tile_total, tiles_per_frame, base, bytes, first_tile,
-                       ft_stride);
+                       ft_stride, status, latched);
     return hipGetLastError();
 }
 

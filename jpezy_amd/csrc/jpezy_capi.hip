@@ -698,48 +698,44 @@ int entropy_chunk(jpezy_ctx* c, const int16_t* d_coeffs, int W, int H, int gray,
     job.n_frames = F;
 
     // every block is coded once, into the stream of its tile (256 coded blocks of a frame); worst case 208 bytes per block
-    const size_t tpf = E::tiles256(nblk), nt = tpf * (size_t)F, piece = E::assemble_piece_bytes();
-    const size_t ft_stride = (nblk * 208 + 8 + piece - 1) / piece;
+    const size_t tpf = E::tiles256(nblk), nt = tpf * (size_t)F, piece = E::assemble_piece_bytes(), chunk = E::chunk_bytes();
+    const size_t u_stride = (nblk * 208 + 8 + piece - 1) / piece * piece, ft_stride = u_stride / piece;
+    const size_t nchunks = u_stride / chunk * F;
+    const bool self = E::assemble_scans_tiles_itself(tpf);
     if (int rc = c->e_tt.reserve(nt * sizeof(uint32_t))) return rc;                          // tile totals (bits)
     if (int rc = c->e_S.reserve(nt * E::tile_stream_bytes())) return rc;                     // tile streams
-    if (int rc = c->e_base.reserve((tpf + 1) * F * sizeof(unsigned long long))) return rc;   // frame-relative tile offsets
-    if (int rc = c->e_ft.reserve(ft_stride * F * sizeof(uint32_t))) return rc;
-    // small arrays: [F] status u32 | [F] bit totals | [F] stream bytes | [F] 0xFF totals
+    if (int rc = c->e_U.reserve(u_stride * F)) return rc;                                    // unstuffed streams
+    if (int rc = c->e_cnt.reserve(nchunks * sizeof(uint32_t))) return rc;                    // 0xFF bytes: per chunk inside its piece,
+    if (int rc = c->e_fft.reserve(ft_stride * F * sizeof(uint32_t))) return rc;              //             per piece
+    if (!self) {
+        if (int rc = c->e_base.reserve((tpf + 1) * F * sizeof(unsigned long long))) return rc;   // frame-relative tile offsets
+        if (int rc = c->e_ft.reserve(ft_stride * F * sizeof(uint32_t))) return rc;
+    }
+    // small arrays: [F] status u32 | [F] (unused) | [F] stream bytes | [F] 0xFF totals
     const size_t small_words = (size_t)F * 8;
     if (int rc = c->e_small.reserve(small_words * sizeof(unsigned long long))) return rc;
     unsigned* d_status = (unsigned*)c->e_small.p;
     unsigned long long* d_bytes = (unsigned long long*)c->e_small.p + 2 * F;
     unsigned long long* d_fftot = d_bytes + F;
 
-    // 1. codes, tile offsets, stream lengths
+    // 1. codes; 2. unstuffed streams, one per frame, with their 0xFF bytes counted; stream lengths
     HIP_TRY(hipMemsetAsync(d_status, 0, sizeof(unsigned) * F, s));
     HIP_TRY(E::launch_code_tiles(job, (uint32_t*)c->e_S.p, (uint32_t*)c->e_tt.p, d_status, s));
-    HIP_TRY(E::launch_tile_bases((const uint32_t*)c->e_tt.p, (unsigned)tpf, F, (unsigned long long*)c->e_base.p, d_bytes,
-                                 (uint32_t*)c->e_ft.p, (unsigned)ft_stride, d_status, nullptr, s));
+    if (!self)
+        HIP_TRY(E::launch_tile_bases((const uint32_t*)c->e_tt.p, (unsigned)tpf, F, (unsigned long long*)c->e_base.p, d_bytes,
+                                     (uint32_t*)c->e_ft.p, (unsigned)ft_stride, d_status, nullptr, s));
+    HIP_TRY(E::launch_assemble((const uint32_t*)c->e_S.p, (const uint32_t*)c->e_tt.p, (const unsigned long long*)c->e_base.p, d_bytes,
+                               (const uint32_t*)c->e_ft.p, (unsigned)ft_stride, (unsigned)tpf, F, (uint32_t*)c->e_U.p, u_stride / 4,
+                               (uint32_t*)c->e_cnt.p, (uint32_t*)c->e_fft.p, d_status, nullptr, s));
+    HIP_TRY(E::launch_ff_frame_totals((const uint32_t*)c->e_fft.p, d_bytes, u_stride / 4, F, d_fftot, s));
     std::vector<unsigned long long> nbytes(F), fftot(F);
     std::vector<unsigned> status(F);
     HIP_TRY(hipMemcpyAsync(nbytes.data(), d_bytes, sizeof(unsigned long long) * F, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(status.data(), d_status, sizeof(unsigned) * F, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-
-    // 2. unstuffed streams, one per frame, at a common stride (whole 16 KB pieces), with their 0xFF bytes counted
-    unsigned long long max_bytes = 0;
-    for (int f = 0; f < F; ++f)
-        if (nbytes[f] > max_bytes) max_bytes = nbytes[f];
-    const size_t chunk = E::chunk_bytes();
-    const size_t u_stride = ((size_t)max_bytes + 8 + piece - 1) / piece * piece;
-    if (int rc = c->e_U.reserve(u_stride * F)) return rc;
-    const size_t nchunks = u_stride / chunk * F, nct = E::tiles256(nchunks);
-    if (int rc = c->e_cnt.reserve(nchunks * sizeof(uint32_t))) return rc;
-    if (int rc = c->e_fft.reserve(nct * sizeof(uint32_t))) return rc;
-    HIP_TRY(E::launch_assemble((const uint32_t*)c->e_S.p, (const unsigned long long*)c->e_base.p, d_bytes, (const uint32_t*)c->e_ft.p,
-                               (unsigned)ft_stride, (unsigned)tpf, F, (uint32_t*)c->e_U.p, u_stride / 4, (uint32_t*)c->e_cnt.p,
-                               (uint32_t*)c->e_fft.p, s));
-
-    // 3. byte stuffing
-    HIP_TRY(E::launch_ff_frame_totals((const uint32_t*)c->e_fft.p, u_stride / 4, F, d_fftot, s));
     HIP_TRY(hipMemcpyAsync(fftot.data(), d_fftot, sizeof(unsigned long long) * F, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
+
+    // 3. byte stuffing into a buffer sized from the actual lengths
     unsigned long long max_out = 0;
     for (int f = 0; f < F; ++f)
         if (nbytes[f] + fftot[f] > max_out) max_out = nbytes[f] + fftot[f];
@@ -808,6 +804,7 @@ int jpezy_write_jpeg_gpu_dev(jpezy_ctx* c, const int16_t* d_coeffs, int W, int H
     const int per = (int)std::max<size_t>(1, std::min<size_t>(std::min<size_t>((size_t)n_frames, 65535), ((size_t)1 << 30) / u_stride));
     const size_t cpf = jpezy_coeff_count(W, H, gray);
     const size_t tpf = E::tiles256(nblk);                           // tiles of one frame (a tile never straddles frames)
+    const bool self = E::assemble_scans_tiles_itself(tpf);
     for (int f0 = 0; f0 < n_frames; f0 += per) {
         const int F = std::min(per, n_frames - f0);
         const size_t nchunks = u_stride / chunk * F, nt = tpf * F, nct = E::tiles256(nchunks);
@@ -820,8 +817,10 @@ int jpezy_write_jpeg_gpu_dev(jpezy_ctx* c, const int16_t* d_coeffs, int W, int H
         job.n_frames = F;
         if (int rc = c->e_tt.reserve(nt * sizeof(uint32_t))) return rc;
         if (int rc = c->e_S.reserve(nt * E::tile_stream_bytes())) return rc;
-        if (int rc = c->e_base.reserve((tpf + 1) * F * sizeof(unsigned long long))) return rc;
-        if (int rc = c->e_ft.reserve(u_stride / piece * F * sizeof(uint32_t))) return rc;
+        if (!self) {
+            if (int rc = c->e_base.reserve((tpf + 1) * F * sizeof(unsigned long long))) return rc;
+            if (int rc = c->e_ft.reserve(u_stride / piece * F * sizeof(uint32_t))) return rc;
+        }
         if (int rc = c->e_small.reserve((size_t)F * 8 * sizeof(unsigned long long))) return rc;
         if (int rc = c->e_U.reserve(u_stride * F)) return rc;
         if (int rc = c->e_cnt.reserve(nchunks * sizeof(uint32_t))) return rc;
@@ -836,11 +835,12 @@ int jpezy_write_jpeg_gpu_dev(jpezy_ctx* c, const int16_t* d_coeffs, int W, int H
         // every block coded once into its tile's stream; tile offsets; streams assembled and their 0xFF bytes counted; the
         // 0xFF offsets; files written (header, stuffed stream, EOI, size or verdict)
         HIP_TRY(E::launch_code_tiles(job, (uint32_t*)c->e_S.p, (uint32_t*)c->e_tt.p, d_status, s));
-        HIP_TRY(E::launch_tile_bases((const uint32_t*)c->e_tt.p, (unsigned)tpf, F, (unsigned long long*)c->e_base.p, d_bytes,
-                                     (uint32_t*)c->e_ft.p, (unsigned)(u_stride / piece), d_status, d_latched, s));
-        HIP_TRY(E::launch_assemble((const uint32_t*)c->e_S.p, (const unsigned long long*)c->e_base.p, d_bytes, (const uint32_t*)c->e_ft.p,
-                                   (unsigned)(u_stride / piece), (unsigned)tpf, F, (uint32_t*)c->e_U.p, u_stride / 4,
-                                   (uint32_t*)c->e_cnt.p, (uint32_t*)c->e_fft.p, s));
+        if (!self)
+            HIP_TRY(E::launch_tile_bases((const uint32_t*)c->e_tt.p, (unsigned)tpf, F, (unsigned long long*)c->e_base.p, d_bytes,
+                                         (uint32_t*)c->e_ft.p, (unsigned)(u_stride / piece), d_status, d_latched, s));
+        HIP_TRY(E::launch_assemble((const uint32_t*)c->e_S.p, (const uint32_t*)c->e_tt.p, (const unsigned long long*)c->e_base.p, d_bytes,
+                                   (const uint32_t*)c->e_ft.p, (unsigned)(u_stride / piece), (unsigned)tpf, F, (uint32_t*)c->e_U.p,
+                                   u_stride / 4, (uint32_t*)c->e_cnt.p, (uint32_t*)c->e_fft.p, d_status, d_latched, s));
         E::FilePlan plan;
         plan.hdr = (const uint8_t*)c->e_hdr.p;
         plan.hdr_len = hdr_len;

@@ -50,16 +50,20 @@ hipError_t launch_code_tiles(const Job& job, uint32_t* S, uint32_t* tile_total, 
 hipError_t launch_tile_bases(const uint32_t* tile_total, unsigned tiles_per_frame, int n_frames, unsigned long long* base,
                              unsigned long long* bytes, uint32_t* first_tile, unsigned ft_stride, unsigned* status, unsigned* latched,
                              hipStream_t s);
-// unstuffed streams U (stride a multiple of assemble_piece_bytes(), at most ft_stride pieces) and the 0xFF bytes in front of
-// every 64-byte chunk inside its piece (ff_loc[frame][chunk]) + per piece (ff_tile_total[frame][piece]): a prefix sum in two
-// levels whose upper level every stuffing workgroup adds up for itself
-hipError_t launch_assemble(const uint32_t* S, const unsigned long long* base, const unsigned long long* bytes, const uint32_t* first_tile,
-                           unsigned ft_stride, unsigned tiles_per_frame, int n_frames, uint32_t* U, size_t u_stride_words, uint32_t* loc,
-                           uint32_t* ff_tile_total, hipStream_t s);
+// unstuffed streams U (stride a multiple of assemble_piece_bytes()) and the 0xFF bytes in front of every 64-byte chunk inside
+// its piece (ff_loc[frame][chunk]) + per piece (ff_tile_total[frame][piece]): a prefix sum in two levels whose upper level
+// every stuffing workgroup adds up for itself.  Frames with assemble_scans_tiles_itself(tiles): launch_tile_bases is NOT
+// needed -- the kernel scans tile_total itself, publishes bytes[frame] and (latched != nullptr) latches + clears status;
+// base / first_tile are then unused.  Larger frames: launch_tile_bases first (at most ft_stride pieces).
+bool assemble_scans_tiles_itself(size_t tiles_per_frame);
+hipError_t launch_assemble(const uint32_t* S, const uint32_t* tile_total, const unsigned long long* base, unsigned long long* bytes,
+                           const uint32_t* first_tile, unsigned ft_stride, unsigned tiles_per_frame, int n_frames, uint32_t* U,
+                           size_t u_stride_words, uint32_t* loc, uint32_t* ff_tile_total, unsigned* status, unsigned* latched, hipStream_t s);
 hipError_t launch_stuff(const uint32_t* U, size_t u_stride_words, const unsigned long long* frame_bytes, int n_frames,
                         const uint32_t* ff_loc, const uint32_t* ff_tile_total, uint8_t* out, size_t out_stride, FilePlan plan, hipStream_t s);
 // dst[f] = 0xFF bytes of frame f (the host-delivered form sizes its output buffer from it)
-hipError_t launch_ff_frame_totals(const uint32_t* ff_tile_total, size_t u_stride_words, int n_frames, unsigned long long* dst, hipStream_t s);
+hipError_t launch_ff_frame_totals(const uint32_t* ff_tile_total, const unsigned long long* bytes, size_t u_stride_words, int n_frames,
+                                  unsigned long long* dst, hipStream_t s);
 
 }  // namespace entropy
 }  // namespace jpezy_dev

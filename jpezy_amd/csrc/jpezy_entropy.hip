@@ -401,87 +401,154 @@ __global__ __launch_bounds__(256) void tile_bases_kernel(const uint32_t* tile_to
 }
 
 constexpr int ASM_WIN = 96;             // tiles a workgroup's 131072 bits can touch: a tile holds at least 256 x 6 bits
-// One thread per 64-byte chunk of U.  A chunk (512 bits) lies in one tile or straddles the border of two (a tile holds at
-// least 1536 bits; only a frame's last tile may be shorter, and nothing follows it): all 17 + 16 source words are requested
-// at once, words past the end of a tile's stream read as zero (the streams are zero padded to a word), and every output
-// word is one funnel shift per tile.  Dependent memory round trips per workgroup: {stream length, first tile} -> window of
-// tile offsets -> stream words.
-__global__ __launch_bounds__(256) void assemble_kernel(const uint32_t* S, const unsigned long long* base, const unsigned long long* bytes,
-                                                      const uint32_t* first_tile, unsigned tpf, unsigned ft_stride, uint32_t* U,
-                                                      size_t u_stride_words, uint32_t* loc, uint32_t* ff_tile_total)
+constexpr unsigned ASM_SELF_TILES = 2048;   // frames of up to this many tiles: every assembling workgroup scans the totals itself
+
+// the 64 bytes of U that start at frame bit p: tile A (bits [bA, eA) of the frame, stream srcA) holds p; tile B (LB bits,
+// stream srcB; LB = 0: there is none) follows it.  All 17 + 16 source words are requested at once, words past the end of a
+// tile's stream read as zero (the streams are zero padded to a word), every output word is one funnel shift per tile.
+__device__ __forceinline__ unsigned assemble_chunk(unsigned long long p, unsigned long long bA, unsigned long long eA, const uint32_t* srcA,
+                                                   unsigned LB, const uint32_t* srcB, unsigned long long T, uint4* dst)
 {
-    __shared__ unsigned long long wb[ASM_WIN + 2];
-    const unsigned frame = blockIdx.y, tid = threadIdx.x;
-    const size_t chunks_per_frame = u_stride_words * 4 / CHUNK;       // a multiple of 256 (launcher)
-    const size_t ff_tile = (size_t)frame * (chunks_per_frame / 256) + blockIdx.x;
-    const unsigned long long nbytes = bytes[frame];
-    const unsigned t0 = first_tile[(size_t)frame * ft_stride + blockIdx.x];   // (garbage past the stream's end: clamped below, unused)
-    const unsigned long long c0 = (unsigned long long)blockIdx.x * 256u, c = c0 + tid;
-    // the first chunk of a frame is always "used": its offset is read as the frame's base
-    if (blockIdx.x != 0 && c0 * CHUNK > nbytes) {     // (== : the one-past-the-end chunk, whose offset stuff_kernel reads)
-        if (tid == 0) ff_tile_total[ff_tile] = 0;
-        return;
+    const unsigned long long qA = p - bA;
+    const unsigned LA = (unsigned)(eA - bA), aA = (unsigned)(qA >> 5), sA = (unsigned)(qA & 31u);
+    uint32_t wa[17];
+#pragma unroll
+    for (int k = 0; k < 17; ++k) wa[k] = qA < LA && ((aA + k) << 5) < LA ? srcA[aA + k] : 0u;
+    // the next tile starts inside this chunk, at chunk bit dB = 32 * kb + rb
+    const bool two = LB != 0 && p + CHUNK * 8 > eA;
+    const unsigned dB = two ? (unsigned)(eA - p) : 0u, kb = dB >> 5, rb = dB & 31u;
+    uint32_t wn[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) wn[k] = two && (unsigned)k >= kb && (((unsigned)k - kb) << 5) < LB ? srcB[(unsigned)k - kb] : 0u;
+    uint32_t out[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        uint32_t v = sA ? __builtin_amdgcn_alignbit(wa[k], wa[k + 1], 32u - sA) : wa[k];
+        v |= __builtin_amdgcn_alignbit(k > 0 ? wn[k - 1] : 0u, wn[k], rb);
+        out[k] = v;
     }
-    const unsigned long long* B = base + (size_t)frame * (tpf + 1);
-    for (unsigned i = tid; i < (unsigned)ASM_WIN + 2u; i += 256u) wb[i] = B[t0 + i < tpf ? t0 + i : tpf];
-    __syncthreads();
-    unsigned n_ff = 0;
-    if (c * CHUNK < nbytes) {
-        const unsigned long long p = c * (CHUNK * 8ull);
-        int lo = 0, hi = ASM_WIN;                                   // wb[lo] <= p; first wb[hi] > p or the window's end
-        while (hi - lo > 1) {
-            const int mid = (lo + hi) >> 1;
-            if (wb[mid] <= p) lo = mid; else hi = mid;
-        }
-        const int t = lo;
-        const unsigned long long eA = wb[t + 1];
-        const unsigned tA = t0 + (unsigned)t < tpf ? t0 + (unsigned)t : tpf - 1;
-        const uint32_t* srcA = S + ((size_t)frame * tpf + tA) * TILE_STREAM_WORDS;
-        const unsigned long long qA = p - wb[t];
-        const unsigned LA = (unsigned)(eA - wb[t]), aA = (unsigned)(qA >> 5), sA = (unsigned)(qA & 31u);
-        uint32_t wa[17];
-#pragma unroll
-        for (int k = 0; k < 17; ++k) wa[k] = qA < LA && ((aA + k) << 5) < LA ? srcA[aA + k] : 0u;
-        // the next tile starts inside this chunk, at chunk bit dB = 32 * kb + rb
-        const bool two = p + CHUNK * 8 > eA && tA + 1 < tpf;
-        const unsigned dB = two ? (unsigned)(eA - p) : 0u, kb = dB >> 5, rb = dB & 31u;
-        const unsigned LB = two ? (unsigned)(wb[t + 2] - eA) : 0u;
-        const uint32_t* srcB = S + ((size_t)frame * tpf + (two ? tA + 1 : tA)) * TILE_STREAM_WORDS;
-        uint32_t wn[16];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) wn[k] = two && (unsigned)k >= kb && (((unsigned)k - kb) << 5) < LB ? srcB[(unsigned)k - kb] : 0u;
-        uint32_t out[16];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            uint32_t v = sA ? __builtin_amdgcn_alignbit(wa[k], wa[k + 1], 32u - sA) : wa[k];
-            v |= __builtin_amdgcn_alignbit(k > 0 ? wn[k - 1] : 0u, wn[k], rb);
-            out[k] = v;
-        }
 #if JPEZY_PAD_BIT   // alternative frozen choice (include/jpezy_constants.h): one pad bits in the frame's last byte; a padded
                     // 0xFF is then stuffed like any other
-        {
-            const unsigned long long T = B[tpf];
-            const unsigned pad = (unsigned)((8 - (T & 7)) & 7);
-            if (pad && T > p && T < p + CHUNK * 8) {
-                const unsigned kk = (unsigned)((T - p) >> 5), keep = (unsigned)((T - p) & 31u);
+    {
+        const unsigned pad = (unsigned)((8 - (T & 7)) & 7);
+        if (pad && T > p && T < p + CHUNK * 8) {
+            const unsigned kk = (unsigned)((T - p) >> 5), keep = (unsigned)((T - p) & 31u);
 #pragma unroll
-                for (int k = 0; k < 16; ++k)
-                    if ((unsigned)k == kk) out[k] |= ((1u << pad) - 1u) << (32u - keep - pad);
+            for (int k = 0; k < 16; ++k)
+                if ((unsigned)k == kk) out[k] |= ((1u << pad) - 1u) << (32u - keep - pad);
+        }
+    }
+#else
+    (void)T;
+#endif
+    unsigned n_ff = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) n_ff += count_ff(out[k]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        dst[k] = make_uint4(__builtin_bswap32(out[4 * k]), __builtin_bswap32(out[4 * k + 1]), __builtin_bswap32(out[4 * k + 2]),
+                            __builtin_bswap32(out[4 * k + 3]));
+    return n_ff;
+}
+
+// One thread per 64-byte chunk of U, a workgroup per 16 KB piece (grid-stride over the pieces: the grid is sized for a typical
+// stream, U for the worst case).
+// SELF (frames of at most ASM_SELF_TILES tiles -- 4096x4096 has 1536): no launch between the coder and this kernel.  Every
+// workgroup reads the frame's tile totals and scans them in LDS (8 values per thread), a thread finds its chunk's tile by
+// binary search there; workgroup 0 of the frame publishes the stream length and latches + clears the frame's error flag
+// (what tile_bases_kernel does for larger frames).
+// !SELF: tile offsets, stream length and the first tile of every piece come from tile_bases_kernel; a workgroup loads the
+// window of at most ASM_WIN tile offsets its piece can touch.
+template <bool SELF>
+__global__ __launch_bounds__(256) void assemble_kernel(const uint32_t* S, const uint32_t* tile_total, const unsigned long long* base,
+                                                      unsigned long long* bytes, const uint32_t* first_tile, unsigned tpf,
+                                                      unsigned ft_stride, uint32_t* U, size_t u_stride_words, uint32_t* loc,
+                                                      uint32_t* ff_tile_total, unsigned* status, unsigned* latched)
+{
+    __shared__ unsigned long long wb[SELF ? 1 : ASM_WIN + 2];
+    __shared__ uint32_t pre[SELF ? ASM_SELF_TILES + 2 : 1];
+    const unsigned frame = blockIdx.y, tid = threadIdx.x;
+    const size_t chunks_per_frame = u_stride_words * 4 / CHUNK, pieces = chunks_per_frame / 256;   // a multiple of 256 (launcher)
+    unsigned long long T, nbytes;
+    if (SELF) {
+        const uint32_t* tt = tile_total + (size_t)frame * tpf;
+        uint32_t v[8], sum = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const unsigned t = tid * 8u + k;
+            v[k] = t < tpf ? tt[t] : 0u;
+            sum += v[k];
+        }
+        uint32_t total;
+        uint32_t run = wg256_exclusive_scan(sum, &total);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            pre[tid * 8u + k] = run;           // entries past tpf: the total
+            run += v[k];
+        }
+        if (tid == 255) { pre[ASM_SELF_TILES] = total; pre[ASM_SELF_TILES + 1] = total; }
+        __syncthreads();
+        T = total;
+        nbytes = (T + 7) >> 3;
+        if (blockIdx.x == 0 && tid == 0) {
+            bytes[frame] = nbytes;
+            if (latched) {                      // consumed after every writer (the coder), before every reader (the stuffing kernel)
+                latched[frame] = status[frame];
+                status[frame] = 0;
             }
         }
+    } else {
+        nbytes = bytes[frame];
+        T = 0;
+#if JPEZY_PAD_BIT
+        T = base[(size_t)frame * (tpf + 1) + tpf];
 #endif
-        uint4* dst = reinterpret_cast<uint4*>(U + (size_t)frame * u_stride_words) + c * (CHUNK / 16);
-#pragma unroll
-        for (int k = 0; k < 16; ++k) n_ff += count_ff(out[k]);
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-            dst[k] = make_uint4(__builtin_bswap32(out[4 * k]), __builtin_bswap32(out[4 * k + 1]), __builtin_bswap32(out[4 * k + 2]),
-                                __builtin_bswap32(out[4 * k + 3]));
     }
-    uint32_t total;
-    const uint32_t off = wg256_exclusive_scan(n_ff, &total);
-    if (c < chunks_per_frame) loc[(size_t)frame * chunks_per_frame + c] = off;
-    if (tid == 0) ff_tile_total[ff_tile] = total;
+    for (size_t x = blockIdx.x; x < pieces; x += gridDim.x) {
+        const unsigned long long c0 = (unsigned long long)x * 256u, c = c0 + tid;
+        // the first piece of a frame is always written, and so is the one that holds the one-past-the-end chunk (the stuffing
+        // kernel reads that chunk's offset); the pieces behind it are never read
+        if (x != 0 && c0 * CHUNK > nbytes) break;
+        unsigned n_ff = 0;
+        const unsigned long long p = c * (CHUNK * 8ull);
+        uint4* dst = reinterpret_cast<uint4*>(U + (size_t)frame * u_stride_words) + c * (CHUNK / 16);
+        if (SELF) {
+            if (c * CHUNK < nbytes) {
+                unsigned lo = 0, hi = tpf;                              // pre[lo] <= p < pre[hi] = T
+                while (hi - lo > 1) {
+                    const unsigned mid = (lo + hi) >> 1;
+                    if (pre[mid] <= p) lo = mid; else hi = mid;
+                }
+                const unsigned t = lo;
+                const uint32_t* srcA = S + ((size_t)frame * tpf + t) * TILE_STREAM_WORDS;
+                const unsigned LB = t + 1 < tpf ? pre[t + 2] - pre[t + 1] : 0u;
+                n_ff = assemble_chunk(p, pre[t], pre[t + 1], srcA, LB, srcA + TILE_STREAM_WORDS, T, dst);
+            }
+        } else {
+            const unsigned t0 = first_tile[(size_t)frame * ft_stride + x];     // (garbage past the stream's end: clamped, unused)
+            const unsigned long long* B = base + (size_t)frame * (tpf + 1);
+            __syncthreads();                                                    // the previous piece's window is no longer read
+            for (unsigned i = tid; i < (unsigned)ASM_WIN + 2u; i += 256u) wb[i] = B[t0 + i < tpf ? t0 + i : tpf];
+            __syncthreads();
+            if (c * CHUNK < nbytes) {
+                int lo = 0, hi = ASM_WIN;                               // wb[lo] <= p; first wb[hi] > p or the window's end
+                while (hi - lo > 1) {
+                    const int mid = (lo + hi) >> 1;
+                    if (wb[mid] <= p) lo = mid; else hi = mid;
+                }
+                const int t = lo;
+                const unsigned tA = t0 + (unsigned)t < tpf ? t0 + (unsigned)t : tpf - 1;
+                const uint32_t* srcA = S + ((size_t)frame * tpf + tA) * TILE_STREAM_WORDS;
+                const unsigned LB = tA + 1 < tpf ? (unsigned)(wb[t + 2] - wb[t + 1]) : 0u;
+                n_ff = assemble_chunk(p, wb[t], wb[t + 1], srcA, LB, srcA + TILE_STREAM_WORDS, T, dst);
+            }
+        }
+        uint32_t total;
+        const uint32_t off = wg256_exclusive_scan(n_ff, &total);
+        loc[(size_t)frame * chunks_per_frame + c] = off;
+        if (tid == 0) ff_tile_total[(size_t)frame * pieces + x] = total;
+        __syncthreads();                                                        // the scan's LDS is reused by the next piece
+    }
 }
 
 // ---- exclusive prefix sums: 2048 elements per workgroup, recursive over the workgroup totals ----
@@ -764,12 +831,16 @@ hipError_t launch_stuff(const uint32_t* U, size_t u_stride_words, const unsigned
     return hipGetLastError();
 }
 
-// dst[f] = 0xFF bytes of frame f's unstuffed stream (the host-delivered form sizes its output from it)
-__global__ __launch_bounds__(256) void ff_frame_totals_kernel(const uint32_t* ff_tile_total, size_t pieces, unsigned long long* dst)
+// dst[f] = 0xFF bytes of frame f's unstuffed stream (the host-delivered form sizes its output from it): the totals of the
+// pieces the assembling kernel wrote -- up to the one that holds the one-past-the-end chunk
+__global__ __launch_bounds__(256) void ff_frame_totals_kernel(const uint32_t* ff_tile_total, const unsigned long long* bytes, size_t pieces,
+                                                             unsigned long long* dst)
 {
     __shared__ unsigned long long red[4];
+    const size_t piece_bytes = (size_t)256 * CHUNK;
+    const size_t used = (size_t)(bytes[blockIdx.x] / piece_bytes) + 1 < pieces ? (size_t)(bytes[blockIdx.x] / piece_bytes) + 1 : pieces;
     unsigned long long sum = 0;
-    for (size_t x = threadIdx.x; x < pieces; x += 256) sum += ff_tile_total[blockIdx.x * pieces + x];
+    for (size_t x = threadIdx.x; x < used; x += 256) sum += ff_tile_total[blockIdx.x * pieces + x];
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d, 64);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sum;
@@ -777,10 +848,12 @@ __global__ __launch_bounds__(256) void ff_frame_totals_kernel(const uint32_t* ff
     if (threadIdx.x == 0) dst[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 
-hipError_t launch_ff_frame_totals(const uint32_t* ff_tile_total, size_t u_stride_words, int n_frames, unsigned long long* dst, hipStream_t s)
+hipError_t launch_ff_frame_totals(const uint32_t* ff_tile_total, const unsigned long long* bytes, size_t u_stride_words, int n_frames,
+                                  unsigned long long* dst, hipStream_t s)
 {
     if (n_frames <= 0) return hipSuccess;
-    hipLaunchKernelGGL(ff_frame_totals_kernel, dim3((unsigned)n_frames), dim3(256), 0, s, ff_tile_total, u_stride_words * 4 / assemble_piece_bytes(), dst);
+    hipLaunchKernelGGL(ff_frame_totals_kernel, dim3((unsigned)n_frames), dim3(256), 0, s, ff_tile_total, bytes,
+                       u_stride_words * 4 / assemble_piece_bytes(), dst);
     return hipGetLastError();
 }
 
@@ -808,15 +881,26 @@ hipError_t launch_tile_bases(const uint32_t* tile_total, unsigned tiles_per_fram
     return hipGetLastError();
 }
 
-hipError_t launch_assemble(const uint32_t* S, const unsigned long long* base, const unsigned long long* bytes, const uint32_t* first_tile,
-                           unsigned ft_stride, unsigned tiles_per_frame, int n_frames, uint32_t* U, size_t u_stride_words, uint32_t* loc,
-                           uint32_t* ff_tile_total, hipStream_t s)
+bool assemble_scans_tiles_itself(size_t tiles_per_frame) { return tiles_per_frame <= ASM_SELF_TILES; }
+
+hipError_t launch_assemble(const uint32_t* S, const uint32_t* tile_total, const unsigned long long* base, unsigned long long* bytes,
+                           const uint32_t* first_tile, unsigned ft_stride, unsigned tiles_per_frame, int n_frames, uint32_t* U,
+                           size_t u_stride_words, uint32_t* loc, uint32_t* ff_tile_total, unsigned* status, unsigned* latched, hipStream_t s)
 {
     const size_t pieces = u_stride_words * 4 / assemble_piece_bytes();
     if (!pieces || n_frames <= 0) return hipSuccess;
-    if (u_stride_words * 4 % assemble_piece_bytes() || n_frames > 65535 || pieces > ft_stride) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(assemble_kernel, dim3((unsigned)pieces, (unsigned)n_frames), dim3(256), 0, s, S, base, bytes, first_tile,
-                       tiles_per_frame, ft_stride, U, u_stride_words, loc, ff_tile_total);
+    if (u_stride_words * 4 % assemble_piece_bytes() || n_frames > 65535) return hipErrorInvalidValue;
+    // a grid for a typical stream (1024 pieces = 16 MB per frame), fewer per frame when the frames fill the chip
+    size_t gx = pieces < 1024 ? pieces : 1024;
+    if (n_frames > 1 && gx > 128) gx = 128;
+    if (assemble_scans_tiles_itself(tiles_per_frame)) {
+        hipLaunchKernelGGL(assemble_kernel<true>, dim3((unsigned)gx, (unsigned)n_frames), dim3(256), 0, s, S, tile_total, base, bytes, first_tile,
+                           tiles_per_frame, ft_stride, U, u_stride_words, loc, ff_tile_total, status, latched);
+    } else {
+        if (pieces > ft_stride) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(assemble_kernel<false>, dim3((unsigned)gx, (unsigned)n_frames), dim3(256), 0, s, S, tile_total, base, bytes,
+                           first_tile, tiles_per_frame, ft_stride, U, u_stride_words, loc, ff_tile_total, status, latched);
+    }
     return hipGetLastError();
 }
 

@@ -64,21 +64,22 @@ __device__ __forceinline__ uint32_t wg256_exclusive_scan(uint32_t v, uint32_t* t
     return woff + inc - v;
 }
 
-// codes of one block (ref :174-225).  z: 64 zig-zag coefficients in LDS (nullptr: an all-zero block), pred: DC of the
-// previous block of the component.  Returns the length in bits; err is set for values outside the Annex-K tables (the
-// reference throws / the host writer returns JPEZY_E_FORMAT).
+// codes of one block (ref :174-225).  z: its 64 zig-zag coefficients (nullptr: an all-zero block), pred: DC of the previous
+// block of the component; the codes go to the writer w, which also knows how many bits it has taken.  Returns false for
+// values outside the Annex-K tables (the reference throws, the host writer returns JPEZY_E_FORMAT); such a value is coded as
+// the largest size, so the stream stays well formed and the frame is flagged.
 // The reference walks all 63 AC positions and counts zeros; here the lane first forms the 63-bit mask of its block's
 // non-zero AC coefficients (MSB = zig-zag position 1 ... so that the next coefficient is a count-leading-zeros away) and
 // then visits only those: the run before a coefficient is the gap between two set bits.  A wave's loop runs as long as
-// its fullest block has non-zero coefficients (about 25 of 63 on noise, a handful on pictures) and every iteration
-// does the same work in every lane -- the position-by-position loop paid both branch sides 63 times.
-// AC coefficients whose positions are the set bits of m (bit 31 - k: position base + k), in order.  Branch-light on
-// purpose: no early exit (a value outside the tables sets `bad` and is coded as size 10), the ZRL codes of the length pass
-// are a multiply, and the next coefficient is requested from LDS before the current one is coded -- each iteration then
-// waits for one LDS round trip (the code-table lookup), not two.
+// its fullest block has non-zero coefficients and every iteration does the same work in every lane.  Branch-light on
+// purpose: no early exit, the only branch is the rare run over 15 (ZRL codes), and the next coefficient is requested before
+// the current one is coded -- an iteration waits for one LDS round trip (the code-table lookup), not two.  The kernel is bound
+// by VALU issue (2,100 instructions per wave on noise, ~50 per non-zero coefficient): whatever can be derived after the
+// loop (the length from the writer's cursor, the range check from a running maximum) is not tracked inside it.
+// AC coefficients whose positions are the set bits of m (bit 31 - k: position base + k), in order.
 template <class W>
 __device__ __forceinline__ void code_ac(uint32_t m, int base, const int16_t* z, int& prev, const uint32_t* ac, uint32_t zrl, W& w,
-                                        unsigned& len, unsigned& bad)
+                                        unsigned& amax)
 {
 #if defined(JPEZY_ENT_ABL) && JPEZY_ENT_ABL == 2
     m = 0;
@@ -91,32 +92,28 @@ __device__ __forceinline__ void code_ac(uint32_t m, int base, const int16_t* z, 
         m &= 0x7FFFFFFFu >> lz;
         lz = __builtin_clz(m | 1u);             // 31 when nothing is left: a harmless in-bounds read
         vnext = z[base + lz];
-        w.next_unread(m ? base + lz + 1 : base + 32);   // everything below has been read (the in-place writer's licence)
+        w.read_up_to(n);                         // (the in-place writer's licence: positions up to n are dead)
         int run = n - prev - 1;
         prev = n;
         const unsigned a = (unsigned)(v < 0 ? -v : v);
+        amax = a > amax ? a : amax;
         int sz = 32 - __builtin_clz(a);
-        bad |= (unsigned)(sz > 10);
         sz = sz > 10 ? 10 : sz;
-        const int nz = run >> 4;                // ZRL codes in front of this coefficient (runs over 15, ref :198-206)
-        run &= 15;
-        if (W::writes) {
-            for (int r = nz; r > 0; --r) w.put(zrl >> 8, (int)(zrl & 0xFF));
+        if (run > 15) {                          // ZRL codes in front of this coefficient (ref :198-206)
+            for (int r = run >> 4; r > 0; --r) w.put(zrl >> 8, (int)(zrl & 0xFF));
+            run &= 15;
         }
-        len += (unsigned)nz * (zrl & 0xFF);
         const uint32_t e = ac[(run << 4) | sz];
         // code and value bits in one append: at most 16 + 10 bits
-        const int nb = (int)(e & 0xFF) + sz;
-        w.put(((e >> 8) << sz) | ((uint32_t)(v + (v >> 31)) & ((1u << sz) - 1u)), nb);
-        len += (unsigned)nb;
+        w.put(((e >> 8) << sz) | ((uint32_t)(v + (v >> 31)) & ((1u << sz) - 1u)), (int)(e & 0xFF) + sz);
     }
 }
 
 template <class W>
-__device__ __forceinline__ unsigned code_block(const int16_t* z, int pred, const uint32_t* dc, const uint32_t* ac, W& w,
-                                               bool& err)
+__device__ __forceinline__ bool code_block(const int16_t* z, int pred, const uint32_t* dc, const uint32_t* ac, W& w)
 {
-    unsigned len = 0, bad = 0;
+    unsigned amax = 0;
+    bool ok = true;
     uint32_t mhi = 0, mlo = 0;          // bit (31 - n) of mhi: position n in 0..31 is non-zero; mlo likewise for 32..63
     int dcv = 0;
     if (z) {
@@ -139,28 +136,24 @@ __device__ __forceinline__ unsigned code_block(const int16_t* z, int pred, const
         const int diff = dcv - pred;
         const unsigned a = (unsigned)(diff < 0 ? -diff : diff);
         int di = a ? 32 - __builtin_clz(a) : 0;
-        bad |= (unsigned)(di > 11);
+        ok = di <= 11;
         di = di > 11 ? 11 : di;
         const uint32_t e = dc[di];
         // code and value bits in one append: at most 11 + 11 bits
-        const int n = (int)(e & 0xFF) + di;
-        w.put(((e >> 8) << di) | ((uint32_t)(diff + (diff >> 31)) & ((1u << di) - 1u)), n);
-        len += (unsigned)n;
+        w.put(((e >> 8) << di) | ((uint32_t)(diff + (diff >> 31)) & ((1u << di) - 1u)), (int)(e & 0xFF) + di);
     }
     int prev = 0;                        // position of the previous non-zero coefficient (0: the DC)
     if (z) {
         const uint32_t zrl = ac[0xF0];
-        code_ac(mhi, 0, z, prev, ac, zrl, w, len, bad);
-        code_ac(mlo, 32, z, prev, ac, zrl, w, len, bad);
+        code_ac(mhi, 0, z, prev, ac, zrl, w, amax);
+        code_ac(mlo, 32, z, prev, ac, zrl, w, amax);
     }
-    w.next_unread(64);
+    w.read_up_to(63);
     if (prev != 63) {                    // the block ends in zeros (or has no AC coefficient at all): EOB
         const uint32_t e = ac[0x00];
         w.put(e >> 8, (int)(e & 0xFF));
-        len += e & 0xFF;
     }
-    if (bad) err = true;                 // coded as the largest size: lengths and stream stay consistent, the frame is flagged
-    return len;
+    return ok && amax <= 1023u;
 }
 
 constexpr int CHUNK = 64;   // bytes of the unstuffed stream U per thread of the 0xFF counting / stuffing kernels
@@ -177,7 +170,7 @@ __device__ __forceinline__ unsigned count_ff(uint32_t x)
 // The two-pass form above codes every block twice (lengths, then bits at the scanned offset).  Here a lane codes its block
 // ONCE, into its own LDS row, in place: the row holds the block's 64 coefficients from byte 16 on, the private stream grows
 // from byte 0, and a word is only written where every coefficient under it has already been read (RowWriter::limit, fed by
-// code_ac's next_unread) -- on ordinary content the codes are far shorter than the coefficients they replace.  A block whose
+// code_ac's read_up_to) -- on ordinary content the codes are far shorter than the coefficients they replace.  A block whose
 // stream would overtake its unread coefficients or exceed 140 bytes is counted only and re-coded afterwards straight from
 // global memory (DirectWriter; high-quality tables on noise).  After the workgroup's scan over the 256 lengths each lane
 // shift-copies its words to the tile's stream in global memory.  No atomics and no zeroed buffer: a word belongs to the lane
@@ -191,26 +184,23 @@ constexpr int ROW = 144, ROW_DATA = 16, ROW_LAST_WORD = 34;      // private stre
 constexpr unsigned TILE_STREAM_WORDS = 256 * 208 / 4;            // worst case of 208 bytes per block
 
 struct RowWriter {
-    static constexpr bool writes = true;
     unsigned long long acc;
-    int nacc, wj, limit, ovf;
+    int nacc, wj, limit, stored;
     uint32_t* row;
     __device__ __forceinline__ void init(uint32_t* r)
     {
-        row = r; acc = 0; nacc = 0; wj = 0; ovf = 0;
+        row = r; acc = 0; nacc = 0; wj = 0; stored = 0;
         limit = 3;                       // bytes 0..15 are free from the start
     }
-    // positions below `pos` have been read: word j (bytes 4j..4j+3) covers coefficients below 2j - 6
-    __device__ __forceinline__ void next_unread(int pos)
-    {
-        const int l = (pos + 6) >> 1;
-        limit = l > ROW_LAST_WORD ? ROW_LAST_WORD : l;
-    }
+    // positions up to n have been read (n itself is counted as unread: one add and one shift, no clamp -- n <= 63 gives 34):
+    // word j (bytes 4j..4j+3) covers coefficients below 2j - 6
+    __device__ __forceinline__ void read_up_to(int n) { limit = (n + 6) >> 1; }
     // one predicated store; everything else is arithmetic (nested branches here cost more than the coding itself)
     __device__ __forceinline__ void word(uint32_t v, bool due)
     {
-        if (due && wj <= limit) row[wj] = v;
-        ovf |= (int)(due && wj > limit);
+        const bool ok = due && wj <= limit;
+        if (ok) row[wj] = v;
+        stored += (int)ok;
         wj += (int)due;
     }
     __device__ __forceinline__ void put(uint32_t bits, int n)   // n <= 26
@@ -221,15 +211,16 @@ struct RowWriter {
         nacc -= due ? 32 : 0;
         word((uint32_t)(acc >> nacc), due);
     }
+    __device__ __forceinline__ unsigned bits() const { return 32u * (unsigned)wj + (unsigned)nacc; }   // before finish()
     __device__ __forceinline__ void finish()
     {
         word((uint32_t)(acc << (32 - nacc)), nacc > 0);          // left aligned, zero padded (nacc < 32)
     }
+    __device__ __forceinline__ bool overflowed() const { return stored != wj; }                         // after finish()
 };
 
 // second coding pass of the rare block that did not fit its row: bits straight to the tile stream at their final place
 struct DirectWriter {
-    static constexpr bool writes = true;
     unsigned long long acc;
     int nacc;
     unsigned w;
@@ -239,7 +230,7 @@ struct DirectWriter {
     {
         S = tile_stream; w = bitoff >> 5; nacc = (int)(bitoff & 31u); acc = 0; skip = nacc != 0;
     }
-    __device__ __forceinline__ void next_unread(int) {}
+    __device__ __forceinline__ void read_up_to(int) {}
     __device__ __forceinline__ void put(uint32_t bits, int n)
     {
         acc = (acc << n) | bits;
@@ -296,11 +287,11 @@ __global__ __launch_bounds__(WG) void code_tiles_kernel(Job job, uint32_t* S, ui
         }
         RowWriter w;
         w.init(row);
-        bool err = false;
-        n = code_block(zg ? reinterpret_cast<const int16_t*>(tile + tid * ROW + ROW_DATA) : nullptr, pred, L.dc[table], L.ac[table], w, err);
+        const bool ok = code_block(zg ? reinterpret_cast<const int16_t*>(tile + tid * ROW + ROW_DATA) : nullptr, pred, L.dc[table], L.ac[table], w);
+        n = w.bits();
         w.finish();
-        ovf = w.ovf != 0;
-        if (err) atomicOr(status + frame, 1u);
+        ovf = w.overflowed();
+        if (!ok) atomicOr(status + frame, 1u);
     }
     row[ROW_LAST_WORD + 1] = n;            // where the owner of a partial word finds the length of the lanes after it
     uint32_t total;
@@ -334,8 +325,7 @@ __global__ __launch_bounds__(WG) void code_tiles_kernel(Job job, uint32_t* S, ui
     } else {
         DirectWriter w;
         w.init(Sg, o);
-        bool err = false;
-        (void)code_block(zg, pred, L.dc[table], L.ac[table], w, err);
+        (void)code_block(zg, pred, L.dc[table], L.ac[table], w);
         if (w.nacc > 0 && !w.skip) {
             tail_word = w.w;
             tail_fill = (unsigned)w.nacc;

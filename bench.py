@@ -589,7 +589,7 @@ def run_rank(args):
         ea = ebytes / (ent_ms * 1e-3) / 1e9
         entropy_roof = {"bound": "hbm", "achieved": round(ea, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(ea / HBM_PEAK_GBS, 4), "traffic": None,
-                        "kernel": "entropy stage (block_bits + scans + emit + ff_count + stuff), all launches of one frame",
+                        "kernel": "entropy stage (code_tiles + assemble + stuff), all launches of one frame",
                         "algorithmic_bytes_per_step": ebytes, "avg_step_ms_hip_events": round(ent_ms, 5),
                         "jpg_bytes_per_frame": int(sum(sizes) / len(sizes))}
         del g3

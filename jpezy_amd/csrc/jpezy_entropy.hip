@@ -33,12 +33,12 @@ struct LdsTables {
     uint32_t ac[2][256];
 };
 
+// (no barrier: the caller's own barrier after staging its tile covers the tables)
 __device__ __forceinline__ void load_tables(LdsTables& L, const CodeTables* T)
 {
     const uint32_t* src = reinterpret_cast<const uint32_t*>(T);
     uint32_t* dst = reinterpret_cast<uint32_t*>(&L);
     for (unsigned i = threadIdx.x; i < sizeof(LdsTables) / 4; i += blockDim.x) dst[i] = src[i];
-    __syncthreads();
 }
 
 // exclusive prefix sum of one value per thread over a 256-thread workgroup; *total = the workgroup's sum (all threads)
@@ -253,6 +253,21 @@ __global__ __launch_bounds__(WG) void code_tiles_kernel(Job job, uint32_t* S, ui
     const unsigned nblk = job.blocks_per_frame, g0 = blockIdx.x * (unsigned)WG;
     const unsigned nb = nblk - g0 < (unsigned)WG ? nblk - g0 : (unsigned)WG;          // coded blocks of this tile
     const int16_t* fc = job.coeffs + (size_t)frame * job.coeffs_per_frame;
+    // this lane's block: its place in global memory (nullptr: a zero chroma block of gray mode) and its DC predictor -- the
+    // previous block of the same component in scan order, read from global memory (it may be another tile's), requested
+    // before the tile is staged so that its latency hides behind the staging loads
+    const bool valid = tid < nb;
+    int pred = 0, table = 0;
+    const int16_t* zg = nullptr;
+    if (valid) {
+        const unsigned g = g0 + tid, mcu = g / 6u, i = g - mcu * 6u;
+        table = i < 4 ? 0 : 1;
+        if (!(i >= 4 && job.bpm == 4)) {
+            zg = fc + ((size_t)mcu * job.bpm + i) * 64;
+            if (i >= 1 && i <= 3) pred = zg[-64];
+            else if (mcu != 0) pred = i == 0 ? zg[-(job.bpm - 3) * 64] : zg[-job.bpm * 64];
+        }
+    }
     // the tile's stored blocks are contiguous in memory; row = the lane that codes the block
     if (job.bpm == 6) {
         const uint4* src = reinterpret_cast<const uint4*>(fc + (size_t)g0 * 64);
@@ -270,21 +285,10 @@ __global__ __launch_bounds__(WG) void code_tiles_kernel(Job job, uint32_t* S, ui
     }
     __syncthreads();
 
-    const bool valid = tid < nb;
     uint32_t* const row = reinterpret_cast<uint32_t*>(tile + tid * ROW);
     unsigned n = 0;
     bool ovf = false;
-    int pred = 0, table = 0;
-    const int16_t* zg = nullptr;          // the block in global memory; nullptr: a zero chroma block of gray mode
     if (valid) {
-        const unsigned g = g0 + tid, mcu = g / 6u, i = g - mcu * 6u;
-        table = i < 4 ? 0 : 1;
-        if (!(i >= 4 && job.bpm == 4)) {
-            zg = fc + ((size_t)mcu * job.bpm + i) * 64;
-            // predictor: previous block of the same component in scan order, from global memory (it may be another tile's)
-            if (i >= 1 && i <= 3) pred = zg[-64];
-            else if (mcu != 0) pred = i == 0 ? zg[-(job.bpm - 3) * 64] : zg[-job.bpm * 64];
-        }
         RowWriter w;
         w.init(row);
         const bool ok = code_block(zg ? reinterpret_cast<const int16_t*>(tile + tid * ROW + ROW_DATA) : nullptr, pred, L.dc[table], L.ac[table], w);
@@ -460,7 +464,7 @@ __global__ __launch_bounds__(256) void assemble_kernel(const uint32_t* S, const 
     const unsigned frame = blockIdx.y, tid = threadIdx.x;
     const size_t chunks_per_frame = u_stride_words * 4 / CHUNK, pieces = chunks_per_frame / 256;   // a multiple of 256 (launcher)
     unsigned long long T, nbytes;
-    if (SELF) {
+    if constexpr (SELF) {
         const uint32_t* tt = tile_total + (size_t)frame * tpf;
         uint32_t v[8], sum = 0;
 #pragma unroll
@@ -502,7 +506,7 @@ __global__ __launch_bounds__(256) void assemble_kernel(const uint32_t* S, const 
         unsigned n_ff = 0;
         const unsigned long long p = c * (CHUNK * 8ull);
         uint4* dst = reinterpret_cast<uint4*>(U + (size_t)frame * u_stride_words) + c * (CHUNK / 16);
-        if (SELF) {
+        if constexpr (SELF) {
             if (c * CHUNK < nbytes) {
                 unsigned lo = 0, hi = tpf;                              // pre[lo] <= p < pre[hi] = T
                 while (hi - lo > 1) {
@@ -714,86 +718,96 @@ __global__ __launch_bounds__(STUFF_WG) void stuff_kernel(const uint32_t* U, size
     uint8_t* const lb = reinterpret_cast<uint8_t*>(buf);
     const size_t chunks_per_frame = u_stride_words * 4 / CHUNK, pieces = chunks_per_frame / STUFF_WG;
     const size_t frame = blockIdx.y;
-    const size_t c0 = (size_t)blockIdx.x * STUFF_WG;
     const unsigned long long nbytes = frame_bytes[frame];
-    if ((unsigned long long)c0 * CHUNK >= nbytes) return;                       // workgroup-uniform
-    // 0xFF bytes of the frame before this workgroup's chunks, and in the whole frame: the workgroup adds up the tile totals
-    // itself (a few hundred 4-byte values out of the L2) -- a scan launched in between costs more than all of these sums
-    const uint32_t* ft = ff_tile_total + frame * pieces;
-    const size_t used = (size_t)(nbytes / ((unsigned long long)STUFF_WG * CHUNK)) + 1 < pieces ? (size_t)(nbytes / ((unsigned long long)STUFF_WG * CHUNK)) + 1 : pieces;
-    unsigned long long pre = 0, all = 0;
-    for (size_t x = threadIdx.x; x < used; x += STUFF_WG) {
-        const uint32_t v = ft[x];
-        all += v;
-        pre += x < blockIdx.x ? v : 0u;
-    }
+    // grid-stride over the 16 KB pieces: the grid is sized for a typical stream, the buffer for the worst case
+    for (size_t px = blockIdx.x; (unsigned long long)px * STUFF_WG * CHUNK < nbytes; px += gridDim.x) {
+        const size_t c0 = px * STUFF_WG, c = c0 + threadIdx.x;
+        // this thread's 64 bytes and their offset inside the piece: requested now, together with the tile totals below -- the
+        // kernel is a chain of memory round trips (stream length -> {totals, offsets, bytes} -> stores), not arithmetic
+        const uint32_t* loc = ff_loc + frame * chunks_per_frame;                      // 0xFF bytes before a chunk inside its 256-chunk tile
+        const bool has_data = (unsigned long long)c * CHUNK < nbytes;
+        uint4 data[CHUNK / 16];
+        uint32_t my_loc = 0;
+        if (has_data) {
+            const uint4* src = reinterpret_cast<const uint4*>(reinterpret_cast<const uint8_t*>(U + frame * u_stride_words) + c * CHUNK);
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        pre += __shfl_xor(pre, d, 64);
-        all += __shfl_xor(all, d, 64);
-    }
-    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = pre; red[1][threadIdx.x >> 6] = all; }
-    __syncthreads();
-    pre = all = 0;
+            for (int k = 0; k < CHUNK / 16; ++k) data[k] = src[k];
+            my_loc = loc[c];
+        }
+        // 0xFF bytes of the frame before this workgroup's chunks, and in the whole frame: the workgroup adds up the tile totals
+        // itself (a few hundred 4-byte values out of the L2) -- a scan launched in between costs more than all of these sums
+        const uint32_t* ft = ff_tile_total + frame * pieces;
+        const size_t last = (size_t)(nbytes / ((unsigned long long)STUFF_WG * CHUNK)), used = last + 1 < pieces ? last + 1 : pieces;
+        unsigned long long pre = 0, all = 0;
+        for (size_t x = threadIdx.x; x < used; x += STUFF_WG) {
+            const uint32_t v = ft[x];
+            all += v;
+            pre += x < px ? v : 0u;
+        }
 #pragma unroll
-    for (int k = 0; k < STUFF_WG / 64; ++k) { pre += red[0][k]; all += red[1][k]; }
-    if (plan.hdr) {
-        const unsigned long long body = nbytes + all;
-        const unsigned long long total = plan.hdr_len + body + 2;
-        const unsigned st = plan.latched[frame];
-        const bool failed = st != 0 || total > out_stride;
-        if (blockIdx.x == 0) {
-            uint8_t* file = out + frame * out_stride;
-            if (threadIdx.x == 0) {
-                plan.sizes[frame] = st ? -5 : failed ? -6 : (long long)total;
-                if (!failed) {
-                    file[plan.hdr_len + body] = 0xFF;
-                    file[plan.hdr_len + body + 1] = 0xD9;
+        for (int d = 32; d >= 1; d >>= 1) {
+            pre += __shfl_xor(pre, d, 64);
+            all += __shfl_xor(all, d, 64);
+        }
+        if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = pre; red[1][threadIdx.x >> 6] = all; }
+        __syncthreads();
+        pre = all = 0;
+#pragma unroll
+        for (int k = 0; k < STUFF_WG / 64; ++k) { pre += red[0][k]; all += red[1][k]; }
+        if (plan.hdr) {
+            const unsigned long long body = nbytes + all;
+            const unsigned long long total = plan.hdr_len + body + 2;
+            const unsigned st = plan.latched[frame];
+            const bool failed = st != 0 || total > out_stride;
+            if (px == 0) {
+                uint8_t* file = out + frame * out_stride;
+                if (threadIdx.x == 0) {
+                    plan.sizes[frame] = st ? -5 : failed ? -6 : (long long)total;
+                    if (!failed) {
+                        file[plan.hdr_len + body] = 0xFF;
+                        file[plan.hdr_len + body + 1] = 0xD9;
+                    }
+                }
+                if (!failed)
+                    for (size_t i = threadIdx.x; i < plan.hdr_len; i += STUFF_WG) file[i] = plan.hdr[i];
+            }
+            if (failed) return;                                                      // workgroup-uniform
+        }
+        uint8_t* const P = out + (plan.hdr ? plan.hdr_len : 0) + frame * out_stride + c0 * CHUNK + pre;              // first output byte of the workgroup
+        const unsigned shift = (unsigned)(reinterpret_cast<uintptr_t>(P) & 3u);
+        if (has_data) {
+            const int n = (int)((nbytes - (unsigned long long)c * CHUNK) < (unsigned long long)CHUNK ? (nbytes - (unsigned long long)c * CHUNK) : CHUNK);
+            uint8_t* dst = lb + shift + threadIdx.x * CHUNK + my_loc;
+#pragma unroll
+            for (int k = 0; k < CHUNK / 16; ++k) {
+                const uint32_t wd[4] = { data[k].x, data[k].y, data[k].z, data[k].w };
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    if (k * 16 + j < n) {
+                        const uint8_t b = (uint8_t)(wd[j >> 2] >> ((j & 3) * 8));
+                        *dst++ = b;
+                        if (b == 0xFF) *dst++ = 0x00;
+                    }
                 }
             }
-            if (!failed)
-                for (size_t i = threadIdx.x; i < plan.hdr_len; i += STUFF_WG) file[i] = plan.hdr[i];
         }
-        if (failed) return;                                                      // workgroup-uniform
-        out += plan.hdr_len;
-    }
-    const uint32_t* loc = ff_loc + frame * chunks_per_frame;                      // 0xFF bytes before a chunk inside its 256-chunk tile
-    uint8_t* const P = out + frame * out_stride + c0 * CHUNK + pre;              // first output byte of the workgroup
-    const unsigned shift = (unsigned)(reinterpret_cast<uintptr_t>(P) & 3u);
-    const size_t c = c0 + threadIdx.x;
-    if ((unsigned long long)c * CHUNK < nbytes) {
-        const int n = (int)((nbytes - (unsigned long long)c * CHUNK) < (unsigned long long)CHUNK ? (nbytes - (unsigned long long)c * CHUNK) : CHUNK);
-        uint8_t* dst = lb + shift + threadIdx.x * CHUNK + loc[c];
-        const uint4* src = reinterpret_cast<const uint4*>(reinterpret_cast<const uint8_t*>(U + frame * u_stride_words) + c * CHUNK);
-#pragma unroll 1
-        for (int k = 0; k < CHUNK / 16; ++k) {
-            const uint4 v = src[k];
-            const uint32_t wd[4] = { v.x, v.y, v.z, v.w };
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                if (k * 16 + j < n) {
-                    const uint8_t b = (uint8_t)(wd[j >> 2] >> ((j & 3) * 8));
-                    *dst++ = b;
-                    if (b == 0xFF) *dst++ = 0x00;
-                }
+        __syncthreads();
+        // bytes of the workgroup's range: its chunks' bytes plus the 0xFF bytes among them
+        const unsigned long long last_chunk = (nbytes + CHUNK - 1) / CHUNK;          // chunks of the frame that hold data
+        const size_t ce = c0 + STUFF_WG < last_chunk ? c0 + STUFF_WG : (size_t)last_chunk;
+        const unsigned long long src_end = (unsigned long long)ce * CHUNK < nbytes ? (unsigned long long)ce * CHUNK : nbytes;
+        const unsigned total = (unsigned)(src_end - (unsigned long long)c0 * CHUNK) + (ce < c0 + STUFF_WG ? loc[ce] : ft[px]);
+        uint32_t* const A = reinterpret_cast<uint32_t*>(P - shift);                  // 4-byte aligned
+        const unsigned end = shift + total, nwords = (end + 3) / 4;
+        for (unsigned w = threadIdx.x; w < nwords; w += STUFF_WG) {
+            const unsigned lo = w * 4, hi = lo + 4;
+            if (lo >= shift && hi <= end) {
+                A[w] = buf[w];
+            } else {
+                for (unsigned k = lo < shift ? shift : lo; k < (hi < end ? hi : end); ++k) reinterpret_cast<uint8_t*>(A)[k] = lb[k];
             }
         }
-    }
-    __syncthreads();
-    // bytes of the workgroup's range: its chunks' bytes plus the 0xFF bytes among them
-    const unsigned long long last_chunk = (nbytes + CHUNK - 1) / CHUNK;          // chunks of the frame that hold data
-    const size_t ce = c0 + STUFF_WG < last_chunk ? c0 + STUFF_WG : (size_t)last_chunk;
-    const unsigned long long src_end = (unsigned long long)ce * CHUNK < nbytes ? (unsigned long long)ce * CHUNK : nbytes;
-    const unsigned total = (unsigned)(src_end - (unsigned long long)c0 * CHUNK) + (ce < c0 + STUFF_WG ? loc[ce] : ft[blockIdx.x]);
-    uint32_t* const A = reinterpret_cast<uint32_t*>(P - shift);                  // 4-byte aligned
-    const unsigned end = shift + total, nwords = (end + 3) / 4;
-    for (unsigned w = threadIdx.x; w < nwords; w += STUFF_WG) {
-        const unsigned lo = w * 4, hi = lo + 4;
-        if (lo >= shift && hi <= end) {
-            A[w] = buf[w];
-        } else {
-            for (unsigned k = lo < shift ? shift : lo; k < (hi < end ? hi : end); ++k) reinterpret_cast<uint8_t*>(A)[k] = lb[k];
-        }
+        __syncthreads();             // the staging buffer and the partial sums are reused by the next piece
     }
 }
 
@@ -816,7 +830,9 @@ hipError_t launch_stuff(const uint32_t* U, size_t u_stride_words, const unsigned
     const size_t chunks = u_stride_words * 4 / CHUNK;
     if (!chunks || n_frames <= 0) return hipSuccess;
     if (n_frames > 65535 || chunks % STUFF_WG) return hipErrorInvalidValue;      // the frame index is a grid dimension
-    hipLaunchKernelGGL(stuff_kernel, dim3((unsigned)(chunks / STUFF_WG), (unsigned)n_frames), dim3(STUFF_WG), 0, s, U, u_stride_words,
+    size_t gx = chunks / STUFF_WG < 1024 ? chunks / STUFF_WG : 1024;
+    if (n_frames > 1 && gx > 128) gx = 128;
+    hipLaunchKernelGGL(stuff_kernel, dim3((unsigned)gx, (unsigned)n_frames), dim3(STUFF_WG), 0, s, U, u_stride_words,
                        frame_bytes, ff_loc, ff_tile_total, out, out_stride, plan);
     return hipGetLastError();
 }

@@ -170,8 +170,9 @@ int jpezy_write_jpeg_batch(const int16_t* coeffs, int W, int H, int gray, int n_
 /*
  * The same tail on the GPU ("entropy coding off the critical path"): coefficients already in device
  * memory (the output of jpezy_fdct_quant_dev), bytes identical to jpezy_write_jpeg.  pre_DC (encoder/jpezy_encoder.hpp:
- * 180-181) becomes a read of the previous block's DC and the bit cursor a prefix sum of the blocks' code lengths; the
- * 0xFF00 stuffing of the reference's bofstream is a second prefix sum.  out/sizes are host memory: frame f writes at
+ * 180-181) becomes a read of the previous block's DC and the bit cursor a prefix sum of the blocks' code lengths (every
+ * block is coded once; the sum is formed per 256 blocks and across them afterwards); the 0xFF00 stuffing of the reference's
+ * bofstream is a second prefix sum.  out/sizes are host memory: frame f writes at
  * most cap bytes at out + f*cap and sizes[f] receives its length or a negative status.  Synchronous.
  */
 long jpezy_write_jpeg_gpu(jpezy_ctx* ctx, const int16_t* d_coeffs, int W, int H, int gray, const char* comment,
@@ -183,8 +184,8 @@ int jpezy_write_jpeg_gpu_batch(jpezy_ctx* ctx, const int16_t* d_coeffs, int W, i
  * stream; the coefficients must have been produced on it or be complete), nothing is copied to the host, no host
  * synchronisation.  Frame f's complete file (header, entropy-coded segment, EOI) is written at d_out + f*out_stride
  * and d_sizes[f] (device memory) receives its length, JPEZY_E_FORMAT or JPEZY_E_NOSPACE (out_stride too small; nothing
- * is written past it).  Scratch is sized for the worst case of 208 bytes per block and LIVES IN THE CONTEXT (code lengths,
- * bit offsets, the unstuffed stream): calls of the entropy entry points (this one, jpezy_write_jpeg_gpu[_batch],
+ * is written past it).  Scratch is sized for the worst case of 208 bytes per block and LIVES IN THE CONTEXT (the tile
+ * streams, their bit totals, the unstuffed stream): calls of the entropy entry points (this one, jpezy_write_jpeg_gpu[_batch],
  * jpezy_encode_jpeg, jpezy_read_jpeg_gpu, jpezy_decode_jpeg) on one context must not overlap in time -- issue them on one
  * stream or order the streams with events; frames that are to be in flight together need a context each.
  */

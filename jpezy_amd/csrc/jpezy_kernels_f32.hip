@@ -429,21 +429,6 @@ __global__ __launch_bounds__(64 * WPB, JPEZY_F32_WAVES) void fdct_quant_f32_kern
         }
     }
 
-#ifdef JPEZY_PREFETCH
-    // experiment: touch the pixel rows of the quad that starts JPEZY_PREFETCH workgroups later on this XCD (a multiple
-    // of 8 keeps the XCD), so that its own loads hit L2.  The destination register stays reserved until pf_done below.
-    unsigned pf_dummy;
-    {
-        // unconditional (no phi on the destination register): past the end of the frame the last quad is touched again
-        const unsigned fq = min(qidx + (unsigned)(JPEZY_PREFETCH) * (unsigned)WPB, (unsigned)(p.mcu_rows * p.quads_per_row) - 1u);
-        const int fy = (int)fast_div(fq, p.qpr_magic, p.qpr_shift);
-        const int fx = (int)fq - fy * p.quads_per_row;
-        const int pl = lane >> 4, rr = lane & 15;
-        const uint8_t* pbase = pl == 1 ? pg : pl == 2 ? pb : pr;
-        const uint8_t* a = pbase + (unsigned)min(fy * 16 + rr, H - 1) * (unsigned)W + (unsigned)min(fx * 64, W - 1);
-        asm volatile("global_load_ubyte %0, %1, off" : "=&v"(pf_dummy) : "v"(a) : "memory");
-    }
-#endif
 #ifdef JPEZY_TRACE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const unsigned long long tr_t1 = __builtin_amdgcn_s_memrealtime();
@@ -664,9 +649,6 @@ __global__ __launch_bounds__(64 * WPB, JPEZY_F32_WAVES) void fdct_quant_f32_kern
 
 #ifdef JPEZY_TRACE
     const unsigned long long tr_t2 = __builtin_amdgcn_s_memrealtime();
-#endif
-#ifdef JPEZY_PREFETCH
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf_dummy) :: "memory");
 #endif
     // ---- 6. coalesced store of the quad's coefficients ----
     {

@@ -203,3 +203,21 @@ def test_frame_of_more_than_2048_tiles(J, ctx):
     ctx.write_jpeg_gpu_dev(_dev(g), W, H, out, sizes, n_frames=1, gray=True)
     torch.cuda.synchronize()
     assert int(sizes[0]) == len(want) and out[0, :len(want)].cpu().numpy().tobytes() == want
+    # two such frames in one call, the second with a coefficient outside the tables (its error flag is latched by
+    # tile_bases_kernel on this path) and then with a stride that is too small
+    g2 = np.stack([g, g])
+    g2[1, 7, 9, 2, 5] = 1024
+    out2 = torch.zeros((2, len(want) + 4096), dtype=torch.uint8, device="cuda")
+    sizes2 = torch.zeros(2, dtype=torch.int64, device="cuda")
+    ctx.write_jpeg_gpu_dev(_dev(g2).reshape(2, -1), W, H, out2, sizes2, n_frames=2, gray=True)
+    torch.cuda.synchronize()
+    assert int(sizes2[0]) == len(want) and int(sizes2[1]) == -5
+    assert out2[0, :len(want)].cpu().numpy().tobytes() == want
+    g2[1, 7, 9, 2, 5] = 0
+    small = torch.zeros((2, len(want) - 1), dtype=torch.uint8, device="cuda")
+    ctx.write_jpeg_gpu_dev(_dev(g2).reshape(2, -1), W, H, small, sizes2, n_frames=2, gray=True)
+    torch.cuda.synchronize()
+    assert [int(v) for v in sizes2] == [-6, -6]
+    ctx.write_jpeg_gpu_dev(_dev(g2).reshape(2, -1), W, H, out2, sizes2, n_frames=2, gray=True)       # and the flags were left clear
+    torch.cuda.synchronize()
+    assert [int(v) for v in sizes2] == [len(want)] * 2 and out2[1, :len(want)].cpu().numpy().tobytes() == want

@@ -112,7 +112,7 @@ struct jpezy_ctx {
     // GPU entropy coder (jpezy_entropy.hip): code tables + scratch
     jpezy_dev::entropy::CodeTables* d_codes = nullptr;
     DevBuf e_tmp, e_small, e_U, e_cnt, e_out, e_coef;
-    DevBuf e_tt, e_fft;            // tile totals (256 blocks / 256 chunks) of the two two-level prefix sums
+    DevBuf e_tt, e_fft;            // totals per tile (256 coded blocks: bits) and per piece (256 chunks of 64 bytes: 0xFF bytes)
     DevBuf e_S, e_base, e_ft;      // one-pass coder: tile streams, frame-relative tile bit offsets, first tile per 16 KB of output
     DevBuf e_status;               // per-frame error flags of the device-resident entropy path: zero between calls (cleared by their consumer)
     uint8_t* e_pinned = nullptr;   // pinned host staging of the stuffed streams

@@ -178,7 +178,7 @@ __device__ __forceinline__ unsigned count_ff(uint32_t x)
 // the missing bits from the first word of the following lanes' rows (blocks shorter than 32 bits are consumed whole).
 // Tile streams are MSB-first uint32 words, zero padded to a word.  assemble_kernel then forms the frame's unstuffed stream
 // U output-driven (one thread per 64-byte chunk: funnel shifts across tile borders, byte order swapped on the way out) and
-// counts the 0xFF bytes of its chunk while it has them -- what ff_count_kernel did in a launch of its own.
+// counts the 0xFF bytes of its chunk while it has them.
 constexpr int WG = 256;                                          // coded blocks per workgroup ("tile")
 constexpr int ROW = 144, ROW_DATA = 16, ROW_LAST_WORD = 34;      // private stream: words 0..34; word 35 (bytes 140..143): its length
 constexpr unsigned TILE_STREAM_WORDS = 256 * 208 / 4;            // worst case of 208 bytes per block

@@ -10,7 +10,8 @@ a ring of distinct frames whose inputs+outputs exceed the 256 MiB Infinity Cache
 streams from HBM.  The K timed steps are a fixed sequence of K launches (one per step, on torch's
 current stream): they are captured once into a hipGraph; a *replay* of that graph is exactly K steps,
 bracketed by barrier + synchronize on both sides.  The replay is repeated R times (--repeats, default 11);
-`ms_per_step` is the MEDIAN replay divided by K (max over ranks per replay), min/max are reported beside it.
+`ms_per_step` is the MEDIAN replay divided by K (max over ranks per replay), min/max are reported beside it; the W warm-up
+steps are run again before every repetition's bracket (--rewarm 1), so that each repetition is the contract's own sequence.
 
 --gpus N > 1: when WORLD_SIZE is not set this process starts N copies of itself, one per GPU (RANK /
 LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment) *before it touches the GPU*, and rank 0 prints the
@@ -500,7 +501,10 @@ def run_rank(args):
     R = max(1, args.repeats)
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(R)]
     wall = []
-    for ev0, ev1 in evs:       # nothing but the bracket itself between two replays: the GPU idles as briefly as the contract allows
+    for ev0, ev1 in evs:       # every repetition is the contract's sequence: W untimed warm-up steps, then the bracketed K steps
+        if args.rewarm:
+            for i in range(args.warmup):
+                step(i)
         if multi:
             dist.barrier()
         torch.cuda.synchronize(dev)
@@ -715,6 +719,8 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--repeats", type=int, default=11, help="replays of the K-step sequence; ms_per_step is their median")
+    ap.add_argument("--rewarm", type=int, default=1, help="1: the W warm-up steps are run again before every repetition's bracket "
+                    "(each repetition then is `W warm-up steps, K timed steps`, as the first one is); 0: once, before the first")
     ap.add_argument("--workload", default="encode4096", choices=sorted(WORKLOADS))
     ap.add_argument("--ring", type=int, default=0, help="distinct batches in the ring (0 = enough to exceed 512 MiB)")
     ap.add_argument("--variant", type=int, default=None, help="encode kernel variant (0 FP64 butterflies, 1 FP32 first level [default], "

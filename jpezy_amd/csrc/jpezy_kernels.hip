@@ -477,39 +477,40 @@ __device__ __forceinline__ int exact_idct_sample_sparse(const int2* __restrict__
     return (int)(sum / 4 + 128);
 }
 
-// Sample of the reference, int(sum / 4 + 128) (ref :667), from the fast row sum, plus the guard key of the fast path:
-// e = fract(v) - 1/2 in FP32, so that v is within eps of an integer  <=>  |e| > 1/2 - eps.  v_cvt_i32_f64 truncates
-// toward zero like the reference's int() and saturates; a wild v has fract(v) == 0, i.e. |e| == 1/2: flagged.
-// The fast sum is within 2e-10 of the reference's sum, the conversion of fract(v) to FP32 adds 3e-8, and
-// SAMPLE_EPS = 2^-18 is far above both.  Eight keys are reduced with v_max3; the per-sample flag bits are only formed
-// when the reduction says that some lane of the wave has a sample in the band.
-constexpr float SAMPLE_EPS = 0x1p-18f;
-constexpr float SAMPLE_TH = 0.5f - SAMPLE_EPS;
+// Sample of the reference, int(sum / 4 + 128) (ref :667), from the fast row sum, plus the guard key of the fast path.  v is
+// within eps of an integer  <=>  fract(v) < eps or fract(v) > 1 - eps; fract(v) lies in [0, 1), where the high word of a double
+// orders like the value, so the test is one unsigned compare of  key = hi(fract(v)) - hi(eps)  against  hi(1 - eps) - hi(eps)
+// (a fract below eps wraps to a huge key; eps = 2^-18 and 1 - eps have zero low words, so the high words decide exactly --
+// fract == 1 - eps itself is flagged too, harmlessly).  A wild or non-finite v has fract 0 or NaN: flagged.  v_cvt_i32_f64
+// truncates toward zero like the reference's int() and saturates.  The fast sum is within 2e-10 of the reference's sum
+// (DESIGN.md); eps = 2^-18 is far above it.  Eight keys are reduced with v_max3_u32; the per-sample flag bits are only formed
+// when the reduction says that some lane of the wave has a sample in the band.  (Round 1 converted fract(v) to FP32 and
+// compared |e - 1/2|: one conversion per sample more.)
+constexpr uint32_t SAMPLE_KEY_BASE = 0x3ED00000u;                      // high word of 2^-18
+constexpr uint32_t SAMPLE_KEY_TH = 0x3FEFFFF8u - SAMPLE_KEY_BASE;      // high word of 1 - 2^-18, relative
 // v = row sum / 4 + 128 arrives ready-made: the / 4 is folded into the dequantiser constants (an exact scaling of every
 // intermediate value) and the level shift enters the row pass as one addition to its DC input.  fl(s/4 + 128) is what
 // the reference forms (ref :667); a DC-only block still reproduces it bit for bit (its term reaches the addition
 // unrounded, scaled by an exact 1/4).
-__device__ __forceinline__ int sample_of(double v, float& e)
+__device__ __forceinline__ int sample_of(double v, uint32_t& key)
 {
-    e = (float)__builtin_amdgcn_fract(v) - 0.5f;
+    key = (uint32_t)__double2hiint(__builtin_amdgcn_fract(v)) - SAMPLE_KEY_BASE;
     return (int)v;
 }
-__device__ __forceinline__ float absmax8(const float* e)
+__device__ __forceinline__ uint32_t keymax8(const uint32_t* e)
 {
-    return __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(e[0]), __builtin_fabsf(e[1])),
-                                           __builtin_fmaxf(__builtin_fabsf(e[2]), __builtin_fabsf(e[3]))),
-                           __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(e[4]), __builtin_fabsf(e[5])),
-                                           __builtin_fmaxf(__builtin_fabsf(e[6]), __builtin_fabsf(e[7]))));
+    // a chain, so that the compiler pairs it into v_max3_u32 (3 + 1 instructions)
+    return max(max(max(max(max(max(max(e[0], e[1]), e[2]), e[3]), e[4]), e[5]), e[6]), e[7]);
 }
 // flag bits (bit k: sample k is inside the guard band) of eight samples; dc_only: the block's samples are exact by
 // construction (step 2 of the kernel) and exempt.  The bits are only spelled out when some lane needs them.
-__device__ __forceinline__ unsigned guard_bits8(const float* e, bool dc_only)
+__device__ __forceinline__ unsigned guard_bits8(const uint32_t* e, bool dc_only)
 {
-    const float em = dc_only ? 0.f : absmax8(e);
+    const uint32_t em = dc_only ? 0u : keymax8(e);
     unsigned bits = 0;
-    if (wave_any(em > SAMPLE_TH)) {
+    if (wave_any(em >= SAMPLE_KEY_TH)) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) bits |= (__builtin_fabsf(e[k]) > SAMPLE_TH ? 1u : 0u) << k;
+        for (int k = 0; k < 8; ++k) bits |= (e[k] >= SAMPLE_KEY_TH ? 1u : 0u) << k;
         if (dc_only) bits = 0;
     }
     return bits;
@@ -688,7 +689,7 @@ __global__ __launch_bounds__(64 * WPB, GRAY ? JPEZY_DEC_WAVES_GRAY : JPEZY_DEC_W
             for (int k = 0; k < 4; ++k) { const double2 t = src[k]; in[2 * k] = t.x; in[2 * k + 1] = t.y; }
             in[0] += 128.0;          // level shift, see sample_of
             idct8(in, out);
-            float e[8];
+            uint32_t e[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) Y[half * 8 + k] = sample_of(out[k], e[k]);
             yflags |= guard_bits8(e, half ? dc_only_r : dc_only_l) << (half * 8);
@@ -731,7 +732,7 @@ __global__ __launch_bounds__(64 * WPB, GRAY ? JPEZY_DEC_WAVES_GRAY : JPEZY_DEC_W
         in[0] += 128.0;
         idct8(in, out);
         {
-            float e[8];
+            uint32_t e[8];
             int mine[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) mine[k] = sample_of(out[k], e[k]);

@@ -479,38 +479,34 @@ __device__ __forceinline__ int exact_idct_sample_sparse(const int2* __restrict__
 
 // Sample of the reference, int(sum / 4 + 128) (ref :667), from the fast row sum, plus the guard key of the fast path.  v is
 // within eps of an integer  <=>  fract(v) < eps or fract(v) > 1 - eps; fract(v) lies in [0, 1), where the high word of a double
-// orders like the value, so the test is one unsigned compare of  key = hi(fract(v)) - hi(eps)  against  hi(1 - eps) - hi(eps)
-// (a fract below eps wraps to a huge key; eps = 2^-18 and 1 - eps have zero low words, so the high words decide exactly --
-// fract == 1 - eps itself is flagged too, harmlessly).  A wild or non-finite v has fract 0 or NaN: flagged.  v_cvt_i32_f64
+// orders like the value, so the test is  hi(fract(v)) < hi(eps)  or  hi(fract(v)) >= hi(1 - eps)  (eps = 2^-18 and 1 - eps have
+// zero low words, so the high words decide exactly -- fract == 1 - eps itself is flagged too, harmlessly).  A wild or non-finite v has fract 0 or NaN: flagged.  v_cvt_i32_f64
 // truncates toward zero like the reference's int() and saturates.  The fast sum is within 2e-10 of the reference's sum
-// (DESIGN.md); eps = 2^-18 is far above it.  Eight keys are reduced with v_max3_u32; the per-sample flag bits are only formed
-// when the reduction says that some lane of the wave has a sample in the band.  (Round 1 converted fract(v) to FP32 and
+// (DESIGN.md); eps = 2^-18 is far above it.  The per-sample flag bits are only formed when a reduction over the eight
+// keys says that some lane of the wave has a sample in the band.  (Round 1 converted fract(v) to FP32 and
 // compared |e - 1/2|: one conversion per sample more.)
-constexpr uint32_t SAMPLE_KEY_BASE = 0x3ED00000u;                      // high word of 2^-18
-constexpr uint32_t SAMPLE_KEY_TH = 0x3FEFFFF8u - SAMPLE_KEY_BASE;      // high word of 1 - 2^-18, relative
+constexpr uint32_t SAMPLE_KEY_LO = 0x3ED00000u;                        // high word of 2^-18: fract below it <=> hi(fract) below it
+constexpr uint32_t SAMPLE_KEY_HI = 0x3FEFFFF8u;                        // high word of 1 - 2^-18
 // v = row sum / 4 + 128 arrives ready-made: the / 4 is folded into the dequantiser constants (an exact scaling of every
 // intermediate value) and the level shift enters the row pass as one addition to its DC input.  fl(s/4 + 128) is what
 // the reference forms (ref :667); a DC-only block still reproduces it bit for bit (its term reaches the addition
 // unrounded, scaled by an exact 1/4).
 __device__ __forceinline__ int sample_of(double v, uint32_t& key)
 {
-    key = (uint32_t)__double2hiint(__builtin_amdgcn_fract(v)) - SAMPLE_KEY_BASE;
+    key = (uint32_t)__double2hiint(__builtin_amdgcn_fract(v));
     return (int)v;
 }
-__device__ __forceinline__ uint32_t keymax8(const uint32_t* e)
-{
-    // a chain, so that the compiler pairs it into v_max3_u32 (3 + 1 instructions)
-    return max(max(max(max(max(max(max(e[0], e[1]), e[2]), e[3]), e[4]), e[5]), e[6]), e[7]);
-}
 // flag bits (bit k: sample k is inside the guard band) of eight samples; dc_only: the block's samples are exact by
-// construction (step 2 of the kernel) and exempt.  The bits are only spelled out when some lane needs them.
+// construction (step 2 of the kernel) and exempt.  The keys are reduced two-sided (v_min3_u32 / v_max3_u32 chains: 4 + 4
+// instructions for eight samples, no per-sample arithmetic); the bits are only spelled out when some lane needs them.
 __device__ __forceinline__ unsigned guard_bits8(const uint32_t* e, bool dc_only)
 {
-    const uint32_t em = dc_only ? 0u : keymax8(e);
+    const uint32_t emax = max(max(max(max(max(max(max(e[0], e[1]), e[2]), e[3]), e[4]), e[5]), e[6]), e[7]);
+    const uint32_t emin = min(min(min(min(min(min(min(e[0], e[1]), e[2]), e[3]), e[4]), e[5]), e[6]), e[7]);
     unsigned bits = 0;
-    if (wave_any(em >= SAMPLE_KEY_TH)) {
+    if (wave_any(!dc_only && (emin < SAMPLE_KEY_LO || emax >= SAMPLE_KEY_HI))) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) bits |= (e[k] >= SAMPLE_KEY_TH ? 1u : 0u) << k;
+        for (int k = 0; k < 8; ++k) bits |= ((e[k] < SAMPLE_KEY_LO || e[k] >= SAMPLE_KEY_HI) ? 1u : 0u) << k;
         if (dc_only) bits = 0;
     }
     return bits;
@@ -735,8 +731,8 @@ __global__ __launch_bounds__(64 * WPB, GRAY ? JPEZY_DEC_WAVES_GRAY : JPEZY_DEC_W
             uint32_t e[8];
             int mine[8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) mine[k] = sample_of(out[k], e[k]);
-            const unsigned myf = guard_bits8(e, odd ? dc_only_cr : dc_only_cb);
+            for (int k = 0; k < 8; ++k) mine[k] = sample_of(out[k], e[k]) - 128;     // the chroma samples travel as u' = Cb - 128 /
+            const unsigned myf = guard_bits8(e, odd ? dc_only_cr : dc_only_cb);         // v' = Cr - 128 (exact integers: ref :567-568)
             // DPP inside each 16-lane row: banks 0,2 hold even pixel rows (Cb), banks 1,3 odd ones (Cr)
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
@@ -820,8 +816,8 @@ __global__ __launch_bounds__(64 * WPB, GRAY ? JPEZY_DEC_WAVES_GRAY : JPEZY_DEC_W
                     } else if (!GRAY) {
 #pragma unroll
                         for (int k = 0; k < 8; ++k) {
-                            if ((myflags >> (16 + k)) & 1u) Cb[k] = patch[lane * 16 + k];
-                            if ((myflags >> (24 + k)) & 1u) Cr[k] = patch[lane * 16 + 8 + k];
+                            if ((myflags >> (16 + k)) & 1u) Cb[k] = patch[lane * 16 + k] - 128;
+                            if ((myflags >> (24 + k)) & 1u) Cr[k] = patch[lane * 16 + 8 + k] - 128;
                         }
                     }
                 }
@@ -840,7 +836,7 @@ __global__ __launch_bounds__(64 * WPB, GRAY ? JPEZY_DEC_WAVES_GRAY : JPEZY_DEC_W
 #pragma unroll
             for (int cc = 0; cc < 2; ++cc) {
                 const int c = 2 * q + cc;
-                const double up = (double)Cb[c] - 128.0, vp = (double)Cr[c] - 128.0;
+                const double up = (double)Cb[c], vp = (double)Cr[c];       // (sample - 128, subtracted as integers above)
                 const double pr_ = vp * 1.4020, pg1 = up * 0.3441, pg2 = vp * 0.7139, pb_ = up * 1.7718;
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {

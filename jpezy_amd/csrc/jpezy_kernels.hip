@@ -540,7 +540,7 @@ __device__ __forceinline__ int ld_coef(const int16_t* p)
     return v;
 }
 
-// waves per SIMD the register budget is set for (colour: 84 VGPRs since the chroma column pass runs after the luma halves)
+// waves per SIMD the register budget is set for (colour: 87 VGPRs since the chroma column pass runs after the luma halves)
 #ifndef JPEZY_DEC_WAVES
 #define JPEZY_DEC_WAVES 5
 #endif

@@ -143,6 +143,17 @@ void jpezy_ctx_set_force_exact(jpezy_ctx* ctx, int on);
  * rests on: variants 0 and 1 on proven error bounds, variant 2 on a MEASURED model of the undocumented accumulation inside
  * v_mfma_f32_16x16x32_f16 (opt-in for that reason). */
 int jpezy_ctx_set_variant(jpezy_ctx* ctx, int variant);
+/*
+ * Decode tolerance (opt-in; default 0).  BASELINE.json's north_star asks of the decoder "PPM output within +-1 LSB per
+ * channel"; the default kernels deliver more (every byte equal to the reference's truncating FP64 arithmetic,
+ * decoder/jpezy_decoder.hpp:652-676).  With on = 1, jpezy_dequant_idct[_dev] and jpezy_decode_jpeg[_batch] (jpezy's own
+ * 2x2,1x1,1x1 layout) run the LUMA inverse transforms as FP32 butterflies without guard band or exact path: a luma
+ * sample equals the reference's or differs from it by one, chroma samples, colour conversion and clamping stay
+ * bit-exact, so every output byte is within one of the reference's (a unit on Cb would be 1.77 on B: chroma is never
+ * relaxed).  Waves that hold out-of-range coefficients (|c * Q| > 2^15) still take the exact path.  Returns 0 or
+ * JPEZY_E_BADARG.
+ */
+int jpezy_ctx_set_decode_tolerance(jpezy_ctx* ctx, int on);
 /* Synchronises the device and returns how many coefficients/samples were resolved through the
  * exact-order fallback on this context since the previous call (the counter is then reset); -1 on error */
 long jpezy_ctx_last_fallback_count(jpezy_ctx* ctx);

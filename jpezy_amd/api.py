@@ -57,6 +57,7 @@ ABI = [
     ("jpezy_dequant_idct_generic_dev", C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp]),
     ("jpezy_ctx_set_force_exact", None, [_vp, C.c_int]),
     ("jpezy_ctx_set_variant", C.c_int, [_vp, C.c_int]),
+    ("jpezy_ctx_set_decode_tolerance", C.c_int, [_vp, C.c_int]),
     ("jpezy_ctx_last_fallback_count", C.c_long, [_vp]),
     ("jpezy_write_jpeg", C.c_long, [_vp, C.c_int, C.c_int, C.c_int, C.c_char_p, _vp, C.c_size_t]),
     ("jpezy_jpeg_bound", C.c_size_t, [C.c_int, C.c_int]),
@@ -162,6 +163,10 @@ class Context:
 
     def set_variant(self, variant):
         _check(load_library().jpezy_ctx_set_variant(self._h, int(variant)))
+
+    def set_decode_tolerance(self, on):
+        """0: bit-exact decode (default); 1: luma in FP32, every output byte within one of the reference's."""
+        _check(load_library().jpezy_ctx_set_decode_tolerance(self._h, int(on)))
 
     def fallback_count(self):
         return load_library().jpezy_ctx_last_fallback_count(self._h)

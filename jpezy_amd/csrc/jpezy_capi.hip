@@ -98,6 +98,8 @@ struct jpezy_ctx {
     unsigned long long* d_counter = nullptr;
     double* d_dqscale = nullptr;   // [3][8][8]
     int* d_dqt = nullptr;          // [3][64]
+    float* d_dqscale_f = nullptr;  // [8][8] luma constants in FP32 (decode tolerance mode)
+    int dec_tolerance = 0;         // 0 = bit-exact decode (default), 1 = luma in FP32, output within one of the reference per channel
     uint16_t dq_cache[3][64];
     int coef_limit = 0;
     bool dq_valid = false;
@@ -268,6 +270,7 @@ jpezy_ctx* jpezy_ctx_create(int device)
     ok = ok && hipMalloc((void**)&c->d_counter, sizeof(unsigned long long) * COUNTER_SHARDS) == hipSuccess;
     ok = ok && hipMalloc((void**)&c->d_dqscale, sizeof(double) * 3 * 64) == hipSuccess;
     ok = ok && hipMalloc((void**)&c->d_dqt, sizeof(int) * 3 * 64) == hipSuccess;
+    ok = ok && hipMalloc((void**)&c->d_dqscale_f, sizeof(float) * 64) == hipSuccess;
     ok = ok && hipMemcpy(c->d_tab, &h, sizeof h, hipMemcpyHostToDevice) == hipSuccess;
     ok = ok && hipMemset(c->d_counter, 0, sizeof(unsigned long long) * COUNTER_SHARDS) == hipSuccess;
     if (!ok) {
@@ -289,6 +292,7 @@ void jpezy_ctx_destroy(jpezy_ctx* c)
     if (c->d_counter) (void)hipFree(c->d_counter);
     if (c->d_dqscale) (void)hipFree(c->d_dqscale);
     if (c->d_dqt) (void)hipFree(c->d_dqt);
+    if (c->d_dqscale_f) (void)hipFree(c->d_dqscale_f);
     for (auto& b : c->in) b.release();
     c->out.release();
     c->scratch.release();
@@ -313,6 +317,14 @@ void* jpezy_ctx_stream(const jpezy_ctx* c) { return c ? (void*)c->stream : nullp
 void jpezy_ctx_set_force_exact(jpezy_ctx* c, int on)
 {
     if (c) c->force_exact = on < 0 ? 0 : on > 3 ? 3 : on;
+}
+
+int jpezy_ctx_set_decode_tolerance(jpezy_ctx* c, int on)
+{
+    if (!c) return set_err(JPEZY_E_BADARG, "null context");
+    if (on != 0 && on != 1) return set_err(JPEZY_E_BADARG, "decode tolerance: 0 (bit-exact) or 1 (within one per channel)");
+    c->dec_tolerance = on;
+    return JPEZY_OK;
 }
 
 int jpezy_ctx_set_variant(jpezy_ctx* c, int variant)
@@ -458,7 +470,11 @@ static int upload_dequant(jpezy_ctx* c, const uint16_t qt[4][64], const uint8_t 
                 h_scale[k][u][v] = cu * cv * (double)sel[k][v * 8 + u] * 0.25;
                 h_qt[k][v * 8 + u] = sel[k][v * 8 + u];
             }
+    static thread_local float h_scale_f[8][8];
+    for (int u = 0; u < 8; ++u)
+        for (int v = 0; v < 8; ++v) h_scale_f[u][v] = (float)h_scale[0][u][v];
     HIP_TRY(hipMemcpy(c->d_dqscale, h_scale, sizeof h_scale, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->d_dqscale_f, h_scale_f, sizeof h_scale_f, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(c->d_dqt, h_qt, sizeof h_qt, hipMemcpyHostToDevice));
     std::memcpy(c->dq_cache, sel, sizeof sel);
     int qmax = 1;
@@ -486,6 +502,7 @@ int jpezy_dequant_idct_dev(jpezy_ctx* c, const int16_t* d_coeffs, const uint16_t
     p.r = d_r; p.g = d_g; p.b = d_b;
     p.plane_stride = plane_stride;
     p.dqscale = c->d_dqscale;
+    p.dqscale_f = c->d_dqscale_f;
     p.dqt = c->d_dqt;
     p.coef_limit = c->coef_limit;
     p.fallback_count = c->d_counter;
@@ -500,7 +517,7 @@ int jpezy_dequant_idct_dev(jpezy_ctx* c, const int16_t* d_coeffs, const uint16_t
         q.n_frames = n_frames - f0 < kMaxFramesPerLaunch ? n_frames - f0 : kMaxFramesPerLaunch;
         q.coeffs += (size_t)f0 * p.coeffs_per_frame;
         q.r += (size_t)f0 * plane_stride; q.g += (size_t)f0 * plane_stride; q.b += (size_t)f0 * plane_stride;
-        HIP_TRY(launch_dequant_idct(q, gray != 0, c->force_exact != 0, s));
+        HIP_TRY(launch_dequant_idct(q, gray != 0, c->force_exact != 0, c->dec_tolerance != 0, s));
     }
     return JPEZY_OK;
 }

@@ -86,6 +86,7 @@ struct DecParams {
     uint8_t* b;
     size_t plane_stride;
     const double* dqscale;    // [3 comps][8 (u=lane col)][8 (v)] : cu*cv*Q[v*8+u] / 4   (dequant and the final / 4 folded in)
+    const float* dqscale_f;   // [8 (u)][8 (v)]: the luma constants rounded to FP32 (tolerance mode)
     const int* dqt;           // [3 comps][64] natural order quant values (exact path)
     int coef_limit;           // 32768 / largest quantiser: raw coefficients above it send the wave to the exact path
     unsigned long long* fallback_count;
@@ -111,7 +112,8 @@ hipError_t launch_fdct_quant(const EncParams& p, bool gray, bool force_exact, hi
 hipError_t launch_fdct_quant_f32(const EncParams& p, bool gray, int force, hipStream_t stream);
 // variant 2: variant 1 with the luma transforms on the matrix pipe (opt-in: measured error model, jpezy_kernels_f32.hip)
 hipError_t launch_fdct_quant_mfma(const EncParams& p, bool gray, int force, hipStream_t stream);
-hipError_t launch_dequant_idct(const DecParams& p, bool gray, bool force_exact, hipStream_t stream);
+// tolerant: luma in FP32 without guard band (samples within one of the reference's, jpezy_kernels.hip); chroma stays exact
+hipError_t launch_dequant_idct(const DecParams& p, bool gray, bool force_exact, bool tolerant, hipStream_t stream);
 
 // any-layout decode (jpezy_kernels_generic.hip)
 struct GenericDecParams {

@@ -394,7 +394,14 @@ __global__ __launch_bounds__(256) void tile_bases_kernel(const uint32_t* tile_to
     }
 }
 
-constexpr int ASM_WIN = 96;             // tiles a workgroup's 131072 bits can touch: a tile holds at least 256 x 6 bits
+// Tiles a workgroup's ASM_BITS can touch.  The shortest block is a flat chroma block (DC category 0: 2 bits, EOB: 2 bits -- also
+// every zero chroma block of gray mode), a flat luma block takes 2 + 4, so a flat MCU is 32 bits and 256 consecutive blocks
+// hold at least 42 MCUs + the cheapest four consecutive blocks (4 + 4 + 6 + 6) = 1364 bits: a piece that starts inside a tile
+// touches at most ASM_BITS / 1364 + 2 = 98 tiles (only a frame's LAST tile may be shorter, and nothing follows it).
+// (Round 2 assumed 256 x 6 bits and a window of 96: flat frames of more than 2048 tiles lost the last chunks of a piece.)
+constexpr unsigned MIN_TILE_BITS = 42u * 32u + 20u;
+constexpr int ASM_WIN = 128;
+static_assert((unsigned)(ASM_WIN - 2) * MIN_TILE_BITS >= ASM_BITS, "assemble window too small for flat content");
 constexpr unsigned ASM_SELF_TILES = 2048;   // frames of up to this many tiles: every assembling workgroup scans the totals itself
 
 // the 64 bytes of U that start at frame bit p: tile A (bits [bA, eA) of the frame, stream srcA) holds p; tile B (LB bits,

@@ -221,3 +221,27 @@ def test_frame_of_more_than_2048_tiles(J, ctx):
     ctx.write_jpeg_gpu_dev(_dev(g2).reshape(2, -1), W, H, out2, sizes2, n_frames=2, gray=True)       # and the flags were left clear
     torch.cuda.synchronize()
     assert [int(v) for v in sizes2] == [len(want)] * 2 and out2[1, :len(want)].cpu().numpy().tobytes() == want
+
+
+@pytest.mark.parametrize("size", [(4736, 4736), (7680, 4320)])
+def test_flat_frames_of_more_than_2048_tiles(J, ctx, size):
+    """Flat content is the shortest stream a tile can have (a flat MCU is 32 bits: 1,364 bits per 256 blocks), so one 16 KB
+    piece of the unstuffed stream touches up to 98 tiles: the window of tile offsets assemble_kernel<false> loads must cover
+    them (round 2's window of 96 silently zeroed the last chunks of a piece).  Flat black, and flat with a non-zero first DC
+    and noise in the first MCU (the tile grid then sits off the piece grid), colour and gray, against the host writer."""
+    W, H = size
+    mc, mr = J.mcu_grid(W, H)
+    assert -(-mc * mr * 6 // 256) > 2048
+    rng = np.random.default_rng(W)
+    for variant in range(3):
+        co = np.zeros((mr, mc, 6, 64), np.int16)
+        if variant >= 1:
+            co[0, 0, :, 0] = (-700, 3, 90, -5, 200, -200)[:6]
+            co[0, 0, :, 1:] = rng.integers(-30, 31, (6, 63))
+        if variant == 2:                                      # a second disturbance further down the frame
+            co[mr // 2, mc // 3] = rng.integers(-1023, 1024, (6, 64))
+        for gray in (False, True):
+            c = np.ascontiguousarray(co[:, :, :4]) if gray else co
+            want = J.write_jpeg(c, W, H, gray)
+            got = ctx.write_jpeg_gpu(_dev(c), W, H, gray=gray)[0]
+            assert len(got) == len(want) and got == want, (variant, gray)

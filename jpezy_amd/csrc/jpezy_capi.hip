@@ -101,7 +101,8 @@ struct jpezy_ctx {
     float* d_dqscale_f = nullptr;  // [8][8] luma constants in FP32 (decode tolerance mode)
     int dec_tolerance = 0;         // 0 = bit-exact decode (default), 1 = luma in FP32, output within one of the reference per channel
     uint16_t dq_cache[3][64];
-    int coef_limit = 0;
+    int coef_limit = 0;            // 2^15 / largest quantiser: the generic kernels and the tolerance mode of the fused kernel
+    int coef_limit_exact = 0;      // 2^23 / largest quantiser: the fused kernel's exact mode (error 2e-7 against a guard band of 3.8e-6)
     bool dq_valid = false;
     int force_exact = 0;           // 0 normal, 1 everything through the reference-order path, 2 (f32 variant) through level 2,
                                    // 3 (f32 variant) through the per-lane evaluator of the queue-overflow case
@@ -481,6 +482,10 @@ static int upload_dequant(jpezy_ctx* c, const uint16_t qt[4][64], const uint8_t 
     for (int k = 0; k < 3; ++k)
         for (int i = 0; i < 64; ++i) qmax = sel[k][i] > qmax ? sel[k][i] : qmax;
     c->coef_limit = 32768 / qmax;
+    // Fused kernel, exact mode: with |c * Q| <= 2^23 every dequantised input is below 2^21, the two FP64 butterfly passes err by
+    // at most (8 * 6 * 8 + 6 * 64) * 2^21 * 2^-53 = 1.8e-7 -- a twentieth of the 2^-18 guard band.  Every 8-bit quantiser table
+    // gives a limit >= 32768: no int16 coefficient can exceed it and the kernel without the range test is launched.
+    c->coef_limit_exact = (1 << 23) / qmax;
     c->dq_valid = true;
     return JPEZY_OK;
 }
@@ -504,7 +509,7 @@ int jpezy_dequant_idct_dev(jpezy_ctx* c, const int16_t* d_coeffs, const uint16_t
     p.dqscale = c->d_dqscale;
     p.dqscale_f = c->d_dqscale_f;
     p.dqt = c->d_dqt;
-    p.coef_limit = c->coef_limit;
+    p.coef_limit = c->dec_tolerance ? c->coef_limit : c->coef_limit_exact;
     p.fallback_count = c->d_counter;
     p.W = W; p.H = H;
     p.mcu_cols = jpezy_mcu_cols(W);

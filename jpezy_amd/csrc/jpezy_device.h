@@ -88,7 +88,8 @@ struct DecParams {
     const double* dqscale;    // [3 comps][8 (u=lane col)][8 (v)] : cu*cv*Q[v*8+u] / 4   (dequant and the final / 4 folded in)
     const float* dqscale_f;   // [8 (u)][8 (v)]: the luma constants rounded to FP32 (tolerance mode)
     const int* dqt;           // [3 comps][64] natural order quant values (exact path)
-    int coef_limit;           // 32768 / largest quantiser: raw coefficients above it send the wave to the exact path
+    int coef_limit;           // raw coefficients above it send the wave to the exact path: 2^23 / largest quantiser (exact mode;
+                              // >= 32768 = no test needed) or 2^15 / largest quantiser (tolerance mode)
     unsigned long long* fallback_count;
     int W, H, mcu_cols, mcu_rows, quads_per_row, n_frames;
     unsigned qpr_magic, qpr_shift;   // fast_div by quads_per_row (set by the launcher)

@@ -574,9 +574,12 @@ __device__ __forceinline__ int ld_coef(const int16_t* p)
 // for every sample, as the exact kernel does) has |in[u][v]| <= 2^13, so sum |in| <= 2^19 over a block and the FP32 result of the
 // two butterfly passes (at most 13 roundings on any input->output path, dequantiser constants and level shift rounded once
 // each) is within (13 + 2) * 2^-24 * 2^19 = 0.47 < 1 of the exact sample value: the truncated samples differ by at most one.
-template <bool GRAY, bool ALIGNED, bool FORCE_EXACT, bool TOL>
+// MODE: 0 = exact, with the coefficient range test; 1 = exact, no range test (8-bit quantiser tables: see launch_dequant_idct);
+// 2 = tolerance mode (always with the range test: the FP32 bound above needs it)
+template <bool GRAY, bool ALIGNED, bool FORCE_EXACT, int MODE>
 __global__ __launch_bounds__(64 * WPB, GRAY ? JPEZY_DEC_WAVES_GRAY : JPEZY_DEC_WAVES) void dequant_idct_kernel(DecParams p)
 {
+    constexpr bool TOL = MODE == 2, RANGE = MODE != 1;
     __shared__ __attribute__((aligned(16))) uint32_t lds_all[WPB][DEC_LDS_DWORDS];
     constexpr int BPM = 6;
 
@@ -697,15 +700,20 @@ __global__ __launch_bounds__(64 * WPB, GRAY ? JPEZY_DEC_WAVES_GRAY : JPEZY_DEC_W
     const unsigned long long ac_luma = (row >> 3) ? ac_bot : ac_top;                 // this lane's pixel row: top or bottom blocks
     const bool dc_only_l = ((unsigned)ac_luma & colbits) == 0, dc_only_r = ((unsigned)(ac_luma >> 32) & colbits) == 0;
     const bool dc_only_cb = ((unsigned)ac_chr & colbits) == 0, dc_only_cr = ((unsigned)(ac_chr >> 32) & colbits) == 0;
-    // fast path is only trusted for sane magnitudes: |coef| <= coef_limit = 32768 / max quantiser keeps every
-    // dequantised input below 2^15 (error bound); wave-uniform decision
-    const bool force = FORCE_EXACT || wave_any(max(cmx, -cmn) > p.coef_limit);
+    // fast path is only trusted for sane magnitudes (jpezy_capi.hip upload_dequant): |coef| <= coef_limit keeps every
+    // dequantised input below 2^21 (exact mode) / 2^13 (tolerance mode); wave-uniform decision
+    // RANGE false (the launcher: coef_limit >= 32768, i.e. every 8-bit quantiser table): no int16 coefficient leaves the trusted
+    // range and the tracking above is dead code
+    const bool force = FORCE_EXACT || (RANGE && wave_any(max(cmx, -cmn) > p.coef_limit));
     wave_sync();   // staging consumed (the exact path re-reads coefficients from global memory)
 
     // ---- 3. transpose in two halves: the lanes holding the LEFT block columns (cq < 8) publish them, every lane
     //         runs the row pass of its 8 left pixels; then the same for the right blocks ----
     int Y[16];
     unsigned yflags = 0;
+#ifdef JPEZY_DEC_INTERLEAVE
+    double gc_early[8];
+#endif
     if constexpr (TOL) {
         // the whole luma tile as floats (pitch 16, MCU stride 264 dwords: the column stores are conflict-free, the 16-byte row
         // reads 2-way -- tools/lds_bank_model.py); one exchange instead of two, no guard keys
@@ -745,6 +753,19 @@ __global__ __launch_bounds__(64 * WPB, GRAY ? JPEZY_DEC_WAVES_GRAY : JPEZY_DEC_W
             }
         }
         wave_sync();
+#ifdef JPEZY_DEC_INTERLEAVE
+        if (!GRAY && half == 0) {
+            const int comp = 1 + (cq >> 3);
+            double cin[8];
+#pragma unroll
+            for (int v = 0; v < 8; ++v) {
+                const int cv_ = (int)(short)(cpk[v >> 1] >> ((v & 1) * 16));
+                cin[v] = (double)cv_ * p.dqscale[(comp * 8 + u) * 8 + v];
+            }
+            if (u == 0) cin[0] = (JPEZY_S * JPEZY_S) * (double)((int)(short)(cpk[0] & 0xFFFFu) * p.dqt[comp * 64]) * 0.25;
+            idct8(cin, gc_early);
+        }
+#endif
         {
             double in[8], out[8];
             const double2* src = reinterpret_cast<const double2*>(lds + m * DH_MCU + row * DH_PITCH);
@@ -765,6 +786,12 @@ __global__ __launch_bounds__(64 * WPB, GRAY ? JPEZY_DEC_WAVES_GRAY : JPEZY_DEC_W
     if (!GRAY) {
         {
             double gc[8];
+#ifdef JPEZY_DEC_INTERLEAVE
+            if (!TOL) {
+#pragma unroll
+                for (int y = 0; y < 8; ++y) gc[y] = gc_early[y];
+            } else
+#endif
             {
                 const int comp = 1 + (cq >> 3);
                 double cin[8];
@@ -988,11 +1015,13 @@ template <bool GRAY, bool ALIGNED>
 static void dec_launch2(const DecParams& p, bool force, bool tol, dim3 grid, hipStream_t s)
 {
     if (force)           // every sample through the reference-order path: the tolerance switch has nothing left to relax
-        hipLaunchKernelGGL((dequant_idct_kernel<GRAY, ALIGNED, true, false>), grid, dim3(64 * WPB), 0, s, p);
+        hipLaunchKernelGGL((dequant_idct_kernel<GRAY, ALIGNED, true, 0>), grid, dim3(64 * WPB), 0, s, p);
     else if (tol)
-        hipLaunchKernelGGL((dequant_idct_kernel<GRAY, ALIGNED, false, true>), grid, dim3(64 * WPB), 0, s, p);
+        hipLaunchKernelGGL((dequant_idct_kernel<GRAY, ALIGNED, false, 2>), grid, dim3(64 * WPB), 0, s, p);
+    else if (p.coef_limit >= 32768)      // no int16 coefficient can exceed it: the kernel without the range test
+        hipLaunchKernelGGL((dequant_idct_kernel<GRAY, ALIGNED, false, 1>), grid, dim3(64 * WPB), 0, s, p);
     else
-        hipLaunchKernelGGL((dequant_idct_kernel<GRAY, ALIGNED, false, false>), grid, dim3(64 * WPB), 0, s, p);
+        hipLaunchKernelGGL((dequant_idct_kernel<GRAY, ALIGNED, false, 0>), grid, dim3(64 * WPB), 0, s, p);
 }
 
 hipError_t launch_dequant_idct(const DecParams& p0, bool gray, bool force_exact, bool tolerant, hipStream_t stream)

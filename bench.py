@@ -319,9 +319,41 @@ def run_batch(args, torch, dist, J, ctx, dev, rank, world, multi, comm_cpu):
     else:
         t_e2e = t_kernel                    # one GPU: nothing to gather, the consumer already holds the batch
 
-    # (4) the same pipeline on ONE GPU, in the same job (rank 0 alone; the others wait), and the parity property of the
-    #     sharded path: the gathered batch equals the single-GPU batch bit for bit
+    # (3b) the pipeline that is not capped by the consumer's xGMI links: encoder::encode END TO END on every rank (FDCT+quant,
+    #      then the GPU Huffman stage: ref encoder/jpezy_encoder.hpp:38-77) and only the finished .jpg files gathered
+    jstride = args.batch_jpg_stride
+    jring = 3
+    jbuf = [torch.empty((chunk, jstride), dtype=torch.uint8, device=dev) for _ in range(jring)]
+    jsz = [torch.zeros(chunk, dtype=torch.int64, device=dev) for _ in range(jring)]
+    jco = torch.empty((chunk, cpf), dtype=torch.int16, device=dev)
+    meta = dist.new_group(backend="gloo") if (multi and not comm_cpu) else None      # the sizes travel host to host
+
+    def jpg_chunk_from(pr_, pg_, pb_, base):
+        def fn(a, b, slot):
+            n = b - a
+            kernels(a, b, pr_, pg_, pb_, base, jco[:n])
+            ctx.write_jpeg_gpu_dev(jco[:n], W, H, jbuf[slot][:n], jsz[slot][:n], n_frames=n,
+                                   stream=torch.cuda.current_stream(dev).cuda_stream)
+            if comm_cpu:
+                torch.cuda.synchronize(dev)
+                return jbuf[slot][:n].cpu(), jsz[slot][:n].cpu()
+            return jbuf[slot][:n], jsz[slot][:n]
+        return fn
+
+    jpg_res = [None]
+
+    def e2e_jpg_pass():
+        jpg_res[0] = sharding.gather_jpg_to_root_pipelined(jpg_chunk_from(pr, pg, pb, lo), F, chunk, comm_dev, root=0,
+                                                           meta_group=meta, ring=jring)
+    e2e_jpg_pass()                           # first use: entropy scratch, header cache, point-to-point connections
+    t_e2e_jpg = timed(e2e_jpg_pass)
+
+    # (4) the same pipelines on ONE GPU, in the same job (rank 0 alone; the others wait), and the parity property of the
+    #     sharded paths: the gathered batch equals the single-GPU batch bit for bit
     t_one, same = None, None
+    t_one_jpg, same_jpg, jpg_total = None, None, None
+    if rank == 0 and not multi:
+        t_one_jpg, jpg_total = t_e2e_jpg, jpg_res[0].total_bytes()
     if multi:
         if rank == 0:
             fr, fg, fb = synth_frames(torch, 0, F, plane, dev)
@@ -340,7 +372,23 @@ def run_batch(args, torch, dist, J, ctx, dev, rank, world, multi, comm_cpu):
                 ts.append(time.perf_counter() - t0)
             t_one = statistics.median(ts)
             same = bool(torch.equal(out.to(dev) if comm_cpu else out, full))
-            del fr, fg, fb, full
+            del full
+            solo = [None]
+
+            def one_jpg_pass():
+                solo[0] = sharding.gather_jpg_to_root_pipelined(jpg_chunk_from(fr, fg, fb, 0), F, chunk, comm_dev, ring=jring, solo=True)
+            one_jpg_pass()
+            ts = []
+            for _ in range(3):
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                one_jpg_pass()
+                torch.cuda.synchronize(dev)
+                ts.append(time.perf_counter() - t0)
+            t_one_jpg = statistics.median(ts)
+            same_jpg = bool(jpg_res[0].equals(solo[0]))
+            jpg_total = solo[0].total_bytes()
+            del fr, fg, fb, solo
         dist.barrier()
     else:
         t_one = t_kernel
@@ -360,6 +408,14 @@ def run_batch(args, torch, dist, J, ctx, dev, rank, world, multi, comm_cpu):
                                   "note": "all frames on rank 0's GPU, same chunking, measured in this job"},
         "speedup_kernel_only": round(t_one / t_kernel, 3),
         "speedup_end_to_end": round(t_one / t_e2e, 3),
+        "end_to_end_jpg": {"ms": round(t_e2e_jpg * 1e3, 3), "Mpixels_per_s": round(px / t_e2e_jpg / 1e6, 1),
+                           "jpg_bytes": jpg_total, "out_stride": jstride,
+                           "note": "encoder::encode end to end on every rank (FDCT+quant, then the GPU Huffman stage); only the "
+                                   "finished .jpg files travel to rank 0 (sizes host to host, files packed per chunk, overlapped with "
+                                   "the next chunk's kernels)"},
+        "one_gpu_same_pipeline_jpg": {"ms": round(t_one_jpg * 1e3, 3), "Mpixels_per_s": round(px / t_one_jpg / 1e6, 1),
+                                      "note": "all frames on rank 0's GPU through the same chunked FDCT + Huffman + packing pipeline"},
+        "speedup_end_to_end_jpg": round(t_one_jpg / t_e2e_jpg, 3),
     }
     if multi:
         res["gather"] = {"op": "point-to-point sends to rank 0 (batch_isend_irecv), chunks of the finished local buffers",
@@ -368,6 +424,9 @@ def run_batch(args, torch, dist, J, ctx, dev, rank, world, multi, comm_cpu):
         hidden = t_kernel + t_gather - t_e2e
         res["overlap_efficiency"] = round(max(0.0, min(1.0, hidden / max(min(t_kernel, t_gather), 1e-12))), 3)
         res["gathered_equals_one_gpu_result"] = same
+        res["gathered_jpg_equals_one_gpu_result"] = same_jpg
+        own = int(jpg_res[0].sizes[slice(*sharding.shard_range(F, world, 0))].sum())
+        res["end_to_end_jpg"]["bytes_into_rank0"] = jpg_total - own
         if comm_cpu:
             res["rehearsal"] = "all ranks on GPU 0, gloo + host staging: control flow only, the numbers mean nothing"
     return res
@@ -747,7 +806,7 @@ def run_rank(args):
             out["decode_tolerant"] = dec_tol
         if batch:
             out["batch"] = batch
-        if world == 1 and not args.no_cpu:
+        if not args.no_cpu:          # rank 0 only, after every timed region (the other ranks idle at the closing barrier)
             out["cpu_baseline"] = cpu_baseline(W, H, gray, direction)
         print(json.dumps(out), flush=True)
 
@@ -774,6 +833,9 @@ def parse_args(argv=None):
     ap.add_argument("--batch-frames", type=int, default=None,
                     help=f"frames of the configs[3] batch (default {BATCH_FRAMES}; 16 in --rehearse-on-one-gpu)")
     ap.add_argument("--batch-chunk", type=int, default=64, help="frames per launch / per transfer of the batch pipeline")
+    ap.add_argument("--batch-jpg-stride", type=int, default=2 << 20,
+                    help="bytes reserved per frame in the .jpg staging buffers of the batch pipeline (a 1920x1080 random-pixel "
+                         "frame codes to ~0.66 MB; a frame that does not fit is reported, never truncated)")
     ap.add_argument("--dist-timeout", type=int, default=300, help="seconds after which a hanging collective raises (N > 1)")
     ap.add_argument("--streams", type=int, default=1,
                     help="frames in flight: step i is launched on stream i %% S (forked from and joined to the timed stream "

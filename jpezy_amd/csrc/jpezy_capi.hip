@@ -379,6 +379,10 @@ int jpezy_fdct_quant_dev(jpezy_ctx* c, const uint8_t* d_r, const uint8_t* d_g, c
     if (!c->d_trace) HIP_TRY(hipMalloc((void**)&c->d_trace, sizeof(unsigned long long) * 4 * 65536));
     p.trace = c->d_trace;
 #endif
+#ifdef JPEZY_DEFER_PROBE
+    if (int rc = c->dump_t.reserve((size_t)64 * 4096 * 8)) return rc;
+    p.defer_list = c->dump_t.p;
+#endif
 #ifdef JPEZY_DUMP_T
     if (int rc = c->dump_t.reserve(p.coeffs_per_frame * (size_t)n_frames * sizeof(float))) return rc;
     HIP_TRY(hipMemsetAsync(c->dump_t.p, 0, p.coeffs_per_frame * (size_t)n_frames * sizeof(float), s));
@@ -692,11 +696,22 @@ int ensure_code_tables(jpezy_ctx* c)
     uint16_t code[4][256];
     uint8_t len[4][256];
     jpezy_host::enc_code_tables(code, len);
-    jpezy_dev::entropy::CodeTables h;
+    std::vector<jpezy_dev::entropy::CodeTables> hv(1);       // 10 KB: off the stack
+    jpezy_dev::entropy::CodeTables& h = hv[0];
     std::memset(&h, 0, sizeof h);
     for (int t = 0; t < 2; ++t) {      // DHT order: YDc, CDc, YAc, CAc
         for (int k = 0; k < 12; ++k) h.dc[t][k] = ((uint32_t)code[t][k] << 8) | len[t][k];
         for (int k = 0; k < 256; ++k) h.ac[t][k] = ((uint32_t)code[2 + t][k] << 8) | len[2 + t][k];
+        for (int run = 0; run < 16; ++run)
+            for (int v = -32; v < 32; ++v) {
+                if (v == 0) continue;
+                const int a = v < 0 ? -v : v;
+                int sz = 0;
+                while ((a >> sz) != 0) ++sz;
+                const int k = (run << 4) | sz;
+                const uint32_t bits = ((uint32_t)code[2 + t][k] << sz) | ((uint32_t)(v + (v >> 31)) & ((1u << sz) - 1u));
+                h.fast[t][(run << 6) | (v + 32)] = (bits << 5) | (uint32_t)(len[2 + t][k] + sz);
+            }
     }
     HIP_TRY(hipMalloc((void**)&c->d_codes, sizeof h));
     HIP_TRY(hipMemcpy(c->d_codes, &h, sizeof h, hipMemcpyHostToDevice));

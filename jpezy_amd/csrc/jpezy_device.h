@@ -72,6 +72,9 @@ struct EncParams {
 #ifdef JPEZY_TRACE
     unsigned long long* trace;       // development builds only (tools/wave_trace.py): 4 words per wave
 #endif
+#ifdef JPEZY_DEFER_PROBE
+    void* defer_list;                // timing probe only (jpezy_kernels_f32.hip)
+#endif
 #ifdef JPEZY_DUMP_T
     float* dump_t;                   // development builds only (tools/check_level1_bound.py): the f32 kernel's level-1
                                      // t = F * ks of every coefficient, coefficient-buffer layout, NATURAL order in a block

@@ -8,9 +8,13 @@ namespace jpezy_dev {
 namespace entropy {
 
 // entry = (code << 8) | length in bits;  dc[t][category 0..11], ac[t][(run << 4) | size]   (t: 0 luma, 1 chroma)
-struct CodeTables {
+// fast[t][(run << 6) | (v + 32)], run 0..15, v -32..31 (v != 0): the AC code of (run, size(v)) with the value bits already
+// appended, (bits << 5) | total length (at most 16 + 6 bits) -- one lookup and one append per coefficient instead of
+// category -> code lookup -> sign fix -> two appends (round 3; larger values and runs over 15 keep the general path)
+struct alignas(16) CodeTables {
     uint32_t dc[2][16];
     uint32_t ac[2][256];
+    uint32_t fast[2][1024];
 };
 
 struct Job {

@@ -28,17 +28,23 @@ namespace jpezy_dev {
 namespace entropy {
 
 // code tables: entry = (code << 8) | length; dc[t][category], ac[t][(run << 4) | size]   (t: 0 luma, 1 chroma)
-struct LdsTables {
+struct alignas(16) LdsTables {
     uint32_t dc[2][16];
     uint32_t ac[2][256];
+#ifdef JPEZY_ENT_NOFAST
+    uint32_t fast[2][4];
+#else
+    uint32_t fast[2][1024];         // CodeTables::fast
+#endif
 };
+static_assert(sizeof(LdsTables) <= sizeof(CodeTables) && sizeof(LdsTables) % 16 == 0, "table images must match");
 
 // (no barrier: the caller's own barrier after staging its tile covers the tables)
 __device__ __forceinline__ void load_tables(LdsTables& L, const CodeTables* T)
 {
-    const uint32_t* src = reinterpret_cast<const uint32_t*>(T);
-    uint32_t* dst = reinterpret_cast<uint32_t*>(&L);
-    for (unsigned i = threadIdx.x; i < sizeof(LdsTables) / 4; i += blockDim.x) dst[i] = src[i];
+    const uint4* src = reinterpret_cast<const uint4*>(T);
+    uint4* dst = reinterpret_cast<uint4*>(&L);
+    for (unsigned i = threadIdx.x; i < sizeof(LdsTables) / 16; i += blockDim.x) dst[i] = src[i];
 }
 
 // exclusive prefix sum of one value per thread over a 256-thread workgroup; *total = the workgroup's sum (all threads)
@@ -78,12 +84,9 @@ __device__ __forceinline__ uint32_t wg256_exclusive_scan(uint32_t v, uint32_t* t
 // loop (the length from the writer's cursor, the range check from a running maximum) is not tracked inside it.
 // AC coefficients whose positions are the set bits of m (bit 31 - k: position base + k), in order.
 template <class W>
-__device__ __forceinline__ void code_ac(uint32_t m, int base, const int16_t* z, int& prev, const uint32_t* ac, uint32_t zrl, W& w,
-                                        unsigned& amax)
+__device__ __forceinline__ void code_ac(uint32_t m, int base, const int16_t* z, int& prev, const uint32_t* ac, const uint32_t* fast,
+                                        uint32_t zrl, W& w, unsigned& amax)
 {
-#if defined(JPEZY_ENT_ABL) && JPEZY_ENT_ABL == 2
-    m = 0;
-#endif
     int lz = __builtin_clz(m | 1u);
     int vnext = z[base + lz];
 #pragma unroll 1
@@ -95,22 +98,39 @@ __device__ __forceinline__ void code_ac(uint32_t m, int base, const int16_t* z, 
         w.read_up_to(n);                         // (the in-place writer's licence: positions up to n are dead)
         int run = n - prev - 1;
         prev = n;
-        const unsigned a = (unsigned)(v < 0 ? -v : v);
-        amax = a > amax ? a : amax;
-        int sz = 32 - __builtin_clz(a);
-        sz = sz > 10 ? 10 : sz;
-        if (run > 15) {                          // ZRL codes in front of this coefficient (ref :198-206)
-            for (int r = run >> 4; r > 0; --r) w.put(zrl >> 8, (int)(zrl & 0xFF));
-            run &= 15;
+        // Round 3: the code of (run, size(v)) with the value bits appended comes ready-made out of ONE table, for |v| < 32 and
+        // runs up to 15 -- every lane looks it up unconditionally (an index outside the table reads some other LDS word or, beyond
+        // the workgroup's allocation, zero: never used) and appends once.  Larger values and runs over 15 (ZRL) are rare on
+        // dense content: the wave enters the general path only when one of its lanes needs it (a wave-uniform branch; the
+        // branchy form -- fast path or general path per lane -- issued more instructions than the code it replaced).
+        const unsigned v32 = (unsigned)(v + 32);
+        uint32_t e = fast[((unsigned)run << 6) + v32];
+#ifdef JPEZY_ENT_NOFAST
+        const bool slow = true;
+#else
+        const bool slow = v32 > 63u || run > 15;
+#endif
+        {
+            if (slow) {       // (a divergent branch is skipped by the whole wave when no lane takes it: s_cbranch_execz)
+                const unsigned a = (unsigned)(v < 0 ? -v : v);
+                amax = a > amax ? a : amax;
+                int sz = 32 - __builtin_clz(a);
+                sz = sz > 10 ? 10 : sz;
+                if (run > 15) {                          // ZRL codes in front of this coefficient (ref :198-206)
+                    for (int r = run >> 4; r > 0; --r) w.put(zrl >> 8, (int)(zrl & 0xFF));
+                    run &= 15;
+                }
+                const uint32_t g = ac[(run << 4) | sz];
+                // code and value bits: at most 16 + 10 bits, and 5 bits of length
+                e = ((((g >> 8) << sz) | ((uint32_t)(v + (v >> 31)) & ((1u << sz) - 1u))) << 5) | ((g & 0xFF) + (uint32_t)sz);
+            }
         }
-        const uint32_t e = ac[(run << 4) | sz];
-        // code and value bits in one append: at most 16 + 10 bits
-        w.put(((e >> 8) << sz) | ((uint32_t)(v + (v >> 31)) & ((1u << sz) - 1u)), (int)(e & 0xFF) + sz);
+        w.put(e >> 5, (int)(e & 31u));
     }
 }
 
 template <class W>
-__device__ __forceinline__ bool code_block(const int16_t* z, int pred, const uint32_t* dc, const uint32_t* ac, W& w)
+__device__ __forceinline__ bool code_block(const int16_t* z, int pred, const uint32_t* dc, const uint32_t* ac, const uint32_t* fast, W& w)
 {
     unsigned amax = 0;
     bool ok = true;
@@ -145,8 +165,8 @@ __device__ __forceinline__ bool code_block(const int16_t* z, int pred, const uin
     int prev = 0;                        // position of the previous non-zero coefficient (0: the DC)
     if (z) {
         const uint32_t zrl = ac[0xF0];
-        code_ac(mhi, 0, z, prev, ac, zrl, w, amax);
-        code_ac(mlo, 32, z, prev, ac, zrl, w, amax);
+        code_ac(mhi, 0, z, prev, ac, fast, zrl, w, amax);
+        code_ac(mlo, 32, z, prev, ac, fast, zrl, w, amax);
     }
     w.read_up_to(63);
     if (prev != 63) {                    // the block ends in zeros (or has no AC coefficient at all): EOB
@@ -184,39 +204,41 @@ constexpr int ROW = 144, ROW_DATA = 16, ROW_LAST_WORD = 34;      // private stre
 constexpr unsigned TILE_STREAM_WORDS = 256 * 208 / 4;            // worst case of 208 bytes per block
 
 struct RowWriter {
-    unsigned long long acc;
-    int nacc, wj, limit, stored;
-    uint32_t* row;
+    unsigned long long acc;         // the youngest bit is bit 0; nacc < 32 valid bits between two appends
+    int nacc, wj2, npos;            // wj2 = 2 * (words stored or skipped) - 6; npos = position of the coefficient being coded
+    unsigned long long bad;         // wave mask (scalar registers): lanes with a due word beyond the licence (or beyond the row) --
+                                    // their blocks are re-coded (DirectWriter)
+    char* row12;                    // the row's base + 12: word (wj2 + 6) / 2 sits at row12 + 2 * wj2
     __device__ __forceinline__ void init(uint32_t* r)
     {
-        row = r; acc = 0; nacc = 0; wj = 0; stored = 0;
-        limit = 3;                       // bytes 0..15 are free from the start
+        row12 = reinterpret_cast<char*>(r) + 12; acc = 0; nacc = 0; bad = 0;
+        wj2 = -6; npos = 0;             // bytes 0..15 (words 0..3) are free from the start: 2 * 3 - 6 <= 0
     }
-    // positions up to n have been read (n itself is counted as unread: one add and one shift, no clamp -- n <= 63 gives 34):
-    // word j (bytes 4j..4j+3) covers coefficients below 2j - 6
-    __device__ __forceinline__ void read_up_to(int n) { limit = (n + 6) >> 1; }
+    // positions below n have been read (n itself counts as unread).  Word j (bytes 4j..4j+3) covers coefficients below 2j - 6,
+    // so it may be written while 2j - 6 <= n: the licence test compares two registers the loop has anyway (round 2 formed
+    // limit = (n + 6) >> 1 per coefficient); n <= 63 gives word 34, the last one of the row's stream
+    __device__ __forceinline__ void read_up_to(int n) { npos = n; }
     // one predicated store; everything else is arithmetic (nested branches here cost more than the coding itself)
     __device__ __forceinline__ void word(uint32_t v, bool due)
     {
-        const bool ok = due && wj <= limit;
-        if (ok) row[wj] = v;
-        stored += (int)ok;
-        wj += (int)due;
+        const unsigned long long dm = __builtin_amdgcn_ballot_w64(due), lm = __builtin_amdgcn_ballot_w64(wj2 <= npos);
+        if (due && wj2 <= npos) *reinterpret_cast<uint32_t*>(row12 + 2 * wj2) = v;
+        bad |= dm & ~lm;
+        wj2 += due ? 2 : 0;
     }
-    __device__ __forceinline__ void put(uint32_t bits, int n)   // n <= 26
+    __device__ __forceinline__ void put(uint32_t bits, int n)   // n <= 31
     {
         acc = (acc << n) | bits;
-        nacc += n;
-        const bool due = nacc >= 32;
-        nacc -= due ? 32 : 0;
-        word((uint32_t)(acc >> nacc), due);
+        const int t = nacc + n;          // < 64
+        nacc = t & 31;
+        word((uint32_t)(acc >> nacc), t >= 32);
     }
-    __device__ __forceinline__ unsigned bits() const { return 32u * (unsigned)wj + (unsigned)nacc; }   // before finish()
+    __device__ __forceinline__ unsigned bits() const { return 16u * (unsigned)(wj2 + 6) + (unsigned)nacc; }   // before finish()
     __device__ __forceinline__ void finish()
     {
         word((uint32_t)(acc << (32 - nacc)), nacc > 0);          // left aligned, zero padded (nacc < 32)
     }
-    __device__ __forceinline__ bool overflowed() const { return stored != wj; }                         // after finish()
+    __device__ __forceinline__ bool overflowed() const { return (bad >> (threadIdx.x & 63u)) & 1ull; }   // after finish()
 };
 
 // second coding pass of the rare block that did not fit its row: bits straight to the tile stream at their final place
@@ -291,7 +313,8 @@ __global__ __launch_bounds__(WG) void code_tiles_kernel(Job job, uint32_t* S, ui
     if (valid) {
         RowWriter w;
         w.init(row);
-        const bool ok = code_block(zg ? reinterpret_cast<const int16_t*>(tile + tid * ROW + ROW_DATA) : nullptr, pred, L.dc[table], L.ac[table], w);
+        const bool ok = code_block(zg ? reinterpret_cast<const int16_t*>(tile + tid * ROW + ROW_DATA) : nullptr, pred, L.dc[table], L.ac[table],
+                                   L.fast[table], w);
         n = w.bits();
         w.finish();
         ovf = w.overflowed();
@@ -329,7 +352,7 @@ __global__ __launch_bounds__(WG) void code_tiles_kernel(Job job, uint32_t* S, ui
     } else {
         DirectWriter w;
         w.init(Sg, o);
-        (void)code_block(zg, pred, L.dc[table], L.ac[table], w);
+        (void)code_block(zg, pred, L.dc[table], L.ac[table], L.fast[table], w);
         if (w.nacc > 0 && !w.skip) {
             tail_word = w.w;
             tail_fill = (unsigned)w.nacc;

@@ -558,6 +558,21 @@ __global__ __launch_bounds__(64 * WPB, JPEZY_F32_WAVES) void fdct_quant_f32_kern
 
     // ---- 5b. levels 2 and 3 for the queued coefficients (FORCE 1/2: every coefficient of the quad) ----
     const unsigned nq = queue[0];
+#ifdef JPEZY_DEFER_PROBE
+    // timing probe of "deferred resolves" (tools/experiments, WRONG RESULTS: nothing resolves the entries): the guard-band hits
+    // of the wave are appended to a global list sharded 64 ways (one returning atomic per wave with hits), levels 2/3 are not run
+    if (FORCE == 0) {
+        if (nq) {
+            unsigned long long* shard = p.fallback_count + 64 + (qidx & 63u) * 8u;          // probe: counters live in the fallback array
+            unsigned base = 0;
+            if (lane == 0) base = (unsigned)atomicAdd(shard, (unsigned long long)nq);
+            base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+            uint2* list = reinterpret_cast<uint2*>(p.defer_list) + (size_t)(qidx & 63u) * 4096u;
+            for (unsigned e = lane; e < nq && e < (unsigned)QUEUE_CAP; e += 64)
+                list[(base + e) & 4095u] = make_uint2(qidx, reinterpret_cast<const unsigned short*>(queue + 1)[e]);
+        }
+    } else
+#endif
     if (FORCE == 3 || (FORCE == 0 && nq > (unsigned)QUEUE_CAP)) {
         // More guard-band hits than the queue holds (adversarial patterns; FORCE 3 exercises it): every lane evaluates
         // the 24 coefficients of its three block columns in the reference's order by itself.  The integer samples go

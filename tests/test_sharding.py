@@ -125,3 +125,84 @@ def test_pipelined_single_rank_no_process_group():
         dst.copy_(torch.arange(lo * cpf, hi * cpf, dtype=torch.int16).reshape(hi - lo, cpf))
     out = sharding.gather_to_root_pipelined(enc, n, cpf, 2, "cpu")
     assert torch.equal(out.reshape(-1), torch.arange(n * cpf, dtype=torch.int16))
+
+
+def _worker_jpg(rank, world, port, n_frames, chunk, use_meta, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import oracle as O
+        meta = dist.new_group(backend="gloo") if use_meta else None
+        stride = 4096
+        stage = [torch.zeros((chunk, stride), dtype=torch.uint8) for _ in range(2)]
+        calls = []
+
+        def size_of(f):                     # frames of different sizes: variable-length files
+            return 16 + 16 * (f % 3), 16 + 16 * (f % 2)
+
+        def encode_chunk(lo, hi, slot):
+            calls.append((lo, hi, slot))
+            my_lo, my_hi = sharding.shard_range(n_frames, world, rank)
+            assert my_lo <= lo < hi <= my_hi and hi - lo <= chunk and 0 <= slot < 2
+            buf, sizes = stage[slot], torch.zeros(hi - lo, dtype=torch.int64)
+            for k, f in enumerate(range(lo, hi)):
+                W, H = size_of(f)
+                jpg = O.encode_jpeg(*O.synth_rgb(W, H, frame=f), W, H, False)
+                buf[k, : len(jpg)] = torch.frombuffer(bytearray(jpg), dtype=torch.uint8)
+                sizes[k] = len(jpg)
+            return buf[: hi - lo], sizes
+
+        res = sharding.gather_jpg_to_root_pipelined(encode_chunk, n_frames, chunk, "cpu", root=0, meta_group=meta, ring=2)
+        if rank == 0:
+            np.save(Path(out_dir) / "sizes.npy", res.sizes.numpy())
+            for f in range(n_frames):
+                np.save(Path(out_dir) / f"jpg_{f}.npy", res.frame(f).numpy())
+            assert res.total_bytes() == int(res.sizes.sum()) and [c[0] for c in res.chunks] == sorted(c[0] for c in res.chunks)
+        else:
+            assert res is None
+        np.save(Path(out_dir) / f"calls_{rank}.npy", np.array(calls, dtype=np.int64).reshape(-1, 3))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_frames,chunk,use_meta", [(2, 7, 2, True), (3, 8, 1, False), (3, 2, 4, True), (2, 5, 3, False)])
+def test_pipelined_jpg_gather_to_root_gloo(tmp_path, world, n_frames, chunk, use_meta):
+    """every rank codes its frames END TO END (the oracle stands in for FDCT + Huffman stage) and only the .jpg files --
+    variable length -- travel to the consumer: uneven shards, ragged last chunks, a rank with no frames, a staging ring
+    shorter than the number of chunks, sizes through a host-side gloo group or through the data group"""
+    port = _free_port()
+    mp.spawn(_worker_jpg, args=(world, port, n_frames, chunk, use_meta, str(tmp_path)), nprocs=world, join=True)
+    from oracle import oracle as O
+    sizes = np.load(tmp_path / "sizes.npy")
+    for f in range(n_frames):
+        W, H = 16 + 16 * (f % 3), 16 + 16 * (f % 2)
+        want = O.encode_jpeg(*O.synth_rgb(W, H, frame=f), W, H, False)
+        assert int(sizes[f]) == len(want)
+        assert np.load(tmp_path / f"jpg_{f}.npy").tobytes() == want, f
+    seen = []
+    for r in range(world):
+        calls = np.load(tmp_path / f"calls_{r}.npy")
+        lo, hi = sharding.shard_range(n_frames, world, r)
+        assert [(int(a), int(b)) for a, b, _ in calls] == sharding.chunk_spans(lo, hi, chunk)
+        assert [int(s) for _, _, s in calls] == [c % 2 for c in range(len(calls))]
+        seen += [f for a, b, _ in calls for f in range(a, b)]
+    assert sorted(seen) == list(range(n_frames))
+
+
+def test_pipelined_jpg_single_rank_no_process_group():
+    def enc(lo, hi, slot):
+        buf = torch.zeros((hi - lo, 16), dtype=torch.uint8)
+        sizes = torch.tensor([1 + (f % 5) for f in range(lo, hi)], dtype=torch.int64)
+        for k, f in enumerate(range(lo, hi)):
+            buf[k, : int(sizes[k])] = f + 1
+        return buf, sizes
+    res = sharding.gather_jpg_to_root_pipelined(enc, 7, 3, "cpu")
+    assert res.sizes.tolist() == [1 + (f % 5) for f in range(7)]
+    for f in range(7):
+        assert res.frame(f).tolist() == [f + 1] * (1 + f % 5)
+
+    def bad(lo, hi, slot):
+        return torch.zeros((hi - lo, 4), dtype=torch.uint8), torch.full((hi - lo,), -6, dtype=torch.int64)
+    with pytest.raises(RuntimeError):
+        sharding.gather_jpg_to_root_pipelined(bad, 2, 2, "cpu")

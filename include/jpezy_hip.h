@@ -82,6 +82,13 @@ size_t jpezy_coeff_count(int W, int H, int gray);   /* int16 elements per frame 
 int jpezy_fdct_quant(jpezy_ctx* ctx, const uint8_t* r, const uint8_t* g, const uint8_t* b, int W, int H,
                      int gray, int n_frames, int16_t* coeffs);
 /*
+ * The host-buffer entry points (jpezy_fdct_quant, jpezy_dequant_idct, jpezy_encode_jpeg) stream: the call is cut into chunks of
+ * about `n` bytes of input (default 4 MiB: MCU-row bands of a large frame, or several small frames) that flow through a ring of
+ * pinned staging buffers -- upload of chunk c + 1, kernel of chunk c and download of chunk c - 1 overlap, PCIe runs in both
+ * directions at once and the device footprint is the ring, not the batch (host path).  Tuning / test knob.
+ */
+void jpezy_ctx_set_host_chunk_bytes(jpezy_ctx* ctx, size_t n);
+/*
  * jpezy_fdct_quant_dev: same, all pointers are DEVICE pointers; plane_stride = bytes between
  * consecutive frames of one plane (>= W*H); asynchronous on `stream`, a hipStream_t with HIP's own
  * meaning (NULL = the default stream; jpezy_ctx_stream() = the context's private stream).  Used by

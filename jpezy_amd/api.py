@@ -58,6 +58,7 @@ ABI = [
     ("jpezy_ctx_set_force_exact", None, [_vp, C.c_int]),
     ("jpezy_ctx_set_variant", C.c_int, [_vp, C.c_int]),
     ("jpezy_ctx_set_decode_tolerance", C.c_int, [_vp, C.c_int]),
+    ("jpezy_ctx_set_host_chunk_bytes", None, [_vp, C.c_size_t]),
     ("jpezy_ctx_last_fallback_count", C.c_long, [_vp]),
     ("jpezy_write_jpeg", C.c_long, [_vp, C.c_int, C.c_int, C.c_int, C.c_char_p, _vp, C.c_size_t]),
     ("jpezy_jpeg_bound", C.c_size_t, [C.c_int, C.c_int]),
@@ -167,6 +168,10 @@ class Context:
     def set_decode_tolerance(self, on):
         """0: bit-exact decode (default); 1: luma in FP32, every output byte within one of the reference's."""
         _check(load_library().jpezy_ctx_set_decode_tolerance(self._h, int(on)))
+
+    def set_host_chunk_bytes(self, n):
+        """bytes of input per chunk of the streaming host-buffer entry points (default 4 MiB)"""
+        load_library().jpezy_ctx_set_host_chunk_bytes(self._h, int(n))
 
     def fallback_count(self):
         return load_library().jpezy_ctx_last_fallback_count(self._h)

@@ -20,6 +20,7 @@
 #include "jpezy_entropy.h"
 #include "jpezy_huffdec.h"
 #include "jpezy_host_codec.h"
+#include "jpezy_hostpipe.h"
 
 using namespace jpezy_dev;
 
@@ -91,6 +92,31 @@ struct DevBuf {
 
 }  // namespace
 
+namespace {
+
+// Chunks of the streaming host-buffer entry points: MCU-row bands of a frame that is large against the chunk size, otherwise
+// several whole frames.  Chunk k covers frames [f0, f0 + nf) and, in band mode (nf == 1), MCU rows [y0, y1) of frame f0.
+struct HostChunk { int f0, nf, y0, y1; };
+
+std::vector<HostChunk> plan_host_chunks(int W, int H, int n_frames, size_t bytes_per_px, size_t target)
+{
+    std::vector<HostChunk> out;
+    const int mcu_rows = jpezy_mcu_rows(H);
+    const size_t frame_bytes = (size_t)W * H * bytes_per_px;
+    if (frame_bytes > 2 * target) {
+        const size_t row_bytes = (size_t)16 * W * bytes_per_px;
+        const int rows_per = (int)std::max<size_t>(1, target / row_bytes);
+        for (int f = 0; f < n_frames; ++f)
+            for (int y = 0; y < mcu_rows; y += rows_per) out.push_back({ f, 1, y, std::min(y + rows_per, mcu_rows) });
+    } else {
+        const int per = (int)std::max<size_t>(1, target / std::max<size_t>(frame_bytes, 1));
+        for (int f = 0; f < n_frames; f += per) out.push_back({ f, std::min(per, n_frames - f), 0, mcu_rows });
+    }
+    return out;
+}
+
+}  // namespace
+
 struct jpezy_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -124,6 +150,8 @@ struct jpezy_ctx {
     int h_last_passes = 0;         // synchronisation passes of the last jpezy_read_jpeg_gpu (0: the host decoder was used)
     size_t h_min_bytes = 256 << 10;   // scans shorter than this are decoded on the host (the GPU path has ~3 ms of fixed cost)
     DevBuf e_hdr;                  // JFIF header bytes of the device-resident variant (cached per W, H, comment)
+    jpezy_host::HostPipe pipe;     // staging ring of the streaming host-buffer entry points (jpezy_hostpipe.h)
+    size_t host_chunk_bytes = 4u << 20;   // bytes of input per chunk of that pipeline (jpezy_ctx_set_host_chunk_bytes)
     std::vector<jpezy_ctx*> workers;   // jpezy_decode_jpeg_batch: one child context (stream, buffers, tables) per file in flight
     uint8_t e_hdr_host[1024];
     size_t e_hdr_len = 0;
@@ -288,7 +316,9 @@ void jpezy_ctx_destroy(jpezy_ctx* c)
     for (jpezy_ctx* w : c->workers) jpezy_ctx_destroy(w);
     c->workers.clear();
     (void)hipSetDevice(c->device);
-    if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    c->pipe.release();
+    if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->d_tab) (void)hipFree(c->d_tab);
     if (c->d_counter) (void)hipFree(c->d_counter);
     if (c->d_dqscale) (void)hipFree(c->d_dqscale);
@@ -430,32 +460,54 @@ int jpezy_debug_read_trace(jpezy_ctx* c, unsigned long long* host, size_t n)
 }
 #endif
 
+void jpezy_ctx_set_host_chunk_bytes(jpezy_ctx* c, size_t n)
+{
+    if (c) c->host_chunk_bytes = n < 4096 ? 4096 : n;
+}
+
 int jpezy_fdct_quant(jpezy_ctx* c, const uint8_t* r, const uint8_t* g, const uint8_t* b, int W, int H, int gray,
                      int n_frames, int16_t* coeffs)
-{
+try {
     if (int rc = check_dims(c, W, H, n_frames)) return rc;
     if (!r || !g || !b || !coeffs) return set_err(JPEZY_E_BADARG, "null host pointer");
     HIP_TRY(hipSetDevice(c->device));
     const size_t plane = (size_t)W * H;
-    const size_t stride = (plane + 15) & ~(size_t)15;          // keep every frame 16-byte aligned
+    const int mcu_cols = jpezy_mcu_cols(W), B = gray ? 4 : 6;
     const size_t ncoef = jpezy_coeff_count(W, H, gray);
-    const uint8_t* src[3] = { r, g, b };
-    for (int k = 0; k < 3; ++k) {
-        if (int rc = c->in[k].reserve(stride * n_frames)) return rc;
-        if (stride == plane) {
-            HIP_TRY(hipMemcpyAsync(c->in[k].p, src[k], plane * n_frames, hipMemcpyHostToDevice, c->stream));
-        } else {
-            HIP_TRY(hipMemcpy2DAsync(c->in[k].p, stride, src[k], plane, plane, (size_t)n_frames, hipMemcpyHostToDevice, c->stream));
-        }
+    const std::vector<HostChunk> chunks = plan_host_chunks(W, H, n_frames, 3, c->host_chunk_bytes);
+    // a chunk's planes sit one behind the other in its slot, P bytes apart (a multiple of 16: the aligned kernel stays usable)
+    size_t P = 0, max_out = 0;
+    for (const HostChunk& k : chunks) {
+        const size_t rows = (size_t)std::min(H - k.y0 * 16, (k.y1 - k.y0) * 16);
+        P = std::max(P, k.nf > 1 || k.y1 - k.y0 == jpezy_mcu_rows(H) ? plane * k.nf : rows * W);
+        max_out = std::max(max_out, (size_t)k.nf * (k.y1 - k.y0) * mcu_cols * B * 128);
     }
-    if (int rc = c->out.reserve(ncoef * n_frames * sizeof(int16_t))) return rc;
-    if (int rc = jpezy_fdct_quant_dev(c, (const uint8_t*)c->in[0].p, (const uint8_t*)c->in[1].p, (const uint8_t*)c->in[2].p,
-                                      stride, W, H, gray, n_frames, (int16_t*)c->out.p, c->stream))
-        return rc;
-    HIP_TRY(hipMemcpyAsync(coeffs, c->out.p, ncoef * n_frames * sizeof(int16_t), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    P = (P + 15) & ~(size_t)15;
+    const uint8_t* src[3] = { r, g, b };
+    int rc_kernel = JPEZY_OK;
+    std::string err;
+    auto plan = [&](int i) {
+        const HostChunk& k = chunks[(size_t)i];
+        jpezy_host::ChunkPlan p;
+        const size_t rows = (size_t)std::min(H - k.y0 * 16, (k.y1 - k.y0) * 16);
+        const size_t bytes = k.nf > 1 ? plane * k.nf : rows * W, off = (size_t)k.f0 * plane + (size_t)k.y0 * 16 * W;
+        for (int q = 0; q < 3; ++q) p.in.push_back({ const_cast<uint8_t*>(src[q]) + off, bytes, (size_t)q * P });
+        p.out.push_back({ coeffs + (size_t)k.f0 * ncoef + (size_t)k.y0 * mcu_cols * B * 64, (size_t)k.nf * (k.y1 - k.y0) * mcu_cols * B * 128, 0 });
+        return p;
+    };
+    auto kernel = [&](int i, uint8_t* d_in, uint8_t* d_out, hipStream_t s) -> hipError_t {
+        const HostChunk& k = chunks[(size_t)i];
+        const int Hc = std::min(H - k.y0 * 16, (k.y1 - k.y0) * 16);
+        const int rc = jpezy_fdct_quant_dev(c, d_in, d_in + P, d_in + 2 * P, k.nf > 1 ? plane : (size_t)Hc * W, W, Hc, gray, k.nf, (int16_t*)d_out, s);
+        if (rc != JPEZY_OK) { rc_kernel = rc; return hipErrorLaunchFailure; }
+        return hipSuccess;
+    };
+    const hipError_t e = c->pipe.run(c->device, c->stream, (int)chunks.size(), 3 * P, max_out, plan, kernel, &err);
+    if (rc_kernel != JPEZY_OK) return rc_kernel;                    // message set by jpezy_fdct_quant_dev
+    if (e != hipSuccess) return set_err(JPEZY_E_HIP, err.empty() ? std::string("host pipeline: ") + hipGetErrorString(e) : err);
     return JPEZY_OK;
 }
+JPEZY_CATCH
 
 static int upload_dequant(jpezy_ctx* c, const uint16_t qt[4][64], const uint8_t comp_tq[3], hipStream_t s)
 {
@@ -533,31 +585,49 @@ int jpezy_dequant_idct_dev(jpezy_ctx* c, const int16_t* d_coeffs, const uint16_t
 
 int jpezy_dequant_idct(jpezy_ctx* c, const int16_t* coeffs, const uint16_t qt[4][64], const uint8_t comp_tq[3], int W,
                        int H, int gray, int n_frames, uint8_t* r, uint8_t* g, uint8_t* b)
-{
+try {
     if (int rc = check_dims(c, W, H, n_frames)) return rc;
     if (!coeffs || !qt || !comp_tq || !r || !g || !b) return set_err(JPEZY_E_BADARG, "null pointer");
     HIP_TRY(hipSetDevice(c->device));
+    if (int rc = upload_dequant(c, qt, comp_tq, c->stream)) return rc;      // tables first: never rewritten while chunks are in flight
     const size_t plane = (size_t)W * H;
-    const size_t stride = (plane + 15) & ~(size_t)15;
+    const int mcu_cols = jpezy_mcu_cols(W);
     const size_t ncoef = jpezy_coeff_count(W, H, 0);
-    if (int rc = c->out.reserve(ncoef * n_frames * sizeof(int16_t))) return rc;
-    HIP_TRY(hipMemcpyAsync(c->out.p, coeffs, ncoef * n_frames * sizeof(int16_t), hipMemcpyHostToDevice, c->stream));
-    for (int k = 0; k < 3; ++k)
-        if (int rc = c->in[k].reserve(stride * n_frames)) return rc;
-    if (int rc = jpezy_dequant_idct_dev(c, (const int16_t*)c->out.p, qt, comp_tq, stride, W, H, gray, n_frames,
-                                        (uint8_t*)c->in[0].p, (uint8_t*)c->in[1].p, (uint8_t*)c->in[2].p, c->stream))
-        return rc;
-    uint8_t* dst[3] = { r, g, b };
-    for (int k = 0; k < 3; ++k) {
-        if (stride == plane) {
-            HIP_TRY(hipMemcpyAsync(dst[k], c->in[k].p, plane * n_frames, hipMemcpyDeviceToHost, c->stream));
-        } else {
-            HIP_TRY(hipMemcpy2DAsync(dst[k], plane, c->in[k].p, stride, plane, (size_t)n_frames, hipMemcpyDeviceToHost, c->stream));
-        }
+    const std::vector<HostChunk> chunks = plan_host_chunks(W, H, n_frames, 3, c->host_chunk_bytes);
+    size_t P = 0, max_in = 0;
+    for (const HostChunk& k : chunks) {
+        const size_t rows = (size_t)std::min(H - k.y0 * 16, (k.y1 - k.y0) * 16);
+        P = std::max(P, k.nf > 1 || k.y1 - k.y0 == jpezy_mcu_rows(H) ? plane * k.nf : rows * W);
+        max_in = std::max(max_in, (size_t)k.nf * (k.y1 - k.y0) * mcu_cols * 6 * 128);
     }
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    P = (P + 15) & ~(size_t)15;
+    uint8_t* dst[3] = { r, g, b };
+    int rc_kernel = JPEZY_OK;
+    std::string err;
+    auto plan = [&](int i) {
+        const HostChunk& k = chunks[(size_t)i];
+        jpezy_host::ChunkPlan p;
+        const size_t rows = (size_t)std::min(H - k.y0 * 16, (k.y1 - k.y0) * 16);
+        const size_t bytes = k.nf > 1 ? plane * k.nf : rows * W, off = (size_t)k.f0 * plane + (size_t)k.y0 * 16 * W;
+        p.in.push_back({ const_cast<int16_t*>(coeffs) + (size_t)k.f0 * ncoef + (size_t)k.y0 * mcu_cols * 6 * 64,
+                         (size_t)k.nf * (k.y1 - k.y0) * mcu_cols * 6 * 128, 0 });
+        for (int q = 0; q < 3; ++q) p.out.push_back({ dst[q] + off, bytes, (size_t)q * P });
+        return p;
+    };
+    auto kernel = [&](int i, uint8_t* d_in, uint8_t* d_out, hipStream_t s) -> hipError_t {
+        const HostChunk& k = chunks[(size_t)i];
+        const int Hc = std::min(H - k.y0 * 16, (k.y1 - k.y0) * 16);
+        const int rc = jpezy_dequant_idct_dev(c, (const int16_t*)d_in, qt, comp_tq, k.nf > 1 ? plane : (size_t)Hc * W, W, Hc, gray, k.nf, d_out,
+                                              d_out + P, d_out + 2 * P, s);
+        if (rc != JPEZY_OK) { rc_kernel = rc; return hipErrorLaunchFailure; }
+        return hipSuccess;
+    };
+    const hipError_t e = c->pipe.run(c->device, c->stream, (int)chunks.size(), max_in, 3 * P, plan, kernel, &err);
+    if (rc_kernel != JPEZY_OK) return rc_kernel;
+    if (e != hipSuccess) return set_err(JPEZY_E_HIP, err.empty() ? std::string("host pipeline: ") + hipGetErrorString(e) : err);
     return JPEZY_OK;
 }
+JPEZY_CATCH
 
 // geometry + tables + the two launches of the any-layout decoder on device memory; asynchronous on stream s (the tables are
 // uploaded synchronously when they changed since the last call)
@@ -928,16 +998,37 @@ try {
     if (int rc = check_dims(c, W, H, 1)) return rc;
     if (!r || !g || !b || !out) return set_err(JPEZY_E_BADARG, "encode_jpeg: null pointer");
     HIP_TRY(hipSetDevice(c->device));
-    const size_t plane = (size_t)W * H, stride = (plane + 15) & ~(size_t)15;
-    const uint8_t* src[3] = { r, g, b };
-    for (int k = 0; k < 3; ++k) {
-        if (int rc = c->in[k].reserve(stride)) return rc;
-        HIP_TRY(hipMemcpyAsync(c->in[k].p, src[k], plane, hipMemcpyHostToDevice, c->stream));
-    }
+    // the planes go up band by band (jpezy_hostpipe.h) while the bands before them are transformed into the frame's
+    // coefficient buffer on the device; the Huffman stage then runs on the whole frame
+    const size_t plane = (size_t)W * H;
+    const int mcu_cols = jpezy_mcu_cols(W), B = gray ? 4 : 6;
     if (int rc = c->e_coef.reserve(jpezy_coeff_count(W, H, gray) * sizeof(int16_t))) return rc;
-    if (int rc = jpezy_fdct_quant_dev(c, (const uint8_t*)c->in[0].p, (const uint8_t*)c->in[1].p, (const uint8_t*)c->in[2].p, stride, W, H,
-                                      gray, 1, (int16_t*)c->e_coef.p, c->stream))
-        return rc;
+    const std::vector<HostChunk> chunks = plan_host_chunks(W, H, 1, 3, c->host_chunk_bytes);
+    size_t P = 0;
+    for (const HostChunk& k : chunks) P = std::max(P, (size_t)std::min(H - k.y0 * 16, (k.y1 - k.y0) * 16) * W);
+    P = (P + 15) & ~(size_t)15;
+    const uint8_t* src[3] = { r, g, b };
+    int rc_kernel = JPEZY_OK;
+    std::string err;
+    auto plan = [&](int i) {
+        const HostChunk& k = chunks[(size_t)i];
+        jpezy_host::ChunkPlan p;
+        const size_t rows = (size_t)std::min(H - k.y0 * 16, (k.y1 - k.y0) * 16);
+        for (int q = 0; q < 3; ++q) p.in.push_back({ const_cast<uint8_t*>(src[q]) + (size_t)k.y0 * 16 * W, rows * W, (size_t)q * P });
+        return p;
+    };
+    auto kernel = [&](int i, uint8_t* d_in, uint8_t*, hipStream_t s) -> hipError_t {
+        const HostChunk& k = chunks[(size_t)i];
+        const int Hc = std::min(H - k.y0 * 16, (k.y1 - k.y0) * 16);
+        const int rc = jpezy_fdct_quant_dev(c, d_in, d_in + P, d_in + 2 * P, (size_t)Hc * W, W, Hc, gray, 1,
+                                            (int16_t*)c->e_coef.p + (size_t)k.y0 * mcu_cols * B * 64, s);
+        if (rc != JPEZY_OK) { rc_kernel = rc; return hipErrorLaunchFailure; }
+        return hipSuccess;
+    };
+    const hipError_t e = c->pipe.run(c->device, c->stream, (int)chunks.size(), 3 * P, 0, plan, kernel, &err);
+    if (rc_kernel != JPEZY_OK) return rc_kernel;
+    if (e != hipSuccess) return set_err(JPEZY_E_HIP, err.empty() ? std::string("host pipeline: ") + hipGetErrorString(e) : err);
+    (void)plane;
     return jpezy_write_jpeg_gpu(c, (const int16_t*)c->e_coef.p, W, H, gray, comment, out, cap);
 }
 JPEZY_CATCH

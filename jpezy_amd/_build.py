@@ -25,7 +25,7 @@ LIB_SOURCES = [CSRC / "jpezy_kernels.hip", CSRC / "jpezy_kernels_f32.hip", CSRC 
                CSRC / "jpezy_entropy.hip", CSRC / "jpezy_huffdec.hip",
                CSRC / "jpezy_capi.hip",
                CSRC / "jpezy_host_codec.cpp"]
-LIB_DEPS = LIB_SOURCES + [CSRC / "jpezy_device.h", CSRC / "jpezy_host_codec.h", CSRC / "jpezy_entropy.h", CSRC / "jpezy_huffdec.h",
+LIB_DEPS = LIB_SOURCES + [CSRC / "jpezy_device.h", CSRC / "jpezy_experiment.h", CSRC / "jpezy_hostpipe.h", CSRC / "jpezy_host_codec.h", CSRC / "jpezy_entropy.h", CSRC / "jpezy_huffdec.h",
                           ROOT / "include" / "jpezy_hip.h", ROOT / "include" / "jpezy_constants.h"]
 CLI = {"jpezy_encode": CSRC / "host" / "encode_main.cpp", "jpezy_decode": CSRC / "host" / "decode_main.cpp"}
 
@@ -63,25 +63,6 @@ def build_lib(force=False, verbose=False, constants=None, out=None):
             objs.append(obj)
         _run([HIPCC, "-shared", "-fPIC", *DEVICE, "-o", lib, *objs])
     return lib
-
-
-ALT_DIR = PKG / "_alt"          # alternative-constants builds (git-ignored *.so / *.h are regenerated by build_alt)
-
-
-def build_alt(variant="alt1", force=False):
-    """Product library and oracle built against tools/gen_constants.py --variant <variant>: proves that both follow
-    the one constants header (the GPU tables are host-built from it).  Returns (product .so, oracle .so, header)."""
-    import sys
-    hdr = ALT_DIR / f"jpezy_constants_{variant}.h"
-    gen = ROOT / "tools" / "gen_constants.py"
-    if force or _stale(hdr, [gen]):
-        ALT_DIR.mkdir(parents=True, exist_ok=True)
-        _run([sys.executable, gen, "--variant", variant, "--out", hdr])
-    lib = build_lib(force, constants=hdr, out=ALT_DIR / f"libjpezy_hip_{variant}.so")
-    sys.path.insert(0, str(ROOT))
-    from oracle import oracle as O
-    ora = O.build(force, constants=hdr, out=ROOT / "oracle" / "_alt" / f"libjpezy_oracle_{variant}.so")
-    return lib, ora, hdr
 
 
 def build_cli(force=False):

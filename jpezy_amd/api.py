@@ -41,6 +41,7 @@ _TQ = C.POINTER(C.c_uint8 * 3)
 ABI = [
     ("jpezy_hip_last_error", C.c_char_p, []),
     ("jpezy_hip_device_count", C.c_int, []),
+    ("jpezy_hip_is_experimental_build", C.c_int, []),
     ("jpezy_ctx_create", _vp, [C.c_int]),
     ("jpezy_ctx_destroy", None, [_vp]),
     ("jpezy_ctx_sync", C.c_int, [_vp]),
@@ -99,6 +100,9 @@ def load_library():
             fn = getattr(lib, name)          # AttributeError if the library does not export the symbol
             fn.restype = res
             fn.argtypes = args
+        if lib.jpezy_hip_is_experimental_build() and os.environ.get("JPEZY_ALLOW_EXPERIMENT") != "1":
+            raise JpezyError(f"{_LIBPATH} was built with a wrong-result timing probe (JPEZY_EXPERIMENT); "
+                             "set JPEZY_ALLOW_EXPERIMENT=1 to load it for timing only")
         _LIB = lib
     return _LIB
 

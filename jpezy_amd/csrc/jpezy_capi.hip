@@ -161,6 +161,15 @@ extern "C" {
 
 const char* jpezy_hip_last_error(void) { return g_err.c_str(); }
 
+int jpezy_hip_is_experimental_build(void)
+{
+#ifdef JPEZY_EXPERIMENT
+    return 1;
+#else
+    return 0;
+#endif
+}
+
 int jpezy_hip_device_count(void)
 {
     int n = 0;

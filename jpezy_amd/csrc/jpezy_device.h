@@ -1,5 +1,6 @@
 // jpezy_device.h -- shared declarations of the gfx950 kernels and their launchers (internal).
 #pragma once
+#include "jpezy_experiment.h"
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 #include <stdint.h>

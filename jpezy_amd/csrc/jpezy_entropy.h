@@ -1,5 +1,6 @@
 // jpezy_entropy.h -- GPU Huffman coder + bit packer + byte stuffer (internal; see jpezy_entropy.hip)
 #pragma once
+#include "jpezy_experiment.h"
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 #include <stdint.h>

@@ -326,9 +326,6 @@ __global__ __launch_bounds__(WG) void code_tiles_kernel(Job job, uint32_t* S, ui
     const size_t t_index = (size_t)frame * gridDim.x + blockIdx.x;
     if (tid == 0) tile_total[t_index] = total;
     if (!valid) return;
-#if defined(JPEZY_ENT_ABL) && JPEZY_ENT_ABL == 1
-    return;
-#endif
 
     uint32_t* const Sg = S + t_index * TILE_STREAM_WORDS;
     const unsigned sh = o & 31u, w0 = o >> 5, end = o + n;

@@ -18,8 +18,8 @@ sys.path.insert(0, str(ROOT))
 
 @pytest.fixture(scope="module")
 def alt():
-    from jpezy_amd import _build
-    lib, ora, hdr = _build.build_alt("alt1")        # a no-op when __graft_entry__.build() already made them
+    from tools import build_alt
+    lib, ora, hdr = build_alt.build_alt("alt1")     # a no-op when __graft_entry__.build() already made them
     return lib, ora, hdr
 
 

@@ -151,7 +151,8 @@ void jpezy_ctx_set_force_exact(jpezy_ctx* ctx, int on);
  * reference-order third level (default), 2 = variant 1 with the luma transforms of a quad as one f16-limb matrix product on
  * the matrix pipe.  All produce identical coefficients in every test; they differ in speed -- and in what the exactness
  * rests on: variants 0 and 1 on proven error bounds, variant 2 on a MEASURED model of the undocumented accumulation inside
- * v_mfma_f32_16x16x32_f16 (opt-in for that reason). */
+ * v_mfma_f32_16x16x32_f16 (opt-in for that reason): variant 2 is BEST-EFFORT parity -- identical on everything
+ * tested (parity suite, adversarial near-integer soak), not proven. */
 int jpezy_ctx_set_variant(jpezy_ctx* ctx, int variant);
 /*
  * Decode tolerance (opt-in; default 0).  BASELINE.json's north_star asks of the decoder "PPM output within +-1 LSB per

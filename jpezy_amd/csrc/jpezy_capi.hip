@@ -55,13 +55,18 @@ inline bool aligned16(const void* p) { return ((uintptr_t)p & 15u) == 0; }
 // Context-wide device tables (dequantiser constants, cached JFIF header) may be read by launches still in flight on ANY
 // stream the caller drives this context with: before rewriting them, wait for the whole device; and never from inside
 // a stream capture (a synchronisation there would invalidate the capture).
-int drain_before_table_rewrite(hipStream_t s, const char* what)
+// own_stream_only: the context is a child of jpezy_decode_jpeg_batch -- it is only ever driven on its own stream, so waiting for
+// that stream is enough (eight children that each stalled the whole device for every file with new tables serialised the batch).
+int drain_before_table_rewrite(hipStream_t s, const char* what, bool own_stream_only = false)
 {
     hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(s, &st) == hipSuccess && st != hipStreamCaptureStatusNone)
         return set_err(JPEZY_E_BADARG, std::string(what) + ": new tables/header cannot be uploaded while the stream is being captured; "
                                                             "make the first call with these arguments outside the capture");
-    HIP_TRY(hipDeviceSynchronize());
+    if (own_stream_only)
+        HIP_TRY(hipStreamSynchronize(s));
+    else
+        HIP_TRY(hipDeviceSynchronize());
     return JPEZY_OK;
 }
 
@@ -152,6 +157,7 @@ struct jpezy_ctx {
     DevBuf e_hdr;                  // JFIF header bytes of the device-resident variant (cached per W, H, comment)
     jpezy_host::HostPipe pipe;     // staging ring of the streaming host-buffer entry points (jpezy_hostpipe.h)
     size_t host_chunk_bytes = 4u << 20;   // bytes of input per chunk of that pipeline (jpezy_ctx_set_host_chunk_bytes)
+    bool is_batch_child = false;       // a worker of jpezy_decode_jpeg_batch: only ever driven on its own stream
     std::vector<jpezy_ctx*> workers;   // jpezy_decode_jpeg_batch: one child context (stream, buffers, tables) per file in flight
     uint8_t e_hdr_host[1024];
     size_t e_hdr_len = 0;
@@ -524,7 +530,7 @@ static int upload_dequant(jpezy_ctx* c, const uint16_t qt[4][64], const uint8_t 
     for (int k = 0; k < 3; ++k) std::memcpy(sel[k], qt[comp_tq[k] & 3], sizeof sel[k]);
     if (c->dq_valid && !std::memcmp(sel, c->dq_cache, sizeof sel)) return JPEZY_OK;
     // A previous launch -- on this or another stream -- may still be reading the tables.
-    if (int rc = drain_before_table_rewrite(s, "dequant_idct")) return rc;
+    if (int rc = drain_before_table_rewrite(s, "dequant_idct", c->is_batch_child && s == c->stream)) return rc;
     static thread_local double h_scale[3][8][8];
     static thread_local int h_qt[3][64];
     const double S = JPEZY_INV_SQRT2;
@@ -951,12 +957,20 @@ int jpezy_write_jpeg_gpu_dev(jpezy_ctx* c, const int16_t* d_coeffs, int W, int H
         // every block coded once into its tile's stream; tile offsets; streams assembled and their 0xFF bytes counted; the
         // 0xFF offsets; files written (header, stuffed stream, EOI, size or verdict)
         HIP_TRY(E::launch_code_tiles(job, (uint32_t*)c->e_S.p, (uint32_t*)c->e_tt.p, d_status, s));
+        // the coder may have raised per-frame error flags that only their consumer (tile_bases / assemble) clears: if the call ends
+        // between the two, the flags are cleared here so that they do not leak into the context's next call
+        hipError_t e_mid = hipSuccess;
         if (!self)
-            HIP_TRY(E::launch_tile_bases((const uint32_t*)c->e_tt.p, (unsigned)tpf, F, (unsigned long long*)c->e_base.p, d_bytes,
-                                         (uint32_t*)c->e_ft.p, (unsigned)(u_stride / piece), d_status, d_latched, s));
-        HIP_TRY(E::launch_assemble((const uint32_t*)c->e_S.p, (const uint32_t*)c->e_tt.p, (const unsigned long long*)c->e_base.p, d_bytes,
-                                   (const uint32_t*)c->e_ft.p, (unsigned)(u_stride / piece), (unsigned)tpf, F, (uint32_t*)c->e_U.p,
-                                   u_stride / 4, (uint32_t*)c->e_cnt.p, (uint32_t*)c->e_fft.p, d_status, d_latched, s));
+            e_mid = E::launch_tile_bases((const uint32_t*)c->e_tt.p, (unsigned)tpf, F, (unsigned long long*)c->e_base.p, d_bytes,
+                                         (uint32_t*)c->e_ft.p, (unsigned)(u_stride / piece), d_status, d_latched, s);
+        if (e_mid == hipSuccess)
+            e_mid = E::launch_assemble((const uint32_t*)c->e_S.p, (const uint32_t*)c->e_tt.p, (const unsigned long long*)c->e_base.p, d_bytes,
+                                       (const uint32_t*)c->e_ft.p, (unsigned)(u_stride / piece), (unsigned)tpf, F, (uint32_t*)c->e_U.p,
+                                       u_stride / 4, (uint32_t*)c->e_cnt.p, (uint32_t*)c->e_fft.p, d_status, d_latched, s);
+        if (e_mid != hipSuccess) {
+            (void)hipMemsetAsync(d_status, 0, sizeof(unsigned) * (size_t)F, s);
+            return hip_err(e_mid, "entropy stage (tile offsets / assembly)");
+        }
         E::FilePlan plan;
         plan.hdr = (const uint8_t*)c->e_hdr.p;
         plan.hdr_len = hdr_len;
@@ -1334,6 +1348,7 @@ try {
     while ((int)c->workers.size() < nw) {
         jpezy_ctx* w = jpezy_ctx_create(c->device);
         if (!w) return JPEZY_E_HIP;                                  // message set by jpezy_ctx_create
+        w->is_batch_child = true;
         c->workers.push_back(w);
     }
     for (int k = 0; k < nw; ++k) c->workers[k]->h_min_bytes = c->h_min_bytes;

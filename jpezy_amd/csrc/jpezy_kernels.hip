@@ -955,19 +955,20 @@ __global__ __launch_bounds__(64 * WPB, GRAY ? JPEZY_DEC_WAVES_GRAY : JPEZY_DEC_W
         uint8_t* obp = p.b + (size_t)frame * p.plane_stride + (size_t)py * W;
         if (ALIGNED) {
             const size_t off = (size_t)mcu_x * 16;
-#ifndef JPEZY_DEC_PLAIN_STORES
-            // non-temporal: the planes are never re-read by the kernel, and 50 MB of dirty lines are not left in the eight L2s
-            // for the end-of-kernel write-back.  A quad covers 64 bytes of a pixel row, so the stores go out as half lines
-            // (WRITE_SIZE counts +40 % requests) -- and the launch is still 1.5-2.4 us shorter (profiles/r03a_ab_decode.txt:
-            // 37.4 -> 35.1-35.9 us; round 2 judged this by the request count alone and kept plain stores)
-            nt_store16(reinterpret_cast<uint4*>(orp + off), make_uint4(Rw[0], Rw[1], Rw[2], Rw[3]));
-            nt_store16(reinterpret_cast<uint4*>(ogp + off), make_uint4(Gw[0], Gw[1], Gw[2], Gw[3]));
-            nt_store16(reinterpret_cast<uint4*>(obp + off), make_uint4(Bw[0], Bw[1], Bw[2], Bw[3]));
-#else
-            *reinterpret_cast<uint4*>(orp + off) = make_uint4(Rw[0], Rw[1], Rw[2], Rw[3]);
-            *reinterpret_cast<uint4*>(ogp + off) = make_uint4(Gw[0], Gw[1], Gw[2], Gw[3]);
-            *reinterpret_cast<uint4*>(obp + off) = make_uint4(Bw[0], Bw[1], Bw[2], Bw[3]);
-#endif
+            // Colour: non-temporal -- the planes are never re-read by the kernel, and 50 MB of dirty lines are not left in the eight
+            // L2s for the end-of-kernel write-back.  A quad covers 64 bytes of a pixel row, so the stores go out as half lines
+            // (WRITE_SIZE counts +30 % requests) -- and the launch is still 1.5-2.4 us shorter (profiles/r03a_ab_decode.txt:
+            // 37.4 -> 35.1-35.9 us; round 2 judged this by the request count alone and kept plain stores).  Gray (three planes of
+            // the same bytes, twice the pixels per coefficient read): plain stores measure better, 46.9 against 50.5 us at 8K.
+            if (!GRAY) {
+                nt_store16(reinterpret_cast<uint4*>(orp + off), make_uint4(Rw[0], Rw[1], Rw[2], Rw[3]));
+                nt_store16(reinterpret_cast<uint4*>(ogp + off), make_uint4(Gw[0], Gw[1], Gw[2], Gw[3]));
+                nt_store16(reinterpret_cast<uint4*>(obp + off), make_uint4(Bw[0], Bw[1], Bw[2], Bw[3]));
+            } else {
+                *reinterpret_cast<uint4*>(orp + off) = make_uint4(Rw[0], Rw[1], Rw[2], Rw[3]);
+                *reinterpret_cast<uint4*>(ogp + off) = make_uint4(Gw[0], Gw[1], Gw[2], Gw[3]);
+                *reinterpret_cast<uint4*>(obp + off) = make_uint4(Bw[0], Bw[1], Bw[2], Bw[3]);
+            }
         } else {
 #pragma unroll
             for (int k = 0; k < 16; ++k) {

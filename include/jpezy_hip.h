@@ -258,8 +258,11 @@ int jpezy_decode_jpeg(jpezy_ctx* ctx, const uint8_t* data, size_t len, int gray,
                       uint8_t* g, uint8_t* b, size_t plane_cap);
 /*
  * jpezy_decode_jpeg for n files at once (n decoder objects of the reference, decoder/jpezy_decoder.hpp:39-134, one per
- * file): files are decoded concurrently, up to 8 in flight on the context's device -- a single file's pipeline is
- * latency-bound, so a batch of 1080p files takes about a fifth of the time of n single calls.  data[i] / len[i]: file i;
+ * file).  Files of jpezy's own layout (3 components sampled 2x2/1x1/1x1, 8 bit, no restart intervals) are grouped by size and
+ * quantiser tables and decoded TOGETHER: one sequence of Huffman-decoder launches per slice of 16 scans (every file with its own
+ * code tables), one IDCT launch per slice, the planes of a slice copied out while the next slice is decoded -- a single file keeps 80
+ * waves busy for a chain of launches that is pure latency, a slice fills the chip for the same chain; a batch is bounded by PCIe.  Everything else (other layouts, irregular or non-converging streams, single files)
+ * is decoded file by file, up to 8 in flight on child contexts, with the host decoder as the last word, as before.  data[i] / len[i]: file i;
  * r[i], g[i], b[i]: its planes (plane_cap[i] >= width*height bytes each; sizes come from a header-only jpezy_decode_jpeg or
  * jpezy_read_jpeg call); info[i] and status[i] (JPEZY_OK or that file's negative error code) are written per file.
  * Returns JPEZY_OK when every file decoded, else the first failing file's code (message: which file and why); the other
@@ -270,6 +273,8 @@ int jpezy_decode_jpeg_batch(jpezy_ctx* ctx, int n, const uint8_t* const* data, c
                             const size_t* plane_cap, int* status);
 /* Synchronisation passes the last jpezy_read_jpeg_gpu call needed; 0 = the host decoder was used (test/diagnostic hook). */
 int jpezy_ctx_last_huffdec_passes(jpezy_ctx* ctx);
+/* Files of the last jpezy_decode_jpeg_batch call that were decoded by the batch form of the kernels (test/diagnostic hook). */
+int jpezy_ctx_last_batch_fast_count(jpezy_ctx* ctx);
 /* Scans shorter than n bytes are decoded on the host (default 256 KiB: the GPU decoder has ~3 ms of fixed cost); 0
  * sends every scan to the GPU decoder (tests). */
 void jpezy_ctx_set_huffdec_min_bytes(jpezy_ctx* ctx, size_t n);

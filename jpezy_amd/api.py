@@ -73,6 +73,7 @@ ABI = [
     ("jpezy_decode_jpeg", C.c_int, [_vp, _vp, C.c_size_t, C.c_int, C.POINTER(FrameInfo), _vp, _vp, _vp, C.c_size_t]),
     ("jpezy_decode_jpeg_batch", C.c_int, [_vp, C.c_int, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp]),
     ("jpezy_ctx_last_huffdec_passes", C.c_int, [_vp]),
+    ("jpezy_ctx_last_batch_fast_count", C.c_int, [_vp]),
     ("jpezy_ctx_set_huffdec_min_bytes", None, [_vp, C.c_size_t]),
 ]
 
@@ -319,6 +320,10 @@ class Context:
 
     def set_huffdec_min_bytes(self, n):
         load_library().jpezy_ctx_set_huffdec_min_bytes(self._h, n)
+
+    def last_batch_fast_count(self):
+        """files of the last decode_jpeg_batch call that took the batch form of the Huffman decoder kernels"""
+        return load_library().jpezy_ctx_last_batch_fast_count(self._h)
 
     def last_huffdec_passes(self):
         """synchronisation passes of the last read_jpeg_gpu call; 0 = the host decoder was used"""

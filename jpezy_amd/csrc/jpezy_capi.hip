@@ -3,6 +3,7 @@
 // No CPU fallback: every compute entry point needs a HIP device.
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -154,6 +155,10 @@ struct jpezy_ctx {
     DevBuf h_scan, h_U, h_cnt, h_off, h_state, h_setup, h_small, h_dc;   // GPU Huffman decoder (jpezy_huffdec.hip)
     int h_last_passes = 0;         // synchronisation passes of the last jpezy_read_jpeg_gpu (0: the host decoder was used)
     size_t h_min_bytes = 256 << 10;   // scans shorter than this are decoded on the host (the GPU path has ~3 ms of fixed cost)
+    DevBuf b_scan, b_U, b_cnt, b_rb, b_state, b_prop, b_meta, b_coef, b_planes[2];   // jpezy_decode_jpeg_batch, batch form of the Huffman decoder
+    int b_last_fast = 0;           // files of the last jpezy_decode_jpeg_batch call that took the batch form (diagnostic hook)
+    uint8_t* b_pin = nullptr;      // pinned staging of the concatenated scans
+    size_t b_pin_cap = 0;
     DevBuf e_hdr;                  // JFIF header bytes of the device-resident variant (cached per W, H, comment)
     jpezy_host::HostPipe pipe;     // staging ring of the streaming host-buffer entry points (jpezy_hostpipe.h)
     size_t host_chunk_bytes = 4u << 20;   // bytes of input per chunk of that pipeline (jpezy_ctx_set_host_chunk_bytes)
@@ -344,6 +349,8 @@ void jpezy_ctx_destroy(jpezy_ctx* c)
     c->scratch.release();
     if (c->d_codes) (void)hipFree(c->d_codes);
     if (c->e_pinned) (void)hipHostFree(c->e_pinned);
+    if (c->b_pin) (void)hipHostFree(c->b_pin);
+    for (DevBuf* b : { &c->b_scan, &c->b_U, &c->b_cnt, &c->b_rb, &c->b_state, &c->b_prop, &c->b_meta, &c->b_coef, &c->b_planes[0], &c->b_planes[1] }) b->release();
     for (DevBuf* b : { &c->e_tmp, &c->e_small, &c->e_U, &c->e_cnt, &c->e_out, &c->e_coef, &c->e_hdr, &c->e_status, &c->e_tt, &c->e_fft, &c->e_S, &c->e_base, &c->e_ft,
                        &c->dump_t, &c->h_scan, &c->h_U, &c->h_cnt, &c->h_off, &c->h_state, &c->h_setup, &c->h_small, &c->h_dc }) b->release();
     delete c;
@@ -1333,6 +1340,204 @@ try {
 }
 JPEZY_CATCH
 
+// ---- batch form (round 3): files of jpezy's own layout and one size go through the Huffman decoder TOGETHER ----
+namespace {
+
+struct FastFile {
+    int index;                          // position in the caller's arrays
+    jpezy_host::ScanSetup setup;
+    const uint8_t* scan;
+    size_t n;
+};
+
+// One slice of a group (same W x H, same quantiser tables, jpezy's own 2x2,1x1,1x1 layout): Huffman decoding of all files in one
+// sequence of launches (jpezy_huffdec.h, batch form), ONE dequant_idct launch over the slice, the planes copied out per file.
+// ok[k] = 1 for files decoded here; the others (not converged, irregular stream) are left to the per-file path, whose verdict --
+// host decoder included -- is the authoritative one.
+int decode_slice_fast(jpezy_ctx* c, const std::vector<FastFile>& files, const jpezy_frame_info& info, int gray, int plane_buf,
+                      std::vector<char>& ok)
+{
+    namespace HD = jpezy_dev::huffdec;
+    namespace E = jpezy_dev::entropy;
+    hipStream_t s = c->stream;
+    const unsigned nf = (unsigned)files.size();
+    const unsigned L = HD::subseq_bits();
+    const size_t chunk = HD::chunk_bytes();
+    const int W = info.width, H = info.height;
+    const size_t nmcu = (size_t)info.mcu_cols * info.mcu_rows, cpf = nmcu * 6 * 64, plane = (size_t)W * H, pstride = (plane + 15) & ~(size_t)15;
+    ok.assign(nf, 0);
+    const bool dbg = std::getenv("JPEZY_BATCH_DEBUG") != nullptr;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_mark = now();
+    auto lap = [&](const char* what) {
+        if (!dbg) return;
+        (void)hipStreamSynchronize(s);
+        const double t = now();
+        std::fprintf(stderr, "  batch slice (%u files): %-28s %.3f ms\n", nf, what, (t - t_mark) * 1e3);
+        t_mark = t;
+    };
+
+    // geometry of the slice
+    std::vector<HD::BatchFile> F(nf);
+    std::vector<HD::Setup> setups(nf);
+    std::vector<unsigned> wg_file, wg_first;
+    size_t total_chunks = 0, total_slots = 0, u_bytes = 0;
+    std::vector<char> usable(nf, 1);
+    for (unsigned k = 0; k < nf; ++k) {
+        const FastFile& ff = files[k];
+        HD::BatchFile& f = F[k];
+        std::memset(&f, 0, sizeof f);
+        f.chunk0 = (unsigned)total_chunks;
+        f.n_chunks = (unsigned)((ff.n + chunk - 1) / chunk);
+        f.n_bytes = (unsigned)ff.n;
+        f.sub0 = (unsigned)total_slots;
+        f.n_sub_max = (unsigned)((ff.n * 8 + L - 1) / L);
+        f.u_off = u_bytes;
+        const size_t ub = (((size_t)f.n_sub_max * L / 8 + 64) + 3) & ~(size_t)3;
+        f.u_words = (unsigned)(ub / 4);
+        f.coeff_off = (unsigned long long)k * cpf;
+        f.total_blocks = (unsigned)(nmcu * 6);
+        f.nmcu = (unsigned)nmcu; f.bpm = 6; f.ncomp = 3;
+        f.cstart[0] = 0; f.ccount[0] = 4; f.cstart[1] = 4; f.ccount[1] = 1; f.cstart[2] = 5; f.ccount[2] = 1;
+        total_chunks += f.n_chunks;
+        total_slots += ((size_t)f.n_sub_max + 255) / 256 * 256;           // a workgroup never straddles two files
+        u_bytes += ub;
+        for (unsigned i0 = 0; i0 < f.n_sub_max; i0 += 256) { wg_file.push_back(k); wg_first.push_back(i0); }
+        // tables (any DHT the file carries); one the device form cannot express sends the file to the per-file path
+        HD::Setup& S = setups[k];
+        std::memset(&S, 0, sizeof S);
+        for (int td = 0; td < 3; ++td) {
+            if (ff.setup.present[td]) usable[k] = build_dev_table(S.dc[td], ff.setup.bits[td], ff.setup.vals[td], ff.setup.nvals[td]) && usable[k];
+            if (ff.setup.present[4 + td]) usable[k] = build_dev_table(S.ac[td], ff.setup.bits[4 + td], ff.setup.vals[4 + td], ff.setup.nvals[4 + td]) && usable[k];
+        }
+        S.total_blocks = f.total_blocks;
+        {
+            int seq[6] = { ff.setup.Td[0], ff.setup.Td[0], ff.setup.Td[0], ff.setup.Td[0], ff.setup.Td[1], ff.setup.Td[2] };
+            int period = 6;
+            for (int pd = 1; pd < 6; ++pd) {
+                if (6 % pd) continue;
+                bool same = true;
+                for (int i = pd; i < 6 && same; ++i) same = seq[i] == seq[i - pd];
+                if (same) { period = pd; break; }
+            }
+            S.bpm = period;
+            for (int i = 0; i < period; ++i) S.btd[i] = seq[i];
+        }
+    }
+    if (total_chunks >= 0xFFFFFFFFull || total_slots >= 0xFFFFFFFFull) return set_err(JPEZY_E_BADARG, "decode_jpeg_batch: slice too large");
+    const unsigned n_wg = (unsigned)wg_file.size();
+
+    // buffers
+    const size_t scan_bytes = total_chunks * chunk;
+    if (c->b_pin_cap < scan_bytes) {
+        if (c->b_pin) (void)hipHostFree(c->b_pin);
+        c->b_pin = nullptr; c->b_pin_cap = 0;
+        HIP_TRY(hipHostMalloc((void**)&c->b_pin, scan_bytes + (scan_bytes >> 2) + 4096, hipHostMallocDefault));
+        c->b_pin_cap = scan_bytes + (scan_bytes >> 2) + 4096;
+    }
+    const size_t meta_F = (sizeof(HD::BatchFile) * nf + 255) & ~(size_t)255, meta_S = (sizeof(HD::Setup) * nf + 255) & ~(size_t)255;
+    const size_t meta_wg = ((size_t)n_wg * 4 + 255) & ~(size_t)255, meta_act = ((size_t)nf * 4 + 255) & ~(size_t)255;
+    if (int rc = c->b_scan.reserve(scan_bytes + 64)) return rc;
+    if (int rc = c->b_U.reserve(u_bytes + 64)) return rc;
+    if (int rc = c->b_cnt.reserve(std::max(total_chunks, total_slots) * sizeof(uint32_t))) return rc;
+    if (int rc = c->b_rb.reserve((std::max(total_chunks, total_slots) + 1) * sizeof(unsigned long long))) return rc;
+    if (int rc = c->b_state.reserve(total_slots * 3 * sizeof(uint32_t))) return rc;
+    if (int rc = c->b_prop.reserve((total_slots + 1) * sizeof(unsigned long long))) return rc;
+    if (int rc = c->b_meta.reserve(meta_F + meta_S + 2 * meta_wg + meta_act)) return rc;
+    if (int rc = c->b_coef.reserve((size_t)nf * cpf * sizeof(int16_t))) return rc;
+    if (int rc = c->e_tmp.reserve(E::scan_tmp_elems(std::max(total_chunks, total_slots)) * sizeof(unsigned long long))) return rc;
+    uint8_t* meta = (uint8_t*)c->b_meta.p;
+    HD::BatchFile* d_F = (HD::BatchFile*)meta;
+    HD::Setup* d_S = (HD::Setup*)(meta + meta_F);
+    unsigned* d_wg_file = (unsigned*)(meta + meta_F + meta_S);
+    unsigned* d_wg_first = (unsigned*)(meta + meta_F + meta_S + meta_wg);
+    unsigned* d_active = (unsigned*)(meta + meta_F + meta_S + 2 * meta_wg);
+
+    // scans side by side (64-byte aligned, zero padded) in pinned memory: one upload
+    for (unsigned k = 0; k < nf; ++k) {
+        uint8_t* dst = c->b_pin + (size_t)F[k].chunk0 * chunk;
+        std::memcpy(dst, files[k].scan, files[k].n);
+        std::memset(dst + files[k].n, 0, (size_t)F[k].n_chunks * chunk - files[k].n);
+    }
+    HIP_TRY(hipMemcpyAsync(c->b_scan.p, c->b_pin, scan_bytes, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d_F, F.data(), sizeof(HD::BatchFile) * nf, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d_S, setups.data(), sizeof(HD::Setup) * nf, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d_wg_file, wg_file.data(), (size_t)n_wg * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d_wg_first, wg_first.data(), (size_t)n_wg * 4, hipMemcpyHostToDevice, s));
+    lap("setup + scans up");
+
+    // 1. stuffing out
+    HIP_TRY(hipMemsetAsync(c->b_U.p, 0, u_bytes, s));
+    HIP_TRY(HD::launch_unstuff_count_batch((const uint8_t*)c->b_scan.p, d_F, nf, (unsigned)total_chunks, (uint32_t*)c->b_cnt.p, s));
+    HIP_TRY(E::launch_scan_u32((const uint32_t*)c->b_cnt.p, (unsigned long long*)c->b_rb.p, total_chunks, (unsigned long long*)c->e_tmp.p, s));
+    HIP_TRY(HD::launch_unstuff_copy_batch((const uint8_t*)c->b_scan.p, d_F, nf, (unsigned)total_chunks, (const unsigned long long*)c->b_rb.p,
+                                          (uint8_t*)c->b_U.p, s));
+    lap("unstuff");
+    // 2. speculation, confirmation, refinement -- one loop for the whole slice
+    uint32_t* d_exit = (uint32_t*)c->b_state.p;
+    uint32_t* d_last = d_exit + total_slots;
+    unsigned* d_nblocks = (unsigned*)(d_last + total_slots);
+    HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)d_exit, (int)0x80000000u, total_slots, s));
+    HIP_TRY(hipMemsetAsync(d_last, 0xFF, total_slots * 4, s));
+    HIP_TRY(hipMemsetAsync(d_nblocks, 0, total_slots * 4, s));
+    HIP_TRY(HD::launch_speculate_batch(d_S, (const uint32_t*)c->b_U.p, d_F, d_wg_file, d_wg_first, n_wg, (unsigned)total_slots,
+                                       (unsigned long long*)c->b_prop.p, d_exit, s));
+    lap("speculate");
+    std::vector<unsigned> active(nf);
+    std::vector<char> converged(nf, 0), dead(nf, 0);
+    for (unsigned k = 0; k < nf; ++k) { active[k] = usable[k] ? 1u : 0u; dead[k] = !usable[k]; }
+    for (int pass = 0; pass < 7; ++pass) {
+        bool any = false;
+        for (unsigned k = 0; k < nf; ++k) any = any || active[k];
+        if (!any) break;
+        HIP_TRY(hipMemcpyAsync(d_active, active.data(), (size_t)nf * 4, hipMemcpyHostToDevice, s));
+        HIP_TRY(HD::launch_sync_batch(d_S, (const uint32_t*)c->b_U.p, d_F, d_wg_file, d_wg_first, n_wg, d_active, d_exit, d_last, d_nblocks,
+                                      pass == 0 ? 1 : 24, s));
+        HIP_TRY(hipMemcpyAsync(F.data(), d_F, sizeof(HD::BatchFile) * nf, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        for (unsigned k = 0; k < nf; ++k) {
+            if (!active[k]) continue;
+            const unsigned moved = F[k].changed[0], pending = F[k].changed[1];
+            if (F[k].n_sub == 0) { active[k] = 0; dead[k] = 1; continue; }
+            if (moved == 0 && pending == 0) { active[k] = 0; converged[k] = 1; continue; }
+            // many proposals moved at the first look (periodic data never falls into step), or the budget is spent: per-file path
+            if ((pass == 0 && moved > F[k].n_sub / 2 + 16) || pass == 6) { active[k] = 0; dead[k] = 1; }
+        }
+        // reset the per-pass counters of the files that go on
+        for (unsigned k = 0; k < nf; ++k)
+            if (active[k]) HIP_TRY(hipMemsetAsync(&d_F[k].changed[0], 0, 2 * sizeof(unsigned), s));
+    }
+    lap("confirm + refine");
+    // 3. block index of every lane, coefficients, DC predictors -- for the files that converged
+    for (unsigned k = 0; k < nf; ++k) active[k] = converged[k] ? 1u : 0u;
+    HIP_TRY(hipMemcpyAsync(d_active, active.data(), (size_t)nf * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(c->b_cnt.p, d_nblocks, total_slots * 4, hipMemcpyDeviceToDevice, s));
+    unsigned long long* d_bb = (unsigned long long*)c->b_prop.p;          // (the proposals are dead: same buffer)
+    HIP_TRY(E::launch_scan_u32((const uint32_t*)c->b_cnt.p, d_bb, total_slots, (unsigned long long*)c->e_tmp.p, s));
+    HIP_TRY(hipMemsetAsync(c->b_coef.p, 0, (size_t)nf * cpf * sizeof(int16_t), s));
+    HIP_TRY(HD::launch_emit_batch(d_S, (const uint32_t*)c->b_U.p, d_F, d_wg_file, d_wg_first, n_wg, d_active, d_exit, d_bb, (int16_t*)c->b_coef.p, s));
+    HIP_TRY(HD::launch_dc_prefix_batch((int16_t*)c->b_coef.p, d_F, d_active, nf, s));
+    HIP_TRY(hipMemcpyAsync(F.data(), d_F, sizeof(HD::BatchFile) * nf, hipMemcpyDeviceToHost, s));
+    lap("emit + DC");
+    // 4. dequantisation + IDCT + colour conversion of the whole slice in one launch (a file that failed decodes to garbage nobody reads)
+    if (int rc = c->b_planes[plane_buf].reserve(3 * pstride * nf)) return rc;
+    uint8_t* pl = (uint8_t*)c->b_planes[plane_buf].p;
+    const uint8_t tq[3] = { (uint8_t)info.Tq[0], (uint8_t)info.Tq[1], (uint8_t)info.Tq[2] };
+    if (int rc = jpezy_dequant_idct_dev(c, (const int16_t*)c->b_coef.p, info.qt, tq, pstride, W, H, gray, (int)nf, pl, pl + pstride * nf,
+                                        pl + 2 * pstride * nf, s))
+        return rc;
+    HIP_TRY(hipStreamSynchronize(s));
+    lap("IDCT");
+    for (unsigned k = 0; k < nf; ++k) {
+        const unsigned long long data_bits = ((unsigned long long)F[k].n_bytes - F[k].removed) * 8;
+        ok[k] = converged[k] && !F[k].error && F[k].last_bit <= data_bits;
+    }
+    (void)plane;
+    return JPEZY_OK;      // the planes of the files with ok[k] wait in b_planes[plane_buf]: [r | g | b][nf][pstride]
+}
+
+}  // namespace
+
 // Many files: the per-file pipeline is latency-bound (small launches, five host synchronisations), so files are decoded
 // concurrently -- up to 8 in flight, each on a child context of its own (stream, scratch, quantiser tables), one host
 // thread per child.  Files are independent (ref decoder objects are per file): status[i] is file i's own result.
@@ -1342,6 +1547,119 @@ try {
     if (!c || n < 0 || (n > 0 && (!data || !len || !info || !r || !g || !b || !plane_cap || !status)))
         return set_err(JPEZY_E_BADARG, "decode_jpeg_batch: bad argument");
     if (n == 0) return JPEZY_OK;
+    // Fast path (round 3): files of jpezy's own layout are grouped by size and quantiser tables and go through the batch form of
+    // the GPU Huffman decoder and ONE IDCT launch per slice; whatever that path declines or cannot settle (other layouts, restart
+    // intervals, irregular streams, streams that do not converge) takes the per-file path below, file by file as before.
+    std::vector<char> done((size_t)n, 0);
+    c->b_last_fast = 0;
+    HIP_TRY(hipSetDevice(c->device));
+    {
+        struct Cand { FastFile ff; jpezy_frame_info info; bool good = false; };
+        std::vector<Cand> all((size_t)n);
+        // headers and the end of every scan (a memchr over the whole entropy-coded segment), spread over host threads
+        auto prep = [&](int i) {
+            Cand& cd = all[(size_t)i];
+            std::string err;
+            if (!data[i] || !r[i] || !g[i] || !b[i]) return;
+            if (jpezy_host::parse_header(data[i], len[i], &cd.info, &cd.ff.setup, &err) < 0) return;
+            const jpezy_frame_info& fi = cd.info;
+            const bool own = fi.ncomp == 3 && fi.precision == 8 && fi.H[0] == 2 && fi.V[0] == 2 && fi.H[1] == 1 && fi.V[1] == 1 && fi.H[2] == 1 &&
+                             fi.V[2] == 1 && fi.restart_interval == 0 && fi.width > 0 && fi.height > 0;
+            if (!own || cd.ff.setup.scan_pos >= len[i] || plane_cap[i] < (size_t)fi.width * fi.height) return;
+            bool tabs = true;
+            for (int q = 0; q < 3 && tabs; ++q)
+                tabs = cd.ff.setup.Td[q] >= 0 && cd.ff.setup.Td[q] <= 2 && cd.ff.setup.present[cd.ff.setup.Td[q]] && cd.ff.setup.present[4 + cd.ff.setup.Td[q]];
+            if (!tabs) return;
+            const uint8_t* scan = data[i] + cd.ff.setup.scan_pos;
+            size_t ns = len[i] - cd.ff.setup.scan_pos;
+            for (const uint8_t* q = scan; (q = (const uint8_t*)std::memchr(q, 0xFF, (size_t)(scan + ns - q))) != nullptr; ++q) {
+                if (q + 1 >= scan + ns) { ns = (size_t)(q - scan); break; }
+                if (q[1] != 0x00) { ns = (size_t)(q - scan); break; }
+            }
+            const size_t nblk = (size_t)fi.mcu_cols * fi.mcu_rows * 6;
+            if (ns == 0 || nblk > 4 * len[i]) return;
+            cd.ff.index = i; cd.ff.scan = scan; cd.ff.n = ns;
+            cd.good = true;
+        };
+        {
+            unsigned hwp = std::thread::hardware_concurrency();
+            const int nt = (int)std::max(1u, std::min<unsigned>(std::min<unsigned>(hwp ? hwp : 4u, 8u), (unsigned)(n + 15) / 16));
+            std::atomic<int> next{ 0 };
+            auto work = [&] { for (int i = next.fetch_add(1); i < n; i = next.fetch_add(1)) prep(i); };
+            std::vector<std::thread> pool;
+            for (int t = 1; t < nt; ++t) pool.emplace_back(work);
+            work();
+            for (auto& t : pool) t.join();
+        }
+        std::vector<const Cand*> cand;
+        for (const Cand& cd : all)
+            if (cd.good) cand.push_back(&cd);
+        // the planes of slice k go down to the caller's buffers on a thread and a stream of their own while slice k + 1 is decoded
+        // (two plane buffers): a 1080p file is 6.2 MB of planes, PCIe is what bounds a batch
+        hipStream_t s_down = nullptr;
+        HIP_TRY(hipStreamCreateWithFlags(&s_down, hipStreamNonBlocking));
+        std::thread drainer[2];
+        std::atomic<int> drain_err{ 0 };
+        int slice_no = 0;
+        auto join_all = [&] { for (auto& t : drainer) if (t.joinable()) t.join(); };
+        std::vector<char> taken(cand.size(), 0);
+        for (size_t a = 0; a < cand.size(); ++a) {
+            if (taken[a]) continue;
+            // the group of cand[a]: same size, same quantiser tables for the three components
+            std::vector<FastFile> grp;
+            auto same_group = [&](const jpezy_frame_info& x, const jpezy_frame_info& y) {
+                if (x.width != y.width || x.height != y.height) return false;
+                for (int q = 0; q < 3; ++q)
+                    if (std::memcmp(x.qt[x.Tq[q] & 3], y.qt[y.Tq[q] & 3], sizeof x.qt[0])) return false;
+                return true;
+            };
+            for (size_t k = a; k < cand.size(); ++k)
+                if (!taken[k] && same_group(cand[a]->info, cand[k]->info)) { taken[k] = 1; grp.push_back(cand[k]->ff); }
+            if (grp.size() < 2) continue;                                   // a single file gains nothing here
+            const jpezy_frame_info& gi = cand[a]->info;
+            // slices: at most 16 files (JPEZY_BATCH_SLICE: development knob) and ~1.5 GB of planes + coefficients at a time
+            const size_t per_file = (size_t)gi.width * gi.height * 3 + (size_t)gi.mcu_cols * gi.mcu_rows * 6 * 128;
+            static const size_t slice_files = [] { const char* e = std::getenv("JPEZY_BATCH_SLICE"); const int v = e ? std::atoi(e) : 16; return (size_t)(v < 2 ? 2 : v > 512 ? 512 : v); }();
+            const size_t per_slice = std::max<size_t>(2, std::min<size_t>(slice_files, ((size_t)3 << 29) / std::max<size_t>(per_file, 1)));
+            const size_t plane = (size_t)gi.width * gi.height, pstride = (plane + 15) & ~(size_t)15;
+            for (size_t s0 = 0; s0 < grp.size(); s0 += per_slice) {
+                std::vector<FastFile> slice(grp.begin() + s0, grp.begin() + std::min(grp.size(), s0 + per_slice));
+                std::vector<char> okv;
+                const int pb = slice_no & 1;
+                if (drainer[pb].joinable()) drainer[pb].join();             // the slice that used this plane buffer has been delivered
+                if (decode_slice_fast(c, slice, gi, gray, pb, okv) != JPEZY_OK) continue;      // (the per-file path reports what is wrong)
+                ++slice_no;
+                std::vector<int> idx;                                        // (k, caller index) of the files decoded here
+                for (size_t k = 0; k < slice.size(); ++k)
+                    if (okv[k]) {
+                        const int i = slice[k].index;
+                        info[i] = all[(size_t)i].info;
+                        status[i] = JPEZY_OK;
+                        done[(size_t)i] = 1;
+                        ++c->b_last_fast;
+                        idx.push_back((int)k); idx.push_back(i);
+                    }
+                const uint8_t* pl = (const uint8_t*)c->b_planes[pb].p;
+                const size_t nfs = slice.size();
+                const int device = c->device;
+                drainer[pb] = std::thread([=, &drain_err] {
+                    if (hipSetDevice(device) != hipSuccess) { drain_err.store(1); return; }
+                    for (size_t q = 0; q + 1 < idx.size(); q += 2) {
+                        const size_t k = (size_t)idx[q];
+                        const int i = idx[q + 1];
+                        if (hipMemcpyAsync(r[i], pl + pstride * k, plane, hipMemcpyDeviceToHost, s_down) != hipSuccess ||
+                            hipMemcpyAsync(g[i], pl + pstride * (nfs + k), plane, hipMemcpyDeviceToHost, s_down) != hipSuccess ||
+                            hipMemcpyAsync(b[i], pl + pstride * (2 * nfs + k), plane, hipMemcpyDeviceToHost, s_down) != hipSuccess)
+                            drain_err.store(1);
+                    }
+                    if (hipStreamSynchronize(s_down) != hipSuccess) drain_err.store(1);
+                });
+            }
+        }
+        join_all();
+        (void)hipStreamDestroy(s_down);
+        if (drain_err.load()) return set_err(JPEZY_E_HIP, "decode_jpeg_batch: copying the planes to the host failed");
+    }
     unsigned hw = std::thread::hardware_concurrency();
     if (hw == 0) hw = 4;
     const int nw = (int)std::min<unsigned>(std::min<unsigned>((unsigned)n, hw), 8u);
@@ -1356,6 +1674,7 @@ try {
     auto work = [&](int k) {
         jpezy_ctx* w = c->workers[(size_t)k];
         for (int i = k; i < n; i += nw) {
+            if (done[(size_t)i]) continue;
             status[i] = jpezy_decode_jpeg(w, data[i], len[i], gray, &info[i], r[i], g[i], b[i], plane_cap[i]);
             if (status[i] < 0) msg[(size_t)i] = g_err;               // this thread's message
         }
@@ -1371,6 +1690,7 @@ try {
 JPEZY_CATCH
 
 int jpezy_ctx_last_huffdec_passes(jpezy_ctx* c) { return c ? c->h_last_passes : 0; }
+int jpezy_ctx_last_batch_fast_count(jpezy_ctx* c) { return c ? c->b_last_fast : 0; }
 void jpezy_ctx_set_huffdec_min_bytes(jpezy_ctx* c, size_t n) { if (c) c->h_min_bytes = n; }
 
 int jpezy_read_jpeg(const uint8_t* data, size_t len, jpezy_frame_info* info, int16_t* coeffs, size_t coeff_cap)

@@ -28,6 +28,36 @@ struct Setup {
 unsigned subseq_bits();
 size_t chunk_bytes();
 
+// ---- batch form (round 3): many files per launch.  Every kernel above exists once more with the file as an index: a file owns a
+// range of 64-byte chunks of the concatenated scans (unstuffing) and a range of subsequence slots (decoding); a workgroup never
+// straddles two files (wg_file / wg_first say whose subsequences it takes), every file brings its own tables. ----
+struct BatchFile {
+    unsigned chunk0, n_chunks;          // 64-byte chunks of the concatenated scan buffer: bytes [chunk0 * 64, chunk0 * 64 + n_bytes)
+    unsigned n_bytes;
+    unsigned sub0, n_sub_max, n_sub;    // subsequence slots; n_sub = the ones that hold data once the stuffing is gone (device)
+    unsigned long long u_off;           // byte offset of the file's unstuffed stream in U (a multiple of 4)
+    unsigned u_words;                   // 32-bit words of U the file may read
+    unsigned removed;                   // stuffing bytes removed (device)
+    unsigned long long coeff_off;       // int16 offset of the file's coefficients
+    unsigned total_blocks, nmcu, bpm, ncomp;
+    unsigned cstart[3], ccount[3];      // component c owns blocks [cstart, cstart + ccount) of every MCU
+    unsigned changed[2];                // per pass: lanes that moved / lanes left pending (device)
+    unsigned error, pad;
+    unsigned long long last_bit;
+};
+
+hipError_t launch_unstuff_count_batch(const uint8_t* S, const BatchFile* F, unsigned n_files, unsigned total_chunks, uint32_t* counts, hipStream_t s);
+hipError_t launch_unstuff_copy_batch(const uint8_t* S, BatchFile* F, unsigned n_files, unsigned total_chunks, const unsigned long long* removed_before,
+                                     uint8_t* U, hipStream_t s);       // also fills F[].removed, n_sub and resets the per-file flags
+hipError_t launch_speculate_batch(const Setup* setups, const uint32_t* U, const BatchFile* F, const unsigned* wg_file, const unsigned* wg_first,
+                                  unsigned n_wg, unsigned n_slots, unsigned long long* proposal, uint32_t* exit_state, hipStream_t s);
+// active[f] (host-written between the phases): refinement passes -- the file still has lanes to settle; emit / DC pass -- the file converged
+hipError_t launch_sync_batch(const Setup* setups, const uint32_t* U, BatchFile* F, const unsigned* wg_file, const unsigned* wg_first, unsigned n_wg,
+                             const unsigned* active, uint32_t* exit_state, uint32_t* last_entry, unsigned* nblocks, int max_inner, hipStream_t s);
+hipError_t launch_emit_batch(const Setup* setups, const uint32_t* U, BatchFile* F, const unsigned* wg_file, const unsigned* wg_first, unsigned n_wg,
+                             const unsigned* active, const uint32_t* exit_state, const unsigned long long* blocks_before, int16_t* coeffs, hipStream_t s);
+hipError_t launch_dc_prefix_batch(int16_t* coeffs, const BatchFile* F, const unsigned* active, unsigned n_files, hipStream_t s);
+
 hipError_t launch_unstuff_count(const uint8_t* S, size_t n, uint32_t* counts, hipStream_t s);
 hipError_t launch_unstuff_copy(const uint8_t* S, size_t n, const unsigned long long* removed_before, uint8_t* U, hipStream_t s);
 // speculation pass: fills exit_state with the best available guess of every subsequence's true exit state

@@ -317,6 +317,241 @@ __global__ __launch_bounds__(256) void unstuff_copy_kernel(const uint8_t* S, siz
     }
 }
 
+// ======================================================================================================
+// Batch form: the same kernels with the file as an index (jpezy_huffdec.h).  A single 1080p file keeps 80 waves busy
+// for a chain of launches that is pure latency; 256 of them fill the chip for the same chain.
+// ======================================================================================================
+__device__ __forceinline__ unsigned file_of_chunk(const BatchFile* F, unsigned n_files, unsigned c)
+{
+    unsigned lo = 0, hi = n_files;                  // F[lo].chunk0 <= c < F[hi].chunk0
+    while (hi - lo > 1) {
+        const unsigned mid = (lo + hi) >> 1;
+        if (F[mid].chunk0 <= c) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(256) void unstuff_count_batch_kernel(const uint8_t* S, const BatchFile* F, unsigned n_files, unsigned total_chunks,
+                                                                  uint32_t* counts)
+{
+    const unsigned c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= total_chunks) return;
+    const unsigned f = file_of_chunk(F, n_files, c);
+    const size_t base = (size_t)F[f].chunk0 * CHUNK, n = F[f].n_bytes;
+    const size_t b0 = (size_t)(c - F[f].chunk0) * CHUNK;
+    unsigned cnt = 0;
+    if (b0 < n) {
+        uint8_t prev = b0 ? S[base + b0 - 1] : 0;
+        const size_t e = b0 + CHUNK < n ? b0 + CHUNK : n;
+        for (size_t i = b0; i < e; ++i) {
+            const uint8_t v = S[base + i];
+            if (v == 0x00 && prev == 0xFF) { ++cnt; prev = 0x01; } else prev = v;
+        }
+    }
+    counts[c] = cnt;
+}
+
+__global__ __launch_bounds__(256) void unstuff_copy_batch_kernel(const uint8_t* S, BatchFile* F, unsigned n_files, unsigned total_chunks,
+                                                                 const unsigned long long* removed_before, uint8_t* U)
+{
+    const unsigned c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= total_chunks) return;
+    const unsigned f = file_of_chunk(F, n_files, c);
+    const size_t base = (size_t)F[f].chunk0 * CHUNK, n = F[f].n_bytes;
+    const size_t b0 = (size_t)(c - F[f].chunk0) * CHUNK;
+    const unsigned long long rb0 = removed_before[F[f].chunk0];
+    if (c == F[f].chunk0) {                          // the file's first chunk also publishes the file's totals and resets its flags
+        const unsigned removed = (unsigned)(removed_before[F[f].chunk0 + F[f].n_chunks] - rb0);
+        F[f].removed = removed;
+        F[f].n_sub = (unsigned)((((unsigned long long)n - removed) * 8 + SUBSEQ_BITS - 1) / SUBSEQ_BITS);
+        F[f].changed[0] = F[f].changed[1] = 0;
+        F[f].error = 0;
+        F[f].last_bit = ~0ull;
+    }
+    if (b0 >= n) return;
+    uint8_t* dst = U + F[f].u_off + b0 - (removed_before[c] - rb0);
+    uint8_t prev = b0 ? S[base + b0 - 1] : 0;
+    const size_t e = b0 + CHUNK < n ? b0 + CHUNK : n;
+    for (size_t i = b0; i < e; ++i) {
+        const uint8_t v = S[base + i];
+        if (v == 0x00 && prev == 0xFF) { prev = 0x01; continue; }
+        *dst++ = v;
+        prev = v;
+    }
+}
+
+__device__ __forceinline__ void load_setup(Setup& S, const Setup* g)
+{
+    const uint4* src = reinterpret_cast<const uint4*>(g);
+    uint4* dst = reinterpret_cast<uint4*>(&S);
+    for (unsigned i = threadIdx.x; i < sizeof(Setup) / 16; i += WGS) dst[i] = src[i];
+}
+static_assert(sizeof(Setup) % 16 == 0, "Setup is copied in 16-byte pieces");
+
+__global__ __launch_bounds__(WGS) void spec_batch_kernel(const Setup* setups, const uint32_t* U, const BatchFile* F, const unsigned* wg_file,
+                                                         const unsigned* wg_first, unsigned long long* proposal, unsigned overflow)
+{
+    __shared__ Setup S;
+    __shared__ uint32_t win[WINDOW_WORDS];
+    const unsigned f = wg_file[blockIdx.x], i0 = wg_first[blockIdx.x], n_sub = F[f].n_sub;
+    if (i0 >= n_sub) return;                                            // (workgroup-uniform: the slots were sized before unstuffing)
+    load_setup(S, setups + f);
+    load_window(win, U + F[f].u_off / 4, i0, F[f].u_words);
+    __syncthreads();
+    const unsigned i = i0 + threadIdx.x;
+    if (i >= n_sub) return;
+    unsigned long long* prop = proposal + F[f].sub0;
+    Cursor c;
+    c.init(win, (unsigned long long)i0 * SUBSEQ_BITS, (unsigned long long)i * SUBSEQ_BITS);
+    unsigned b = 0, k = 0, nb = 0;
+    for (unsigned r = 0; r <= overflow && i + r < n_sub; ++r) {
+        const unsigned long long end = (unsigned long long)(i + r + 1) * SUBSEQ_BITS;
+        run_subsequence<false>(S, c, end, b, k, nb, 0, nullptr);
+        const unsigned long long rank = i == 0 ? 0xFFFFull : r;
+        atomicMax(prop + i + r, (rank << 32) | pack_state((unsigned)(c.pos - end), b, k));
+    }
+}
+
+__global__ __launch_bounds__(WGS) void sync_batch_kernel(const Setup* setups, const uint32_t* U, BatchFile* F, const unsigned* wg_file,
+                                                         const unsigned* wg_first, const unsigned* active, uint32_t* exit_state_all,
+                                                         uint32_t* last_entry_all, unsigned* nblocks_all, int max_inner)
+{
+    __shared__ Setup S;
+    __shared__ uint32_t win[WINDOW_WORDS];
+    __shared__ uint32_t sh_exit[WGS + 1];
+    const unsigned f = wg_file[blockIdx.x], i0 = wg_first[blockIdx.x], n_sub = F[f].n_sub;
+    if (i0 >= n_sub || !active[f]) return;                              // workgroup-uniform
+    load_setup(S, setups + f);
+    load_window(win, U + F[f].u_off / 4, i0, F[f].u_words);
+    uint32_t* exit_state = exit_state_all + F[f].sub0;
+    uint32_t* last_entry = last_entry_all + F[f].sub0;
+    unsigned* nblocks_out = nblocks_all + F[f].sub0;
+    const unsigned t = threadIdx.x, i = i0 + t;
+    const bool live = i < n_sub;
+    uint32_t my_last = live ? last_entry[i] : 0u, my_exit = live ? exit_state[i] : 0u;
+    const uint32_t exit_before = my_exit;
+    unsigned nb = live ? nblocks_out[i] : 0u;
+    sh_exit[t + 1] = my_exit;
+    if (t == 0) sh_exit[0] = i0 ? exit_state[i0 - 1] : pack_state(0, 0, 0);
+    __syncthreads();
+    for (int inner = 0; inner < max_inner; ++inner) {
+        const uint32_t entry = sh_exit[t];
+        bool redo = live && entry != my_last;
+        __syncthreads();
+        if (redo) {
+            my_last = entry;
+            nb = 0;
+            if (entry & 0x40000000u) {
+                my_exit = STATE_ERR;
+            } else {
+                Cursor c;
+                c.init(win, (unsigned long long)i0 * SUBSEQ_BITS, (unsigned long long)i * SUBSEQ_BITS + ((entry >> 16) & 0x3FFFu));
+                unsigned b = (entry >> 8) & 0xFFu, k = entry & 0xFFu;
+                const unsigned long long end = (unsigned long long)(i + 1) * SUBSEQ_BITS;
+                run_subsequence<false>(S, c, end, b, k, nb, 0, nullptr);
+                my_exit = pack_state((unsigned)(c.pos - end), b, k);
+            }
+            redo = sh_exit[t + 1] != my_exit;
+            sh_exit[t + 1] = my_exit;
+        }
+        if (!__syncthreads_or(redo)) break;
+    }
+    if (live) {
+        last_entry[i] = my_last;
+        nblocks_out[i] = nb;
+        const bool pending = sh_exit[t] != my_last;
+        if (my_exit != exit_before) {
+            exit_state[i] = my_exit;
+            atomicAdd(&F[f].changed[0], 1u);
+        } else if (pending) {
+            atomicAdd(&F[f].changed[1], 1u);
+        }
+    }
+}
+
+__global__ __launch_bounds__(WGS) void emit_batch_kernel(const Setup* setups, const uint32_t* U, BatchFile* F, const unsigned* wg_file,
+                                                         const unsigned* wg_first, const unsigned* active, const uint32_t* exit_state_all,
+                                                         const unsigned long long* blocks_before_all, int16_t* coeffs)
+{
+    __shared__ Setup S;
+    __shared__ uint32_t win[WINDOW_WORDS];
+    const unsigned f = wg_file[blockIdx.x], i0 = wg_first[blockIdx.x], n_sub = F[f].n_sub;
+    if (i0 >= n_sub || !active[f]) return;                              // active: here "the file converged" (set by the host)
+    load_setup(S, setups + f);
+    load_window(win, U + F[f].u_off / 4, i0, F[f].u_words);
+    __syncthreads();
+    const unsigned i = i0 + threadIdx.x;
+    if (i >= n_sub) return;
+    const uint32_t* exit_state = exit_state_all + F[f].sub0;
+    const unsigned long long g0 = blocks_before_all[F[f].sub0 + i] - blocks_before_all[F[f].sub0];
+    if (g0 >= S.total_blocks) return;
+    const uint32_t entry = i ? exit_state[i - 1] : pack_state(0, 0, 0);
+    if (entry & 0x40000000u) { F[f].error = 1u; return; }
+    int16_t* out = coeffs + F[f].coeff_off;
+    Cursor c;
+    c.init(win, (unsigned long long)i0 * SUBSEQ_BITS, (unsigned long long)i * SUBSEQ_BITS + ((entry >> 16) & 0x3FFFu));
+    unsigned b = (entry >> 8) & 0xFFu, k = entry & 0xFFu, nb = 0;
+    const unsigned long long end = (unsigned long long)(i + 1) * SUBSEQ_BITS;
+    while (c.pos < end && g0 + nb < S.total_blocks) {
+        if (!run_subsequence<true>(S, c, c.pos + 1, b, k, nb, g0, out)) { F[f].error = 1u; return; }
+    }
+    if (g0 + nb >= S.total_blocks && g0 < S.total_blocks) F[f].last_bit = c.pos;
+}
+
+// DC differences -> absolute values (pre_DC, ref :611-614): one workgroup per (file, component) walks the component's DC terms in
+// scan order, 2048 per step with a running carry
+__global__ __launch_bounds__(256) void dc_prefix_batch_kernel(int16_t* coeffs, const BatchFile* F, const unsigned* active)
+{
+    __shared__ long long wsum[4];
+    const unsigned f = blockIdx.x, comp = blockIdx.y;
+    if (comp >= F[f].ncomp || !active[f]) return;
+    const unsigned count = F[f].ccount[comp], start = F[f].cstart[comp], bpm = F[f].bpm;
+    const size_t nd = (size_t)F[f].nmcu * count;
+    int16_t* co = coeffs + F[f].coeff_off;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    long long carry = 0;
+    for (size_t j0 = 0; j0 < nd; j0 += 2048) {
+        long long v[8], s = 0;
+        const size_t jb = j0 + (size_t)threadIdx.x * 8;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const size_t j = jb + q;
+            v[q] = 0;
+            if (j < nd) {
+                const size_t mcu = j / count, t = j - mcu * count;
+                v[q] = co[(mcu * bpm + start + t) * 64];
+            }
+            s += v[q];
+        }
+        long long inc = s;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const long long o = __shfl_up(inc, d, 64);
+            if (lane >= d) inc += o;
+        }
+        if (lane == 63) wsum[wv] = inc;
+        __syncthreads();
+        long long woff = 0, tot = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (q < wv) woff += wsum[q];
+            tot += wsum[q];
+        }
+        long long run = carry + woff + inc - s;        // sum of everything before this thread's first element
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const size_t j = jb + q;
+            run += v[q];
+            if (j < nd) {
+                const size_t mcu = j / count, t = j - mcu * count;
+                co[(mcu * bpm + start + t) * 64] = (int16_t)run;
+            }
+        }
+        carry += tot;
+        __syncthreads();
+    }
+}
+
 // ---- launchers ----
 unsigned subseq_bits() { return SUBSEQ_BITS; }
 size_t chunk_bytes() { return CHUNK; }
@@ -374,6 +609,62 @@ hipError_t launch_dc_scatter(int16_t* coeffs, unsigned bpm, unsigned start, unsi
 {
     if (!n) return hipSuccess;
     hipLaunchKernelGGL(dc_scatter_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, coeffs, bpm, start, count, n, before);
+    return hipGetLastError();
+}
+
+
+static unsigned spec_overflow()
+{
+    static const unsigned overflow = [] {
+        const char* e = std::getenv("JPEZY_HUFFDEC_OVERFLOW");
+        const int v = e ? std::atoi(e) : OVERFLOW_DEFAULT;
+        return (unsigned)(v < 0 ? 0 : v > OVERFLOW ? OVERFLOW : v);
+    }();
+    return overflow;
+}
+
+hipError_t launch_unstuff_count_batch(const uint8_t* S, const BatchFile* F, unsigned n_files, unsigned total_chunks, uint32_t* counts, hipStream_t s)
+{
+    if (!total_chunks) return hipSuccess;
+    hipLaunchKernelGGL(unstuff_count_batch_kernel, dim3((total_chunks + 255) / 256), dim3(256), 0, s, S, F, n_files, total_chunks, counts);
+    return hipGetLastError();
+}
+hipError_t launch_unstuff_copy_batch(const uint8_t* S, BatchFile* F, unsigned n_files, unsigned total_chunks, const unsigned long long* removed_before,
+                                     uint8_t* U, hipStream_t s)
+{
+    if (!total_chunks) return hipSuccess;
+    hipLaunchKernelGGL(unstuff_copy_batch_kernel, dim3((total_chunks + 255) / 256), dim3(256), 0, s, S, F, n_files, total_chunks, removed_before, U);
+    return hipGetLastError();
+}
+hipError_t launch_speculate_batch(const Setup* setups, const uint32_t* U, const BatchFile* F, const unsigned* wg_file, const unsigned* wg_first,
+                                  unsigned n_wg, unsigned n_slots, unsigned long long* proposal, uint32_t* exit_state, hipStream_t s)
+{
+    if (!n_wg) return hipSuccess;
+    hipError_t e = hipMemsetAsync(proposal, 0, (size_t)n_slots * sizeof(unsigned long long), s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(spec_batch_kernel, dim3(n_wg), dim3(WGS), 0, s, setups, U, F, wg_file, wg_first, proposal, spec_overflow());
+    hipLaunchKernelGGL(adopt_proposals_kernel, dim3((n_slots + 255) / 256), dim3(256), 0, s, proposal, n_slots, exit_state);
+    return hipGetLastError();
+}
+hipError_t launch_sync_batch(const Setup* setups, const uint32_t* U, BatchFile* F, const unsigned* wg_file, const unsigned* wg_first, unsigned n_wg,
+                             const unsigned* active, uint32_t* exit_state, uint32_t* last_entry, unsigned* nblocks, int max_inner, hipStream_t s)
+{
+    if (!n_wg) return hipSuccess;
+    hipLaunchKernelGGL(sync_batch_kernel, dim3(n_wg), dim3(WGS), 0, s, setups, U, F, wg_file, wg_first, active, exit_state, last_entry, nblocks,
+                       max_inner < 1 ? 1 : max_inner > WGS + 1 ? WGS + 1 : max_inner);
+    return hipGetLastError();
+}
+hipError_t launch_emit_batch(const Setup* setups, const uint32_t* U, BatchFile* F, const unsigned* wg_file, const unsigned* wg_first, unsigned n_wg,
+                             const unsigned* active, const uint32_t* exit_state, const unsigned long long* blocks_before, int16_t* coeffs, hipStream_t s)
+{
+    if (!n_wg) return hipSuccess;
+    hipLaunchKernelGGL(emit_batch_kernel, dim3(n_wg), dim3(WGS), 0, s, setups, U, F, wg_file, wg_first, active, exit_state, blocks_before, coeffs);
+    return hipGetLastError();
+}
+hipError_t launch_dc_prefix_batch(int16_t* coeffs, const BatchFile* F, const unsigned* active, unsigned n_files, hipStream_t s)
+{
+    if (!n_files) return hipSuccess;
+    hipLaunchKernelGGL(dc_prefix_batch_kernel, dim3(n_files, 3), dim3(256), 0, s, coeffs, F, active);
     return hipGetLastError();
 }
 

@@ -251,3 +251,63 @@ def test_differential_fuzz_small(J, ctx):
     root = Path(__file__).resolve().parent.parent
     out = subprocess.run([sys.executable, str(root / "tools" / "fuzz_huffdec.py"), "30"], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "files identical" in out.stdout, out.stdout + out.stderr
+
+
+def test_decode_jpeg_batch_fast_path(J, ctx, oracle):
+    """The batch form of the Huffman decoder kernels (round 3): files of jpezy's own layout and one size are decoded TOGETHER --
+    one sequence of launches for all their scans (per-file tables, workgroups that never straddle files), one IDCT launch per
+    slice.  Several groups (two sizes, two quantiser settings via libjpeg 4:2:0 files of two qualities), more files than a
+    slice holds, smooth content (few symbols per subsequence), flat content (periodic: never synchronises -> per-file path),
+    a truncated and a bit-flipped file in the middle of a group (their own errors, the neighbours untouched); every decodable
+    file equals the oracle's decoder (ref decoder/jpezy_decoder.hpp:76-134)."""
+    from PIL import Image
+    rng = np.random.default_rng(2026)
+    files = []
+    for k in range(70):                                   # group A: 70 files 208x120 (a slice holds 64)
+        r, g, b = oracle.synth_rgb(208, 120, frame=500 + k)
+        files.append(ctx.encode_jpeg(r, g, b, 208, 120))
+    for k in range(6):                                    # group B: another size
+        r, g, b = oracle.synth_rgb(333, 77, frame=900 + k)
+        files.append(ctx.encode_jpeg(r, g, b, 333, 77))
+    yy, xx = np.mgrid[0:120, 0:208]
+    sm = ((xx * 3 + yy * 2) // 8 % 256).astype(np.uint8).reshape(-1)
+    files.append(ctx.encode_jpeg(sm, sm[::-1].copy(), np.roll(sm, 77), 208, 120))       # smooth, same group as A
+    flat = np.full(208 * 120, 90, np.uint8)
+    files.append(ctx.encode_jpeg(flat, flat, flat, 208, 120))                            # flat
+    for q in (85, 85, 85, 40, 40):                        # libjpeg 4:2:0 = jpezy's layout with other tables: groups C (q85) and D (q40)
+        img = rng.integers(0, 256, (120, 208, 3), dtype=np.uint8)
+        buf = io.BytesIO()
+        Image.fromarray(img).save(buf, "JPEG", quality=q, subsampling=2)
+        files.append(buf.getvalue())
+    bad_trunc, bad_flip = 10, 20
+    files[bad_trunc] = files[bad_trunc][: len(files[bad_trunc]) * 2 // 3]
+    fl = bytearray(files[bad_flip]); fl[700] ^= 0x5A; files[bad_flip] = bytes(fl)
+    for gray in (False, True):
+        got = ctx.decode_jpeg_batch(files, gray=gray, raise_on_error=False)
+        assert len(got) == len(files)
+        # the fast path took what it should: the 68 intact files of group A, group B, the smooth file, groups C and D
+        # (the flat file never synchronises, the two damaged ones are the per-file path's to judge)
+        assert ctx.last_batch_fast_count() >= 68 + 6 + 1 + 5, ctx.last_batch_fast_count()
+        for i, f in enumerate(files):
+            try:
+                want = oracle.decode_jpeg(f, gray)
+            except Exception:
+                want = None
+            if want is None:
+                assert got[i] is None, i
+                continue
+            assert got[i] is not None, i
+            info, rr, gg, bb = got[i]
+            n = info.width * info.height
+            for a, e in zip((rr, gg, bb), want[-3:]):
+                assert np.array_equal(a, np.asarray(e).reshape(-1)[:n]), i
+    # and with the tolerance switch the batch stays within one of the exact result
+    exact = ctx.decode_jpeg_batch(files[30:40])
+    ctx.set_decode_tolerance(1)
+    try:
+        tol = ctx.decode_jpeg_batch(files[30:40])
+    finally:
+        ctx.set_decode_tolerance(0)
+    for a, b_ in zip(exact, tol):
+        for k in (1, 2, 3):
+            assert int(np.abs(a[k].astype(np.int16) - b_[k].astype(np.int16)).max()) <= 1

@@ -74,7 +74,36 @@ def main():
     tb = time.perf_counter() - t
     same = all(np.array_equal(a[1], b_[1]) and np.array_equal(a[3], b_[3]) for a, b_ in zip(single, batch))
     print(f"32 x 1920x1080 random pixels ({len(files[0]) / 1e6:.2f} MB each), .jpg on the host -> planes on the host: one call per file "
-          f"{ts * 1e3 / 32:.2f} ms/file, jpezy_decode_jpeg_batch {tb * 1e3 / 32:.2f} ms/file ({W * H * 32 / tb / 1e6:.0f} Mpx/s); identical: {same}")
+          f"{ts * 1e3 / 32:.2f} ms/file, jpezy_decode_jpeg_batch {tb * 1e3 / 32:.2f} ms/file ({W * H * 32 / tb / 1e6:.0f} Mpx/s, "
+          f"{ctx.last_batch_fast_count()} files through the batch form of the kernels); identical: {same}")
+    # 256 x 1080p through the C-ABI with preallocated, touched output planes (the Python wrapper's allocations
+    # are not part of the path); random pixels (0.66 MB scans) and picture-like content (smaller scans)
+    import ctypes as C
+    from jpezy_amd import api
+    lib = api.load_library()
+    for name, make in (("random pixels", lambda k: [np.random.default_rng(1000 + k).integers(0, 256, W * H, dtype=np.uint8) for _ in range(3)]),
+                       ("smooth + noise", lambda k: [np.clip(((np.mgrid[0:H, 0:W][1] * (2 + k % 3) + np.mgrid[0:H, 0:W][0] * 3) // 8 % 256
+                                                              + np.random.default_rng(k).normal(0, 6, (H, W))), 0, 255).astype(np.uint8).reshape(-1)] * 3)):
+        base = [ctx.encode_jpeg(*make(k), W, H) for k in range(16)]
+        n = 256
+        fl = [base[k % 16] for k in range(n)]
+        arrs = [np.frombuffer(f, dtype=np.uint8) for f in fl]
+        planes = [[np.zeros(W * H, dtype=np.uint8) for _ in range(3)] for _ in range(n)]
+        vpa = C.c_void_p * n
+        data = vpa(*[a.ctypes.data for a in arrs]); lens = (C.c_size_t * n)(*[a.size for a in arrs])
+        rr, gg, bb = (vpa(*[p[k].ctypes.data for p in planes]) for k in range(3))
+        caps = (C.c_size_t * n)(*[W * H] * n); status = (C.c_int * n)(); infos = (api.FrameInfo * n)()
+        def call():
+            assert lib.jpezy_decode_jpeg_batch(ctx._h, n, data, lens, 0, infos, rr, gg, bb, caps, status) == 0
+        call()
+        ts = []
+        for _ in range(3):
+            t = time.perf_counter(); call(); ts.append(time.perf_counter() - t)
+        tb = min(ts)
+        ref = ctx.decode_jpeg(fl[5])
+        ok = np.array_equal(planes[5][0], ref[1]) and np.array_equal(planes[255][2], ctx.decode_jpeg(fl[255])[3])
+        print(f"256 x 1920x1080 {name} ({len(fl[0]) / 1e6:.2f} MB each): jpezy_decode_jpeg_batch {tb * 1e3:.1f} ms = {tb * 1e3 / n:.3f} ms/file "
+              f"({W * H * n / tb / 1e6:.0f} Mpx/s; {ctx.last_batch_fast_count()} files through the batch form); spot checks identical: {ok}")
 
 
 if __name__ == "__main__":

@@ -948,6 +948,34 @@ __global__ __launch_bounds__(64 * WPB, GRAY ? JPEZY_DEC_WAVES_GRAY : JPEZY_DEC_W
 #pragma unroll
         for (int q = 0; q < 4; ++q) Rw[q] = Gw[q] = Bw[q] = clamp_pack4(Y + 4 * q);
     }
+#ifdef JPEZY_DEC_FULLLINE
+    // Experiment (round 3): the two waves of a workgroup hold the two 64-byte halves of every 128-byte line of their 16 pixel rows.
+    // They swap through LDS so that wave 0 stores rows 0..7 and wave 1 rows 8..15 of BOTH quads: eight lanes = one whole line.
+    if (ALIGNED && !GRAY && WPB == 2) {
+        const unsigned q0 = blockIdx.x * 2u;                                         // the workgroup's first quad
+        const int qx0 = (int)q0 - (int)fast_div(q0, p.qpr_magic, p.qpr_shift) * p.quads_per_row;
+        const bool pair_ok = (p.quads_per_row & 1) == 0 && (qx0 + 2) * 64 <= W && q0 + 1u < (unsigned)(p.mcu_rows * p.quads_per_row);   // workgroup-uniform
+        if (pair_ok) {
+            wave_sync();                                                             // (the slice's earlier uses are over)
+            uint4* slot = reinterpret_cast<uint4*>(reinterpret_cast<char*>(lds_all[wave]) + lane * 48);
+            slot[0] = make_uint4(Rw[0], Rw[1], Rw[2], Rw[3]);
+            slot[1] = make_uint4(Gw[0], Gw[1], Gw[2], Gw[3]);
+            slot[2] = make_uint4(Bw[0], Bw[1], Bw[2], Bw[3]);
+            __syncthreads();
+            const int r8 = wave * 8 + (lane >> 3), seg = lane & 7;
+            const uint4* src = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(lds_all[seg >> 2]) + ((r8 << 2) | (seg & 3)) * 48);
+            const uint4 vR = src[0], vG = src[1], vB = src[2];
+            const int pyy = mcu_y * 16 + r8;
+            if (pyy < H) {
+                const size_t off = (size_t)frame * p.plane_stride + (size_t)pyy * W + (size_t)qx0 * 64 + (size_t)seg * 16;
+                nt_store16(reinterpret_cast<uint4*>(p.r + off), vR);
+                nt_store16(reinterpret_cast<uint4*>(p.g + off), vG);
+                nt_store16(reinterpret_cast<uint4*>(p.b + off), vB);
+            }
+            return;
+        }
+    }
+#endif
     const int py = mcu_y * 16 + row;
     if (live && py < H) {
         uint8_t* orp = p.r + (size_t)frame * p.plane_stride + (size_t)py * W;

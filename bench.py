@@ -51,6 +51,8 @@ WORKLOADS = {
     "gray8k_decode": (7680, 4320, True, 1, "decode", "BASELINE configs[4]: 7680x4320 --gray decode (r = g = b = Y)"),
     "encode4096_jpg": (4096, 4096, False, 1, "encode+entropy",
                        "4096x4096 planes -> complete .jpg in HBM (FDCT+quant kernel, then the GPU Huffman stage)"),
+    "decode4096_jpg": (4096, 4096, False, 1, "entropy+decode",
+                       "4096x4096 .jpg bytes (host) -> GPU Huffman decoder -> dequant+IDCT+RGB planes in HBM"),
 }
 BATCH_W, BATCH_H, BATCH_FRAMES = 1920, 1080, 4096      # BASELINE configs[3]
 
@@ -470,6 +472,9 @@ def run_rank(args):
 
     W, H, gray, fps, direction, desc = WORKLOADS[args.workload]
     with_entropy = direction == "encode+entropy"
+    with_huffdec = direction == "entropy+decode"        # jpezy_read_jpeg_gpu synchronises between its passes: no graph, one stream
+    if with_huffdec:
+        args.no_graph, args.streams, args.pipelined, args.no_tolerant = True, 1, False, True
     if with_entropy and args.streams > 1:
         # the entropy stage keeps its scratch (tile streams, offsets, unstuffed stream) in the context: two calls in flight on
         # one context would overwrite each other's (include/jpezy_hip.h); frames in flight need a context each -- which is
@@ -515,7 +520,33 @@ def run_rank(args):
         k = i % ring
         ctx.dequant_idct_dev(co[k], W, H, pr[k], pg[k], pb[k], gray=gray, n_frames=fps, stream=stream.cuda_stream)
 
-    if direction == "decode":
+    jfiles = []
+    if with_huffdec:
+        # real files: encode the ring's random frames to complete .jpg files with the GPU coder, bring the bytes to the host
+        # (what decoder::decode reads from disk), then time .jpg -> coefficients -> planes
+        cap = J.load_library().jpezy_jpeg_bound(W, H)
+        jtmp = torch.empty((fps, cap), dtype=torch.uint8, device=dev)
+        jn = torch.zeros((fps,), dtype=torch.int64, device=dev)
+        for k in range(ring):
+            ctx.fdct_quant_dev(pr[k], pg[k], pb[k], W, H, co[k], gray=False, n_frames=fps, stream=stream.cuda_stream)
+            ctx.write_jpeg_gpu_dev(co[k], W, H, jtmp, jn, gray=False, n_frames=fps, stream=stream.cuda_stream)
+            torch.cuda.synchronize(dev)
+            jfiles.append([jtmp[f, : int(jn[f])].cpu().numpy().copy() for f in range(fps)])
+            co[k].zero_()
+        del jtmp, jn
+
+    def huffdec(i):
+        k = i % ring
+        for f in range(fps):
+            ctx.read_jpeg_gpu_into(jfiles[k][f], co[k][f])
+
+    def huffdec_dec(i):
+        huffdec(i)
+        dec(i)
+
+    if with_huffdec:
+        step = huffdec_dec
+    elif direction == "decode":
         for k in range(ring):      # real coefficients: encode the random frames once (6-block layout), then time the decode
             ctx.fdct_quant_dev(pr[k], pg[k], pb[k], W, H, co[k], gray=False, n_frames=fps, stream=stream.cuda_stream)
         torch.cuda.synchronize(dev)
@@ -672,6 +703,33 @@ def run_rank(args):
         copy_gbs = 2 * half * reps / (c0.elapsed_time(c1) * 1e-3) / 1e9
         del src_bufs, dst_bufs
 
+    huffdec_roof = None
+    # Huffman decoder alone (workload decode4096_jpg): K calls of jpezy_read_jpeg_gpu, HIP events on its stream around them.  The
+    # call parses the header on the host, uploads the scan and synchronises between its passes, so this is the whole call.
+    if with_huffdec and rank == 0:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        hms, passes = [], 0
+        for _ in range(R):
+            torch.cuda.synchronize(dev)
+            e0.record(stream)
+            for i in range(args.steps):
+                huffdec(i)
+            e1.record(stream)
+            torch.cuda.synchronize(dev)
+            hms.append(e0.elapsed_time(e1))
+            passes = ctx.last_huffdec_passes()
+        h_ms = statistics.median(hms) / args.steps
+        jbytes = sum(a.size for a in jfiles[0])
+        hbytes = jbytes + ncoef * 2 * fps                 # the .jpg read once + the coefficients written once
+        ha = hbytes / (h_ms * 1e-3) / 1e9
+        huffdec_roof = {"bound": "hbm", "achieved": round(ha, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(ha / HBM_PEAK_GBS, 5), "traffic": None,
+                        "kernel": "jpezy_read_jpeg_gpu (unstuff + speculate + confirm/refine passes + emit + DC prefix), the whole call",
+                        "algorithmic_bytes_per_step": hbytes, "avg_step_ms_hip_events": round(h_ms, 5),
+                        "jpg_bytes_per_frame": jbytes // fps, "sync_passes": passes,
+                        "note": "a chain of dependent launches with host decisions between them: latency-bound, not bandwidth-bound; "
+                                "the .jpg bytes start on the host (decoder::decode reads a file), the coefficients stay in HBM"}
+
     # entropy stage alone (workload encode4096_jpg): its own launch sequence, timed with HIP events on the same stream
     entropy_roof = None
     if with_entropy and rank == 0:
@@ -752,10 +810,11 @@ def run_rank(args):
                 tsrc = tj.get(args.workload, {}).get("source")
             except Exception:
                 traffic = None
-        if with_entropy:
+        if with_entropy or with_huffdec:
             traffic = None
         metric = {"encode": "Mpixels/s encode (FDCT+quant)", "decode": "Mpixels/s decode (dequant+IDCT)",
-                  "encode+entropy": "Mpixels/s encode (FDCT+quant + GPU Huffman stage)"}[direction]
+                  "encode+entropy": "Mpixels/s encode (FDCT+quant + GPU Huffman stage)",
+                  "entropy+decode": "Mpixels/s decode (GPU Huffman decoder + dequant+IDCT)"}[direction]
         kernel = {None: "f32::fdct_quant_f32_kernel", 1: "f32::fdct_quant_f32_kernel", 2: "f32::fdct_quant_mfma_kernel",
                   0: "fdct_quant_kernel"}[args.variant] if direction.startswith("encode") else "dequant_idct_kernel"
         out = {
@@ -782,12 +841,16 @@ def run_rank(args):
             "config": {"workload": desc, "name": args.workload, "width": W, "height": H, "mode": "gray" if gray else "color",
                        "frames_per_step": fps, "ring_batches": ring, "pixels_per_step_per_gpu": px_per_step,
                        "inputs": "iid uniform u8 r,g,b planes resident in HBM", "parallelism": f"frames x{world}",
-                       "submission": ("one launch per step" if not with_entropy else "FDCT launch + entropy-stage launches per step")
+                       "submission": ("jpezy_read_jpeg_gpu call + IDCT launch per step" if with_huffdec else
+                                      "one launch per step" if not with_entropy else "FDCT launch + entropy-stage launches per step")
                                      + ("" if args.no_graph else ", the K steps captured once and replayed as a hipGraph")
                                      + ("" if args.streams <= 1 else f", {args.streams} steps in flight on {args.streams} streams")},
             "exact_fallbacks_per_step": round(nfallback / max(1, args.steps * R), 2),
         }
-        if not with_entropy:
+        if with_huffdec:
+            out["roofline"] = huffdec_roof
+            out["config"]["inputs"] = ".jpg files of iid uniform u8 frames (GPU coder's output), bytes on the host; coefficients and planes in HBM"
+        elif not with_entropy:
             out["roofline"] = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": tsrc,
                                "kernel": kernel,

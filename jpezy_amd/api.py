@@ -276,6 +276,13 @@ class Context:
         _check(lib.jpezy_read_jpeg_gpu(self._h, _np_ptr(arr), arr.size, C.byref(info), co.data_ptr(), co.numel()))
         return info, co
 
+    def read_jpeg_gpu_into(self, arr, d_coeffs):
+        """read_jpeg_gpu without the header-only call or an allocation: arr a contiguous numpy uint8 array holding the file,
+        d_coeffs a torch int16 tensor on this context's device with room for the frame's coefficients; returns FrameInfo."""
+        info = FrameInfo()
+        _check(load_library().jpezy_read_jpeg_gpu(self._h, _np_ptr(arr), arr.size, C.byref(info), d_coeffs.data_ptr(), d_coeffs.numel()))
+        return info
+
     def decode_jpeg(self, data, gray=False):
         """.jpg bytes -> (FrameInfo, r, g, b) planes of width*height bytes (decoder::decode end to end)."""
         lib = load_library()

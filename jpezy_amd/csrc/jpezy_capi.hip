@@ -1066,27 +1066,57 @@ JPEZY_CATCH
 // ---- GPU Huffman decoding (decode side) ----
 namespace {
 
-// false: the counts do not describe a prefix code (more codes of some length than the code space has left) -- such a
-// table is left to the host decoder, whose canonical loop defines what it means
-bool build_dev_table(jpezy_dev::huffdec::Table& t, const uint8_t bits[16], const uint8_t* vals, int n)
+// The device decoder's two-level table of one Huffman table (jpezy_huffdec.h).  dc: the symbol is the number of value bits.
+// false: the counts do not describe a prefix code (more codes of some length than the code space has left), or the long codes
+// spread over more 10-bit prefixes than the table has room for -- such a table is left to the host decoder, whose canonical loop
+// defines what it means.
+bool build_dev_table(jpezy_dev::huffdec::Table& t, const uint8_t bits[16], const uint8_t* vals, int n, bool dc)
 {
+    namespace HD = jpezy_dev::huffdec;
     std::memset(&t, 0, sizeof t);
-    std::memcpy(t.val, vals, (size_t)n);
+    (void)n;
     unsigned code = 0;
-    int p = 0;
+    int p = 0, subs = 0;
+    long last_prefix = -1;
     for (int l = 1; l <= 16; ++l) {
-        t.off[l] = p - (int)code;
         for (int c = 0; c < bits[l - 1]; ++c, ++p, ++code) {
             if (code >= (1u << l)) return false;                     // more codes of this length than the code space has left
-            if (l <= 9) {
-                const unsigned lo = code << (9 - l);
-                for (unsigned f = 0; f < (1u << (9 - l)); ++f) t.look[lo + f] = (uint16_t)((l << 8) | vals[p]);
+            const unsigned sym = vals[p];
+            unsigned e = 0;
+            if (dc) {
+                if (sym <= 16) e = HD::E_VALID | (sym << 4) | (unsigned)(l - 1);           // a category above 16 is no symbol (entry 0)
+            } else {
+                e = HD::E_VALID | (sym == 0 ? HD::E_EOB : 0u) | ((sym >> 4) << 9) | ((sym & 15u) << 4) | (unsigned)(l - 1);
+            }
+            if (l <= HD::L1_BITS) {
+                const unsigned lo = code << (HD::L1_BITS - l);
+                for (unsigned f = 0; f < (1u << (HD::L1_BITS - l)); ++f) t.l1[lo + f] = (uint16_t)e;
+            } else {
+                const long prefix = (long)(code >> (l - HD::L1_BITS));
+                if (prefix != last_prefix) {                         // canonical codes ascend: so do the prefixes
+                    if (subs == HD::MAX_SUB) return false;
+                    t.l1[prefix] = (uint16_t)(HD::E_VALID | HD::E_LONG | (unsigned)(subs << HD::L2_BITS));
+                    last_prefix = prefix;
+                    ++subs;
+                }
+                const int rest = HD::L1_BITS + HD::L2_BITS - l;      // free bits behind the code inside the 16-bit index
+                const unsigned lo = ((code << rest) & ((1u << HD::L2_BITS) - 1u)) + (unsigned)((subs - 1) << HD::L2_BITS);
+                for (unsigned f = 0; f < (1u << rest); ++f) t.l2[lo + f] = (uint16_t)e;
             }
         }
         if (code > (1u << l)) return false;
-        if (l >= 9) t.limit[l - 9] = code << (16 - l);
         code <<= 1;
     }
+    return true;
+}
+
+// the table selectors of the blocks of one period of the MCU's table sequence, two bits each (Setup::tdmask); false: period too long
+bool pack_td_sequence(const int* seq, int period, unsigned* mask)
+{
+    if (period > jpezy_dev::huffdec::MAX_PERIOD) return false;
+    unsigned m = 0;
+    for (int i = 0; i < period; ++i) m |= (unsigned)(seq[i] & 3) << (2 * i);
+    *mask = m;
     return true;
 }
 
@@ -1103,6 +1133,28 @@ int read_jpeg_host_to_device(jpezy_ctx* c, const uint8_t* data, size_t len, jpez
 }
 
 }  // namespace
+
+// Refinement budget of the GPU Huffman decoder (jpezy_read_jpeg_gpu and the batch form).  After the confirmation launch (one step per
+// lane) some proposed exit states have moved.  A refinement launch lets a corrected state travel `steps` subsequences inside a workgroup
+// (a quiet workgroup leaves at once) and one step across a workgroup boundary.  Isolated wrong proposals -- the usual case -- settle in
+// the first launch of 24 steps.  Longer wrong runs (stretches on which a decoder started at the wrong bit takes long to fall into step;
+// up to ~100 subsequences in the fuzzer's files) get launches of 64 steps, which decode such a stretch lane after lane -- at a fraction of
+// the host decoder's rate, so it only pays while the stretches are short.  The launches therefore go on while they make progress
+// (round 2: a fixed six launches of 24 steps): three launches always run (24 + 64 + 64 steps, ~5 ms at worst); from the fourth on the
+// lanes that moved must be down to a residue (<= 64) or have fallen to 3/4 of the launch before (launches of the same size, so the
+// counts compare); never more than MAX_LAUNCHES.  A file that drops out goes to the host decoder, whose result is the same.
+// (tools/fuzz_huffdec.py with JPEZY_HUFFDEC_DEBUG=1 prints the lanes moved per launch; JPEZY_HUFFDEC_PATIENT=1 lifts the budget.)
+struct RefineBudget {
+    static constexpr int MAX_LAUNCHES = 12;
+    static int steps(int launch) { return launch <= 1 ? 24 : 64; }           // launch: 1-based refinement launch
+    // may refinement launch `launch` (1-based) run, given the lanes that moved in the two launches before it?
+    bool go_on(int launch, unsigned moved_before, unsigned moved_last) const
+    {
+        if (launch > MAX_LAUNCHES) return false;
+        if (launch <= 3 || moved_last <= 64u) return true;
+        return (unsigned long long)moved_last * 4u <= (unsigned long long)moved_before * 3u;
+    }
+};
 
 int jpezy_read_jpeg_gpu(jpezy_ctx* c, const uint8_t* data, size_t len, jpezy_frame_info* info, int16_t* d_coeffs, size_t coeff_cap)
 try {
@@ -1130,11 +1182,7 @@ try {
 
     // the entropy-coded segment ends at the first marker (0xFF followed by anything but 0x00)
     const uint8_t* scan = data + setup.scan_pos;
-    size_t n = len - setup.scan_pos;
-    for (const uint8_t* q = scan; (q = (const uint8_t*)std::memchr(q, 0xFF, (size_t)(scan + n - q))) != nullptr; ++q) {
-        if (q + 1 >= scan + n) { n = (size_t)(q - scan); break; }
-        if (q[1] != 0x00) { n = (size_t)(q - scan); break; }
-    }
+    const size_t n = jpezy_host::entropy_segment_length(scan, len - setup.scan_pos);
     if (n == 0 || n < c->h_min_bytes) return read_jpeg_host_to_device(c, data, len, info, d_coeffs, total);
 
     hipStream_t s = c->stream;
@@ -1160,8 +1208,8 @@ try {
     HD::Setup& S = hs[0];
     std::memset(&S, 0, sizeof S);
     for (int td = 0; td < 3; ++td) {
-        if (setup.present[td]) gpu_ok = build_dev_table(S.dc[td], setup.bits[td], setup.vals[td], setup.nvals[td]) && gpu_ok;
-        if (setup.present[4 + td]) gpu_ok = build_dev_table(S.ac[td], setup.bits[4 + td], setup.vals[4 + td], setup.nvals[4 + td]) && gpu_ok;
+        if (setup.present[td]) gpu_ok = build_dev_table(S.dc[td], setup.bits[td], setup.vals[td], setup.nvals[td], true) && gpu_ok;
+        if (setup.present[4 + td]) gpu_ok = build_dev_table(S.ac[td], setup.bits[4 + td], setup.vals[4 + td], setup.nvals[4 + td], false) && gpu_ok;
     }
     if (!gpu_ok) return read_jpeg_host_to_device(c, data, len, info, d_coeffs, total);
     S.total_blocks = (unsigned)total_blocks;
@@ -1180,7 +1228,7 @@ try {
             if (ok) { period = pd; break; }
         }
         S.bpm = period;
-        for (int i = 0; i < period; ++i) S.btd[i] = seq[i];
+        if (!pack_td_sequence(seq, period, &S.tdmask)) return read_jpeg_host_to_device(c, data, len, info, d_coeffs, total);
     }
     HIP_TRY(hipMemcpyAsync(c->h_setup.p, &S, sizeof S, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(c->h_scan.p, scan, n, hipMemcpyHostToDevice, s));
@@ -1213,6 +1261,7 @@ try {
     HIP_TRY(HD::launch_speculate((const HD::Setup*)c->h_setup.p, (const uint32_t*)c->h_U.p, u_bytes / 4, n_sub,
                                  (unsigned long long*)c->h_dc.p, d_exit, s));
     std::vector<uint32_t> dbg_spec;
+    std::vector<unsigned> dbg_moved;
     const bool dbg = std::getenv("JPEZY_HUFFDEC_DEBUG") != nullptr;
     if (dbg) {
         dbg_spec.resize(n_sub);
@@ -1237,14 +1286,19 @@ try {
             moved = mv[0];
             pending = mv[1] != 0;
             ++passes;
+            if (dbg) dbg_moved.push_back(moved);
             return JPEZY_OK;
         };
         if (int r2 = pass(1)) return r2;
         converged = moved == 0 && !pending;
-        // refinement budget: 6 launches of at most 24 propagation steps (~10 ms); isolated wrong lanes settle in one
-        if (!converged && moved <= n_sub / 2 + 16) {
-            for (int it = 0; it < 6 && !converged; ++it) {
-                if (int r2 = pass(24)) return r2;
+        // refinement, with a budget that follows the launches' progress (RefineBudget above)
+        const bool patient = dbg && std::getenv("JPEZY_HUFFDEC_PATIENT") != nullptr;      // diagnostic: show where the launches would have led
+        if (!converged && (moved <= n_sub / 2 + 16 || patient)) {
+            RefineBudget budget;
+            unsigned prev = moved;
+            for (int it = 1; !converged && (patient ? it <= 40 : budget.go_on(it, prev, moved)); ++it) {
+                prev = moved;
+                if (int r2 = pass(RefineBudget::steps(it))) return r2;
                 converged = moved == 0 && !pending;
             }
         }
@@ -1256,8 +1310,10 @@ try {
         for (unsigned i = 0; i < n_sub; ++i) {
             if (fin[i] == dbg_spec[i]) { ++same; run = 0; } else { ++run; if (run > longest) longest = run; }
         }
-        std::fprintf(stderr, "huffdec: %u subsequences, %zu speculative exit states already true, longest wrong run %zu, %d passes, converged %d\n",
-                     n_sub, same, longest, passes, (int)converged);
+        std::string mv_s;
+        for (unsigned m : dbg_moved) mv_s += " " + std::to_string(m);
+        std::fprintf(stderr, "huffdec: %u subsequences, %zu speculative exit states already true, longest wrong run %zu, %d passes, converged %d; lanes moved per launch:%s\n",
+                     n_sub, same, longest, passes, (int)converged, mv_s.c_str());
     }
     if (!converged) return read_jpeg_host_to_device(c, data, len, info, d_coeffs, total);
 
@@ -1407,8 +1463,8 @@ int decode_slice_fast(jpezy_ctx* c, const std::vector<FastFile>& files, const jp
         HD::Setup& S = setups[k];
         std::memset(&S, 0, sizeof S);
         for (int td = 0; td < 3; ++td) {
-            if (ff.setup.present[td]) usable[k] = build_dev_table(S.dc[td], ff.setup.bits[td], ff.setup.vals[td], ff.setup.nvals[td]) && usable[k];
-            if (ff.setup.present[4 + td]) usable[k] = build_dev_table(S.ac[td], ff.setup.bits[4 + td], ff.setup.vals[4 + td], ff.setup.nvals[4 + td]) && usable[k];
+            if (ff.setup.present[td]) usable[k] = build_dev_table(S.dc[td], ff.setup.bits[td], ff.setup.vals[td], ff.setup.nvals[td], true) && usable[k];
+            if (ff.setup.present[4 + td]) usable[k] = build_dev_table(S.ac[td], ff.setup.bits[4 + td], ff.setup.vals[4 + td], ff.setup.nvals[4 + td], false) && usable[k];
         }
         S.total_blocks = f.total_blocks;
         {
@@ -1421,7 +1477,7 @@ int decode_slice_fast(jpezy_ctx* c, const std::vector<FastFile>& files, const jp
                 if (same) { period = pd; break; }
             }
             S.bpm = period;
-            for (int i = 0; i < period; ++i) S.btd[i] = seq[i];
+            usable[k] = pack_td_sequence(seq, period, &S.tdmask) && usable[k];
         }
     }
     if (total_chunks >= 0xFFFFFFFFull || total_slots >= 0xFFFFFFFFull) return set_err(JPEZY_E_BADARG, "decode_jpeg_batch: slice too large");
@@ -1483,16 +1539,17 @@ int decode_slice_fast(jpezy_ctx* c, const std::vector<FastFile>& files, const jp
     HIP_TRY(HD::launch_speculate_batch(d_S, (const uint32_t*)c->b_U.p, d_F, d_wg_file, d_wg_first, n_wg, (unsigned)total_slots,
                                        (unsigned long long*)c->b_prop.p, d_exit, s));
     lap("speculate");
-    std::vector<unsigned> active(nf);
+    std::vector<unsigned> active(nf), prev_moved(nf, 0u);
     std::vector<char> converged(nf, 0), dead(nf, 0);
     for (unsigned k = 0; k < nf; ++k) { active[k] = usable[k] ? 1u : 0u; dead[k] = !usable[k]; }
-    for (int pass = 0; pass < 7; ++pass) {
+    RefineBudget budget;
+    for (int pass = 0; pass <= RefineBudget::MAX_LAUNCHES; ++pass) {
         bool any = false;
         for (unsigned k = 0; k < nf; ++k) any = any || active[k];
         if (!any) break;
         HIP_TRY(hipMemcpyAsync(d_active, active.data(), (size_t)nf * 4, hipMemcpyHostToDevice, s));
         HIP_TRY(HD::launch_sync_batch(d_S, (const uint32_t*)c->b_U.p, d_F, d_wg_file, d_wg_first, n_wg, d_active, d_exit, d_last, d_nblocks,
-                                      pass == 0 ? 1 : 24, s));
+                                      pass == 0 ? 1 : RefineBudget::steps(pass), s));
         HIP_TRY(hipMemcpyAsync(F.data(), d_F, sizeof(HD::BatchFile) * nf, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
         for (unsigned k = 0; k < nf; ++k) {
@@ -1500,8 +1557,10 @@ int decode_slice_fast(jpezy_ctx* c, const std::vector<FastFile>& files, const jp
             const unsigned moved = F[k].changed[0], pending = F[k].changed[1];
             if (F[k].n_sub == 0) { active[k] = 0; dead[k] = 1; continue; }
             if (moved == 0 && pending == 0) { active[k] = 0; converged[k] = 1; continue; }
-            // many proposals moved at the first look (periodic data never falls into step), or the budget is spent: per-file path
-            if ((pass == 0 && moved > F[k].n_sub / 2 + 16) || pass == 6) { active[k] = 0; dead[k] = 1; }
+            // many proposals moved at the first look (periodic data never falls into step), or the refinement launches have
+            // stopped paying for this file (RefineBudget): per-file path
+            if (pass == 0 ? moved > F[k].n_sub / 2 + 16 : !budget.go_on(pass + 1, prev_moved[k], moved)) { active[k] = 0; dead[k] = 1; }
+            prev_moved[k] = moved;
         }
         // reset the per-pass counters of the files that go on
         for (unsigned k = 0; k < nf; ++k)
@@ -1556,7 +1615,7 @@ try {
     {
         struct Cand { FastFile ff; jpezy_frame_info info; bool good = false; };
         std::vector<Cand> all((size_t)n);
-        // headers and the end of every scan (a memchr over the whole entropy-coded segment), spread over host threads
+        // headers and the end of every scan (a pass over the whole entropy-coded segment), spread over host threads
         auto prep = [&](int i) {
             Cand& cd = all[(size_t)i];
             std::string err;
@@ -1571,11 +1630,7 @@ try {
                 tabs = cd.ff.setup.Td[q] >= 0 && cd.ff.setup.Td[q] <= 2 && cd.ff.setup.present[cd.ff.setup.Td[q]] && cd.ff.setup.present[4 + cd.ff.setup.Td[q]];
             if (!tabs) return;
             const uint8_t* scan = data[i] + cd.ff.setup.scan_pos;
-            size_t ns = len[i] - cd.ff.setup.scan_pos;
-            for (const uint8_t* q = scan; (q = (const uint8_t*)std::memchr(q, 0xFF, (size_t)(scan + ns - q))) != nullptr; ++q) {
-                if (q + 1 >= scan + ns) { ns = (size_t)(q - scan); break; }
-                if (q[1] != 0x00) { ns = (size_t)(q - scan); break; }
-            }
+            const size_t ns = jpezy_host::entropy_segment_length(scan, len[i] - cd.ff.setup.scan_pos);
             const size_t nblk = (size_t)fi.mcu_cols * fi.mcu_rows * 6;
             if (ns == 0 || nblk > 4 * len[i]) return;
             cd.ff.index = i; cd.ff.scan = scan; cd.ff.n = ns;

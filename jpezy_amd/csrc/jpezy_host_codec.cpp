@@ -9,6 +9,9 @@
 #include "jpezy_host_codec.h"
 
 #include <cstring>
+#if defined(__SSE2__)
+#include <emmintrin.h>
+#endif
 
 #include "../../include/jpezy_constants.h"
 
@@ -610,5 +613,22 @@ int read_jpeg_impl(const uint8_t* data, size_t len, jpezy_frame_info* info, int1
     return JPEZY_OK;
 }
 }  // namespace
+
+size_t entropy_segment_length(const uint8_t* scan, size_t n)
+{
+    size_t i = 0;
+#if defined(__SSE2__)
+    const __m128i ff = _mm_set1_epi8((char)0xFF), zero = _mm_setzero_si128();
+    for (; i + 17 <= n; i += 16) {
+        const __m128i a = _mm_loadu_si128(reinterpret_cast<const __m128i*>(scan + i));
+        const __m128i b = _mm_loadu_si128(reinterpret_cast<const __m128i*>(scan + i + 1));
+        const int hit = _mm_movemask_epi8(_mm_andnot_si128(_mm_cmpeq_epi8(b, zero), _mm_cmpeq_epi8(a, ff)));   // 0xFF, next != 0x00
+        if (hit) return i + (size_t)__builtin_ctz((unsigned)hit);
+    }
+#endif
+    for (; i < n; ++i)
+        if (scan[i] == 0xFF && (i + 1 >= n || scan[i + 1] != 0x00)) return i;
+    return n;
+}
 
 }  // namespace jpezy_host

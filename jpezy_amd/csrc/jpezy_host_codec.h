@@ -38,4 +38,10 @@ int parse_header(const uint8_t* data, size_t len, jpezy_frame_info* info, ScanSe
 int read_jpeg(const uint8_t* data, size_t len, jpezy_frame_info* info, int16_t* coeffs, size_t coeff_cap,
               std::string* err);
 
+// Length of the entropy-coded segment that starts at scan[0]: it ends before the first marker -- a 0xFF followed by anything but 0x00 --
+// or before a 0xFF that is the last byte (decoder::decode_huffman reads on until its bit reader meets one, ref decoder/jpezy_decoder.hpp:
+// 583-642); n when there is none.  Compressed data holds a 0xFF every ~256 bytes, so this is a 16-bytes-at-a-time compare, not a memchr
+// per 0xFF.
+size_t entropy_segment_length(const uint8_t* scan, size_t n);
+
 }  // namespace jpezy_host

@@ -45,96 +45,107 @@ constexpr int WINDOW_LINEAR = (WGS + OVERFLOW) * SUBSEQ_BITS / 32 + 16;
 constexpr int WINDOW_WORDS = WINDOW_LINEAR + WINDOW_LINEAR / 32 + 1;
 __device__ __forceinline__ unsigned pad_index(unsigned i) { return i + (i >> 5); }
 
+// The cursor: a bit position relative to the window's first bit and the three window words around it in registers -- w0 holds the bit
+// at pos, w1 the word after it, w2 one more, fetched a symbol ahead of its use so that no LDS latency sits between two symbols except the
+// two table lookups.  The window words are stored most-significant-bit first (load_window swaps the bytes once).
 struct Cursor {
-    const uint32_t* w;            // LDS window, raw words (big-endian bytes)
-    unsigned long long pos;       // absolute bit position
-    unsigned long long buf;       // the next `avail` bits of the stream, left-aligned
-    int avail;                    // 33..64 valid bits
-    unsigned next;                // index of the next window word to append
-    __device__ __forceinline__ void init(const uint32_t* win, unsigned long long base, unsigned long long p)
+    const uint32_t* w;
+    unsigned pos;
+    uint32_t w0, w1, w2;
+    unsigned nxt;                 // window index of the word after w2
+    __device__ __forceinline__ void init(const uint32_t* win, unsigned rel)
     {
         w = win;
-        pos = p;
-        const unsigned rel = (unsigned)(p - base);
+        pos = rel;
         const unsigned i = rel >> 5;
-        const int sh = (int)(rel & 31);
-        buf = (((unsigned long long)__builtin_bswap32(w[pad_index(i)]) << 32) | __builtin_bswap32(w[pad_index(i + 1)])) << sh;
-        avail = 64 - sh;
-        next = i + 2;
+        w0 = w[pad_index(i)];
+        w1 = w[pad_index(i + 1)];
+        w2 = w[pad_index(i + 2)];
+        nxt = i + 3;
     }
-    __device__ __forceinline__ uint32_t peek32() const { return (uint32_t)(buf >> 32); }
-    __device__ __forceinline__ void skip(unsigned n)      // n <= 32
+    // the 32 bits at pos: (w0 << sh) | (w1 >> (32 - sh)), written so that sh = 0 needs no special case (and no branch)
+    __device__ __forceinline__ uint32_t peek32() const
     {
-        buf <<= n;
-        avail -= (int)n;
-        pos += n;
-        if (avail <= 32) {                                // one LDS word per 32 bits consumed
-            buf |= (unsigned long long)__builtin_bswap32(w[pad_index(next++)]) << (32 - avail);
-            avail += 32;
-        }
+        const unsigned sh = pos & 31u;
+        return (w0 << sh) | ((w1 >> 1) >> (31u - sh));
     }
 };
 
 __device__ __forceinline__ void load_window(uint32_t* win, const uint32_t* U, unsigned first_sub, size_t u_words)
 {
     const size_t w0 = (size_t)first_sub * (SUBSEQ_BITS / 32);
-    for (unsigned i = threadIdx.x; i < (unsigned)WINDOW_LINEAR; i += WGS) win[pad_index(i)] = w0 + i < u_words ? U[w0 + i] : 0u;
+    for (unsigned i = threadIdx.x; i < (unsigned)WINDOW_LINEAR; i += WGS) win[pad_index(i)] = w0 + i < u_words ? __builtin_bswap32(U[w0 + i]) : 0u;
 }
 
-// one symbol of table t at the cursor: returns the symbol (or -1) and its code length.  Codes longer than 9 bits take
-// no loop: seven limits (one LDS latency, the loads are independent), six compares, two dependent loads.
-__device__ __forceinline__ int decode_symbol(const Table& t, uint32_t bits, int& len)
+__device__ __forceinline__ void load_setup(Setup& S, const Setup* g)
 {
-    const unsigned e = t.look[bits >> 23];
-    if (e) { len = (int)(e >> 8); return (int)(e & 0xFF); }
-    const unsigned w = bits >> 16;
-    const uint4 la = *reinterpret_cast<const uint4*>(t.limit), lb = *reinterpret_cast<const uint4*>(t.limit + 4);
-    const int l = 10 + (w >= la.y) + (w >= la.z) + (w >= la.w) + (w >= lb.x) + (w >= lb.y) + (w >= lb.z);
-    len = l;
-    if (w >= lb.w) { len = 0; return -1; }
-    return t.val[(unsigned)(t.off[l] + (int)(w >> (16 - l))) & 255u];
+    const uint4* src = reinterpret_cast<const uint4*>(g);
+    uint4* dst = reinterpret_cast<uint4*>(&S);
+    for (unsigned i = threadIdx.x; i < sizeof(Setup) / 16; i += WGS) dst[i] = src[i];
 }
+static_assert(sizeof(Setup) % 16 == 0, "Setup is copied in 16-byte pieces");
 
 __device__ __forceinline__ int extend(int v, int cat) { return (v & (1 << (cat - 1))) ? v : v - ((1 << cat) - 1); }
 
-// Decode from state (pos, b, k) until pos >= end.  EMIT: write coefficients of blocks gidx < total into out.
-// nblocks: blocks completed.  An invalid code or a run past the end of the block: EMIT returns false (the true decode
-// hit it: the stream is bad); a synchronisation pass -- which may well be decoding from a wrong guess, i.e. garbage --
-// abandons the block, moves one bit on and carries on, so that it can still fall into step further down.
-// DC and AC symbols run through the same instructions (the lanes of a wave are at unrelated places of their blocks; two
-// branches would both be executed at every step): a DC symbol is a (run 0, size = category) symbol at k = 0.
-template <bool EMIT>
-__device__ __forceinline__ bool run_subsequence(const Setup& S, Cursor& c, unsigned long long end, unsigned& b, unsigned& k,
-                                                unsigned& nblocks, unsigned long long gidx, int16_t* out)
-{
-    const Table* tabs = S.dc;                                          // dc[0..2] then ac[0..2]
-    int td = S.btd[b];
-    while (c.pos < end) {
-        const uint32_t bits = c.peek32();
-        const bool is_dc = k == 0;
-        int len;
-        const int sym = decode_symbol(tabs[td + (is_dc ? 0 : 3)], bits, len);
-        const unsigned run = is_dc ? 0u : (unsigned)sym >> 4, s = is_dc ? (unsigned)sym : (unsigned)sym & 15u;
-        const bool eob = !is_dc && sym == 0;
-        if (sym < 0 || (is_dc ? sym > 16 : (!eob && run + k > 63))) {
-            if (EMIT) return false;
-            c.skip(1);
-            k = 64;
-        } else {
-            const unsigned kk = k + run;
-            if (EMIT && s && gidx + nblocks < S.total_blocks)              // DC: the difference, made absolute by the DC pass
-                out[(gidx + nblocks) * 64 + kk] = (int16_t)extend((int)((bits << len) >> (32 - s)), (int)s);
-            c.skip((unsigned)len + s);
-            k = eob ? 64u : kk + 1;
-        }
-        if (k >= 64) {
-            k = 0;
-            b = b + 1 == (unsigned)S.bpm ? 0 : b + 1;
-            td = S.btd[b];
-            ++nblocks;
-        }
+// The decoder's state besides the cursor: block inside the table period, zig-zag index (0: a DC symbol comes next), and the
+// offset of the block's table pair inside the Setup (in uint16 units).
+struct Walk {
+    unsigned b, k, tdoff, nblocks;
+    __device__ __forceinline__ void init(unsigned b_, unsigned k_, unsigned tdmask)
+    {
+        b = b_; k = k_; nblocks = 0;
+        tdoff = ((tdmask >> (2u * b)) & 3u) * TABLE_U16;
     }
+};
+
+// One symbol.  DC and AC symbols run through the same instructions (the lanes of a wave are at unrelated places of their blocks): a DC
+// symbol is a (run 0, size = category) symbol at k = 0 from the DC table.  Straight-line code: every decision is a select.
+// An invalid code, or a run past the end of the block: EMIT returns false (the true decode hit it: the stream is bad); a
+// synchronisation pass -- which may well be decoding from a wrong guess, i.e. garbage -- abandons the block, moves one bit on and
+// carries on, so that it can still fall into step further down.
+// EMIT: coefficients of blocks gidx + nblocks < total go to out (DC: the difference, made absolute by the DC pass).
+template <bool EMIT>
+__device__ __forceinline__ bool decode_step(const uint16_t* tabs, unsigned bpm, unsigned tdmask, Cursor& c, Walk& s,
+                                            unsigned long long gidx, unsigned total, int16_t* out)
+{
+    const uint32_t ahead = c.w[pad_index(c.nxt)];                      // used only when this symbol crosses a word boundary
+    const uint32_t bits = c.peek32();
+    const unsigned tb = s.tdoff + (s.k ? 3u * TABLE_U16 : 0u);         // dc[td] or ac[td]
+    const unsigned e1 = tabs[tb + (bits >> (32 - L1_BITS))];
+    const bool lng = (e1 & E_LONG) != 0;
+    const unsigned i2 = lng ? (e1 & 0x3FFFu) + ((bits >> (32 - L1_BITS - L2_BITS)) & ((1u << L2_BITS) - 1u)) : 0u;
+    const unsigned e2 = tabs[tb + (1u << L1_BITS) + i2];
+    const unsigned e = lng ? e2 : e1;
+    const unsigned len = (e & 15u) + 1u, sz = (e >> 4) & 31u, run = (e >> 9) & 15u;
+    const unsigned kk = s.k + run + 1u;                               // zig-zag index after this symbol
+    const bool bad = !(e & E_VALID) || kk > 64u;
+    if (EMIT) {
+        if (bad) return false;
+        if (sz && gidx + s.nblocks < total)
+            out[(gidx + s.nblocks) * 64 + kk - 1u] = (int16_t)extend((int)((bits << len) >> (32u - sz)), (int)sz);
+    }
+    const unsigned skip = bad ? 1u : len + sz;
+    const unsigned kn = (bad || (e & E_EOB)) ? 64u : kk;
+    const bool endb = kn >= 64u;
+    s.k = endb ? 0u : kn;
+    s.nblocks += endb ? 1u : 0u;
+    const unsigned b1 = s.b + 1u == bpm ? 0u : s.b + 1u;
+    s.b = endb ? b1 : s.b;
+    s.tdoff = ((tdmask >> (2u * s.b)) & 3u) * TABLE_U16;
+    const unsigned np = c.pos + skip;
+    const bool adv = ((np ^ c.pos) >> 5) != 0u;                       // skip <= 32: at most one word further
+    c.pos = np;
+    c.w0 = adv ? c.w1 : c.w0;
+    c.w1 = adv ? c.w2 : c.w1;
+    c.w2 = adv ? ahead : c.w2;
+    c.nxt += adv ? 1u : 0u;
     return true;
+}
+
+// decode (without emitting) until pos >= end
+__device__ __forceinline__ void run_subsequence(const uint16_t* tabs, unsigned bpm, unsigned tdmask, Cursor& c, Walk& s, unsigned end)
+{
+    while (c.pos < end) decode_step<false>(tabs, bpm, tdmask, c, s, 0, 0, nullptr);
 }
 
 // Speculation: lane i decodes from the guess (0, 0, 0) at the start of its subsequence through OVERFLOW + 1
@@ -148,23 +159,22 @@ __global__ __launch_bounds__(WGS) void spec_kernel(const Setup* gS, const uint32
 {
     __shared__ Setup S;
     __shared__ uint32_t win[WINDOW_WORDS];
-    {
-        const uint32_t* src = reinterpret_cast<const uint32_t*>(gS);
-        uint32_t* dst = reinterpret_cast<uint32_t*>(&S);
-        for (unsigned i = threadIdx.x; i < sizeof(Setup) / 4; i += WGS) dst[i] = src[i];
-    }
+    load_setup(S, gS);
     const unsigned i0 = blockIdx.x * WGS, i = i0 + threadIdx.x;
     load_window(win, U, i0, u_words);
     __syncthreads();
     if (i >= n_sub) return;
+    const uint16_t* tabs = reinterpret_cast<const uint16_t*>(&S);
+    const unsigned bpm = (unsigned)S.bpm, tdmask = S.tdmask;
     Cursor c;
-    c.init(win, (unsigned long long)i0 * SUBSEQ_BITS, (unsigned long long)i * SUBSEQ_BITS);
-    unsigned b = 0, k = 0, nb = 0;
+    c.init(win, threadIdx.x * SUBSEQ_BITS);
+    Walk wk;
+    wk.init(0, 0, tdmask);
     for (unsigned r = 0; r <= overflow && i + r < n_sub; ++r) {
-        const unsigned long long end = (unsigned long long)(i + r + 1) * SUBSEQ_BITS;
-        run_subsequence<false>(S, c, end, b, k, nb, 0, nullptr);
+        const unsigned end = (threadIdx.x + r + 1) * SUBSEQ_BITS;      // relative to the window's first bit, like c.pos
+        run_subsequence(tabs, bpm, tdmask, c, wk, end);
         const unsigned long long rank = i == 0 ? 0xFFFFull : r;
-        atomicMax(proposal + i + r, (rank << 32) | pack_state((unsigned)(c.pos - end), b, k));
+        atomicMax(proposal + i + r, (rank << 32) | pack_state(c.pos - end, wk.b, wk.k));
     }
 }
 
@@ -184,11 +194,7 @@ __global__ __launch_bounds__(WGS) void sync_kernel(const Setup* gS, const uint32
     __shared__ Setup S;
     __shared__ uint32_t win[WINDOW_WORDS];
     __shared__ uint32_t sh_exit[WGS + 1];
-    {
-        const uint32_t* src = reinterpret_cast<const uint32_t*>(gS);
-        uint32_t* dst = reinterpret_cast<uint32_t*>(&S);
-        for (unsigned i = threadIdx.x; i < sizeof(Setup) / 4; i += WGS) dst[i] = src[i];
-    }
+    load_setup(S, gS);
     const unsigned i0 = blockIdx.x * WGS, t = threadIdx.x, i = i0 + t;
     load_window(win, U, i0, u_words);
     const bool live = i < n_sub;
@@ -198,6 +204,8 @@ __global__ __launch_bounds__(WGS) void sync_kernel(const Setup* gS, const uint32
     sh_exit[t + 1] = my_exit;
     if (t == 0) sh_exit[0] = i0 ? exit_state[i0 - 1] : pack_state(0, 0, 0);
     __syncthreads();
+    const uint16_t* tabs = reinterpret_cast<const uint16_t*>(&S);
+    const unsigned bpm = (unsigned)S.bpm, tdmask = S.tdmask;
     for (int inner = 0; inner < max_inner; ++inner) {
         const uint32_t entry = sh_exit[t];
         bool redo = live && entry != my_last;
@@ -209,11 +217,13 @@ __global__ __launch_bounds__(WGS) void sync_kernel(const Setup* gS, const uint32
                 my_exit = STATE_ERR;
             } else {
                 Cursor c;
-                c.init(win, (unsigned long long)i0 * SUBSEQ_BITS, (unsigned long long)i * SUBSEQ_BITS + ((entry >> 16) & 0x3FFFu));
-                unsigned b = (entry >> 8) & 0xFFu, k = entry & 0xFFu;
-                const unsigned long long end = (unsigned long long)(i + 1) * SUBSEQ_BITS;
-                run_subsequence<false>(S, c, end, b, k, nb, 0, nullptr);
-                my_exit = pack_state((unsigned)(c.pos - end), b, k);
+                c.init(win, t * SUBSEQ_BITS + ((entry >> 16) & 0x3FFFu));
+                Walk wk;
+                wk.init((entry >> 8) & 0xFFu, entry & 0xFFu, tdmask);
+                const unsigned end = (t + 1) * SUBSEQ_BITS;
+                run_subsequence(tabs, bpm, tdmask, c, wk, end);
+                nb = wk.nblocks;
+                my_exit = pack_state(c.pos - end, wk.b, wk.k);
             }
             redo = sh_exit[t + 1] != my_exit;
             sh_exit[t + 1] = my_exit;
@@ -242,11 +252,7 @@ __global__ __launch_bounds__(WGS) void emit_kernel(const Setup* gS, const uint32
 {
     __shared__ Setup S;
     __shared__ uint32_t win[WINDOW_WORDS];
-    {
-        const uint32_t* src = reinterpret_cast<const uint32_t*>(gS);
-        uint32_t* dst = reinterpret_cast<uint32_t*>(&S);
-        for (unsigned i = threadIdx.x; i < sizeof(Setup) / 4; i += WGS) dst[i] = src[i];
-    }
+    load_setup(S, gS);
     const unsigned i0 = blockIdx.x * WGS, i = i0 + threadIdx.x;
     load_window(win, U, i0, u_words);
     __syncthreads();
@@ -255,16 +261,19 @@ __global__ __launch_bounds__(WGS) void emit_kernel(const Setup* gS, const uint32
     if (g0 >= S.total_blocks) return;                  // everything this lane sees lies behind the last block
     const uint32_t entry = i ? exit_state[i - 1] : pack_state(0, 0, 0);
     if (entry & 0x40000000u) { *error = 1u; return; }
+    const uint16_t* tabs = reinterpret_cast<const uint16_t*>(&S);
+    const unsigned bpm = (unsigned)S.bpm, tdmask = S.tdmask, total = S.total_blocks;
     Cursor c;
-    c.init(win, (unsigned long long)i0 * SUBSEQ_BITS, (unsigned long long)i * SUBSEQ_BITS + ((entry >> 16) & 0x3FFFu));
-    unsigned b = (entry >> 8) & 0xFFu, k = entry & 0xFFu, nb = 0;
-    const unsigned long long end = (unsigned long long)(i + 1) * SUBSEQ_BITS;
+    c.init(win, threadIdx.x * SUBSEQ_BITS + ((entry >> 16) & 0x3FFFu));
+    Walk wk;
+    wk.init((entry >> 8) & 0xFFu, entry & 0xFFu, tdmask);
+    const unsigned end = (threadIdx.x + 1) * SUBSEQ_BITS;
     // stop at the end of the last block: what follows are pad bits, not symbols
-    while (c.pos < end && g0 + nb < S.total_blocks) {
-        // one symbol at a time through the same routine (end = pos + 1 decodes exactly one symbol)
-        if (!run_subsequence<true>(S, c, c.pos + 1, b, k, nb, g0, out)) { *error = 1u; return; }
+    while (c.pos < end && g0 + wk.nblocks < total) {
+        if (!decode_step<true>(tabs, bpm, tdmask, c, wk, g0, total, out)) { *error = 1u; return; }
     }
-    if (g0 + nb >= S.total_blocks && g0 < S.total_blocks) *last_bit = c.pos;       // exactly one lane completes the last block
+    // exactly one lane completes the last block; the bit behind it, counted from the start of the stream
+    if (g0 + wk.nblocks >= total) *last_bit = (unsigned long long)i0 * SUBSEQ_BITS + c.pos;
 }
 
 // ---- DC differences -> absolute values, per component (pre_DC, ref :611-614) ----
@@ -380,13 +389,6 @@ __global__ __launch_bounds__(256) void unstuff_copy_batch_kernel(const uint8_t* 
     }
 }
 
-__device__ __forceinline__ void load_setup(Setup& S, const Setup* g)
-{
-    const uint4* src = reinterpret_cast<const uint4*>(g);
-    uint4* dst = reinterpret_cast<uint4*>(&S);
-    for (unsigned i = threadIdx.x; i < sizeof(Setup) / 16; i += WGS) dst[i] = src[i];
-}
-static_assert(sizeof(Setup) % 16 == 0, "Setup is copied in 16-byte pieces");
 
 __global__ __launch_bounds__(WGS) void spec_batch_kernel(const Setup* setups, const uint32_t* U, const BatchFile* F, const unsigned* wg_file,
                                                          const unsigned* wg_first, unsigned long long* proposal, unsigned overflow)
@@ -401,14 +403,17 @@ __global__ __launch_bounds__(WGS) void spec_batch_kernel(const Setup* setups, co
     const unsigned i = i0 + threadIdx.x;
     if (i >= n_sub) return;
     unsigned long long* prop = proposal + F[f].sub0;
+    const uint16_t* tabs = reinterpret_cast<const uint16_t*>(&S);
+    const unsigned bpm = (unsigned)S.bpm, tdmask = S.tdmask;
     Cursor c;
-    c.init(win, (unsigned long long)i0 * SUBSEQ_BITS, (unsigned long long)i * SUBSEQ_BITS);
-    unsigned b = 0, k = 0, nb = 0;
+    c.init(win, threadIdx.x * SUBSEQ_BITS);
+    Walk wk;
+    wk.init(0, 0, tdmask);
     for (unsigned r = 0; r <= overflow && i + r < n_sub; ++r) {
-        const unsigned long long end = (unsigned long long)(i + r + 1) * SUBSEQ_BITS;
-        run_subsequence<false>(S, c, end, b, k, nb, 0, nullptr);
+        const unsigned end = (threadIdx.x + r + 1) * SUBSEQ_BITS;
+        run_subsequence(tabs, bpm, tdmask, c, wk, end);
         const unsigned long long rank = i == 0 ? 0xFFFFull : r;
-        atomicMax(prop + i + r, (rank << 32) | pack_state((unsigned)(c.pos - end), b, k));
+        atomicMax(prop + i + r, (rank << 32) | pack_state(c.pos - end, wk.b, wk.k));
     }
 }
 
@@ -434,6 +439,8 @@ __global__ __launch_bounds__(WGS) void sync_batch_kernel(const Setup* setups, co
     sh_exit[t + 1] = my_exit;
     if (t == 0) sh_exit[0] = i0 ? exit_state[i0 - 1] : pack_state(0, 0, 0);
     __syncthreads();
+    const uint16_t* tabs = reinterpret_cast<const uint16_t*>(&S);
+    const unsigned bpm = (unsigned)S.bpm, tdmask = S.tdmask;
     for (int inner = 0; inner < max_inner; ++inner) {
         const uint32_t entry = sh_exit[t];
         bool redo = live && entry != my_last;
@@ -445,11 +452,13 @@ __global__ __launch_bounds__(WGS) void sync_batch_kernel(const Setup* setups, co
                 my_exit = STATE_ERR;
             } else {
                 Cursor c;
-                c.init(win, (unsigned long long)i0 * SUBSEQ_BITS, (unsigned long long)i * SUBSEQ_BITS + ((entry >> 16) & 0x3FFFu));
-                unsigned b = (entry >> 8) & 0xFFu, k = entry & 0xFFu;
-                const unsigned long long end = (unsigned long long)(i + 1) * SUBSEQ_BITS;
-                run_subsequence<false>(S, c, end, b, k, nb, 0, nullptr);
-                my_exit = pack_state((unsigned)(c.pos - end), b, k);
+                c.init(win, t * SUBSEQ_BITS + ((entry >> 16) & 0x3FFFu));
+                Walk wk;
+                wk.init((entry >> 8) & 0xFFu, entry & 0xFFu, tdmask);
+                const unsigned end = (t + 1) * SUBSEQ_BITS;
+                run_subsequence(tabs, bpm, tdmask, c, wk, end);
+                nb = wk.nblocks;
+                my_exit = pack_state(c.pos - end, wk.b, wk.k);
             }
             redo = sh_exit[t + 1] != my_exit;
             sh_exit[t + 1] = my_exit;
@@ -488,14 +497,17 @@ __global__ __launch_bounds__(WGS) void emit_batch_kernel(const Setup* setups, co
     const uint32_t entry = i ? exit_state[i - 1] : pack_state(0, 0, 0);
     if (entry & 0x40000000u) { F[f].error = 1u; return; }
     int16_t* out = coeffs + F[f].coeff_off;
+    const uint16_t* tabs = reinterpret_cast<const uint16_t*>(&S);
+    const unsigned bpm = (unsigned)S.bpm, tdmask = S.tdmask, total = S.total_blocks;
     Cursor c;
-    c.init(win, (unsigned long long)i0 * SUBSEQ_BITS, (unsigned long long)i * SUBSEQ_BITS + ((entry >> 16) & 0x3FFFu));
-    unsigned b = (entry >> 8) & 0xFFu, k = entry & 0xFFu, nb = 0;
-    const unsigned long long end = (unsigned long long)(i + 1) * SUBSEQ_BITS;
-    while (c.pos < end && g0 + nb < S.total_blocks) {
-        if (!run_subsequence<true>(S, c, c.pos + 1, b, k, nb, g0, out)) { F[f].error = 1u; return; }
+    c.init(win, threadIdx.x * SUBSEQ_BITS + ((entry >> 16) & 0x3FFFu));
+    Walk wk;
+    wk.init((entry >> 8) & 0xFFu, entry & 0xFFu, tdmask);
+    const unsigned end = (threadIdx.x + 1) * SUBSEQ_BITS;
+    while (c.pos < end && g0 + wk.nblocks < total) {
+        if (!decode_step<true>(tabs, bpm, tdmask, c, wk, g0, total, out)) { F[f].error = 1u; return; }
     }
-    if (g0 + nb >= S.total_blocks && g0 < S.total_blocks) F[f].last_bit = c.pos;
+    if (g0 + wk.nblocks >= total) F[f].last_bit = (unsigned long long)i0 * SUBSEQ_BITS + c.pos;
 }
 
 // DC differences -> absolute values (pre_DC, ref :611-614): one workgroup per (file, component) walks the component's DC terms in

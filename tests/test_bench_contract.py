@@ -30,7 +30,7 @@ def test_algorithmic_bytes_match_the_survey():
     assert b.algorithmic_bytes(1920, 1080, False, "encode") == 3 * 1920 * 1080 + 120 * 68 * 6 * 128 == 6220800 + 6266880
     assert b.HBM_PEAK_GBS == 8000.0
     assert b.WORKLOADS["encode4096"][:5] == (4096, 4096, False, 1, "encode")
-    assert set(b.WORKLOADS) == {"encode4096", "decode4096", "gray8k", "batch1080p", "gray8k_decode", "encode4096_jpg"}
+    assert set(b.WORKLOADS) == {"encode4096", "decode4096", "gray8k", "batch1080p", "gray8k_decode", "encode4096_jpg", "decode4096_jpg"}
     assert (b.BATCH_W, b.BATCH_H, b.BATCH_FRAMES) == (1920, 1080, 4096)          # BASELINE configs[3]
 
 

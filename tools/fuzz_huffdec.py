@@ -2,7 +2,9 @@
 """Differential fuzz of the GPU Huffman decoder against the host decoder (and of the GPU entropy coder against the host writer): random sizes, contents, qualities, sampling
 factors, optimised tables (libjpeg via PIL) and jpezy's own encoder; every scan goes to the GPU decoder (min_bytes 0)."""
 import io
+import os
 import sys
+import time
 from pathlib import Path
 
 import numpy as np
@@ -44,9 +46,11 @@ def main():
     ctx.set_huffdec_min_bytes(0)
     rng = np.random.default_rng(2026)
     gpu = host = 0
+    t_gpu, passes, fell = 0.0, {}, []
     for case in range(n_cases):
         W, H = int(rng.integers(8, 1400)), int(rng.integers(8, 1100))
-        img = content(rng, H, W, int(rng.integers(0, 5)))
+        kind = int(rng.integers(0, 5))
+        img = content(rng, H, W, kind)
         files = []
         kw = dict(quality=int(rng.integers(5, 100)), subsampling=int(rng.integers(0, 3)), optimize=bool(rng.integers(0, 2)))
         buf = io.BytesIO(); Image.fromarray(img).save(buf, "JPEG", **kw); files.append(("pil", kw, buf.getvalue()))
@@ -61,11 +65,15 @@ def main():
         files.append(("jpezy", {}, own))
         for name, kw, data in files:
             info, want = J.read_jpeg(data)
+            t0 = time.perf_counter()
             _, got = ctx.read_jpeg_gpu(data)
+            t_gpu += time.perf_counter() - t0
             if ctx.last_huffdec_passes():
                 gpu += 1
+                passes[ctx.last_huffdec_passes()] = passes.get(ctx.last_huffdec_passes(), 0) + 1
             else:
                 host += 1
+                fell.append(f"case {case} {name} {W}x{H} kind {kind} {len(data)} B")
             if not np.array_equal(got.cpu().numpy(), want):
                 print("MISMATCH", case, name, W, H, kw)
                 return 1
@@ -93,6 +101,10 @@ def main():
                 mut_ok += 1
     print(f"{gpu + host} files identical ({gpu} decoded by the GPU decoder, {host} handed to the host decoder)"
           + (f"; {mut_ok + mut_err} damaged copies: {mut_ok} decode identically, {mut_err} rejected by both" if n_mut else ""))
+    print(f"jpezy_read_jpeg_gpu time over the intact files: {t_gpu * 1e3:.1f} ms; synchronisation launches per file (launches: files): "
+          f"{dict(sorted(passes.items()))}; library {os.environ.get('JPEZY_LIB', 'in-tree')}")
+    for line in fell:
+        print("  host decoder:", line)
     return 0
 
 

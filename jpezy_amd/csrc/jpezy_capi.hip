@@ -1134,24 +1134,27 @@ int read_jpeg_host_to_device(jpezy_ctx* c, const uint8_t* data, size_t len, jpez
 
 }  // namespace
 
-// Refinement budget of the GPU Huffman decoder (jpezy_read_jpeg_gpu and the batch form).  After the confirmation launch (one step per
-// lane) some proposed exit states have moved.  A refinement launch lets a corrected state travel `steps` subsequences inside a workgroup
-// (a quiet workgroup leaves at once) and one step across a workgroup boundary.  Isolated wrong proposals -- the usual case -- settle in
-// the first launch of 24 steps.  Longer wrong runs (stretches on which a decoder started at the wrong bit takes long to fall into step;
-// up to ~100 subsequences in the fuzzer's files) get launches of 64 steps, which decode such a stretch lane after lane -- at a fraction of
-// the host decoder's rate, so it only pays while the stretches are short.  The launches therefore go on while they make progress
-// (round 2: a fixed six launches of 24 steps): three launches always run (24 + 64 + 64 steps, ~5 ms at worst); from the fourth on the
-// lanes that moved must be down to a residue (<= 64) or have fallen to 3/4 of the launch before (launches of the same size, so the
-// counts compare); never more than MAX_LAUNCHES.  A file that drops out goes to the host decoder, whose result is the same.
+// Launch schedule of the GPU Huffman decoder's synchronisation phase (jpezy_read_jpeg_gpu and the batch form).  A launch lets a corrected
+// state travel `steps` subsequences inside a workgroup (a workgroup none of whose lanes has a new entry state leaves at once) and one step
+// across a workgroup boundary; it reports the lanes that moved, the lanes it left pending and whether a workgroup's last lane moved -- nothing
+// pending and no boundary moved means the states are the fixed point, i.e. the sequential decode.
+//   first launch: every lane decodes once from its predecessor's proposed exit state (the confirmation) and the corrections travel up to seven
+//     lanes on -- isolated wrong proposals, the usual case, settle here and the file is done after one launch and one look by the host
+//     (round 2: confirmation, a 24-step launch and a launch that found nothing to do, with a host synchronisation after each).  More than half
+//     of the proposals wrong at that first step: the stream does not synchronise (periodic data: flat areas) -- host decoder.
+//   refinement launches of 64 steps for longer wrong runs (up to ~100 subsequences in the fuzzer's files), which decode such a stretch lane
+//     after lane -- at a fraction of the host decoder's rate, so it only pays while the stretches are short.  They go on while they make
+//     progress (round 2: a fixed six launches of 24 steps): two always run; from the third on the lanes that moved must be down to a
+//     residue (<= 64) or have fallen to 3/4 of the launch before; never more than MAX_LAUNCHES.
+// A file that drops out goes to the host decoder, whose result is the same.
 // (tools/fuzz_huffdec.py with JPEZY_HUFFDEC_DEBUG=1 prints the lanes moved per launch; JPEZY_HUFFDEC_PATIENT=1 lifts the budget.)
 struct RefineBudget {
-    static constexpr int MAX_LAUNCHES = 12;
-    static int steps(int launch) { return launch <= 1 ? 24 : 64; }           // launch: 1-based refinement launch
-    // may refinement launch `launch` (1-based) run, given the lanes that moved in the two launches before it?
+    static constexpr int FIRST_STEPS = 8, STEPS = 64, MAX_LAUNCHES = 12;
+    // may refinement launch `launch` (1-based, after the first launch) run, given the lanes that moved in the two launches before it?
     bool go_on(int launch, unsigned moved_before, unsigned moved_last) const
     {
         if (launch > MAX_LAUNCHES) return false;
-        if (launch <= 3 || moved_last <= 64u) return true;
+        if (launch <= 2 || moved_last <= 64u) return true;
         return (unsigned long long)moved_last * 4u <= (unsigned long long)moved_before * 3u;
     }
 };
@@ -1180,9 +1183,11 @@ try {
         gpu_ok = setup.Td[i] >= 0 && setup.Td[i] <= 2 && setup.present[setup.Td[i]] && setup.present[4 + setup.Td[i]];
     if (!gpu_ok) return read_jpeg_host_to_device(c, data, len, info, d_coeffs, total);
 
-    // the entropy-coded segment ends at the first marker (0xFF followed by anything but 0x00)
+    // The entropy-coded segment ends at the first marker (0xFF followed by anything but 0x00).  The device finds it while it counts the
+    // stuffing (jpezy_huffdec.hip): the file goes up from the first scan byte to its end and the host never walks it -- a pass over a
+    // 5 MB scan costs the host 0.3-0.5 ms, a third of the whole call.  n is the upper bound until then.
     const uint8_t* scan = data + setup.scan_pos;
-    const size_t n = jpezy_host::entropy_segment_length(scan, len - setup.scan_pos);
+    size_t n = len - setup.scan_pos;
     if (n == 0 || n < c->h_min_bytes) return read_jpeg_host_to_device(c, data, len, info, d_coeffs, total);
 
     hipStream_t s = c->stream;
@@ -1233,14 +1238,20 @@ try {
     HIP_TRY(hipMemcpyAsync(c->h_setup.p, &S, sizeof S, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(c->h_scan.p, scan, n, hipMemcpyHostToDevice, s));
 
-    // 1. remove the byte stuffing
+    // 1. find the end of the segment, remove the byte stuffing
+    unsigned long long* d_marker = (unsigned long long*)c->h_small.p + 4;     // bytes 32..39 of h_small: first marker; 40..47: stuffing bytes removed
     HIP_TRY(hipMemsetAsync(c->h_U.p, 0, u_bytes, s));
-    HIP_TRY(HD::launch_unstuff_count((const uint8_t*)c->h_scan.p, n, (uint32_t*)c->h_cnt.p, s));
+    HIP_TRY(hipMemsetAsync(d_marker, 0xFF, sizeof(unsigned long long), s));
+    HIP_TRY(hipMemsetAsync(d_marker + 1, 0, sizeof(unsigned long long), s));
+    HIP_TRY(HD::launch_unstuff_count((const uint8_t*)c->h_scan.p, n, (uint32_t*)c->h_cnt.p, d_marker, s));
     HIP_TRY(E::launch_scan_u32((const uint32_t*)c->h_cnt.p, (unsigned long long*)c->h_off.p, nc, (unsigned long long*)c->e_tmp.p, s));
-    HIP_TRY(HD::launch_unstuff_copy((const uint8_t*)c->h_scan.p, n, (const unsigned long long*)c->h_off.p, (uint8_t*)c->h_U.p, s));
-    unsigned long long removed = 0;
-    HIP_TRY(hipMemcpyAsync(&removed, (const unsigned long long*)c->h_off.p + nc, sizeof removed, hipMemcpyDeviceToHost, s));
+    HIP_TRY(HD::launch_unstuff_copy((const uint8_t*)c->h_scan.p, n, d_marker, (const unsigned long long*)c->h_off.p, (uint8_t*)c->h_U.p, d_marker + 1, s));
+    unsigned long long seg[2] = { 0, 0 };
+    HIP_TRY(hipMemcpyAsync(seg, d_marker, sizeof seg, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
+    if (seg[0] < n) n = (size_t)seg[0];
+    const unsigned long long removed = seg[1];
+    if (n == 0 || removed > n) return read_jpeg_host_to_device(c, data, len, info, d_coeffs, total);
     // only the subsequences that hold real data are decoded: behind them U is zero padding, which no decoder ever
     // falls into step on (a periodic stream), so it would be walked lane by lane
     n_sub = (unsigned)(((n - removed) * 8 + L - 1) / L);
@@ -1250,16 +1261,13 @@ try {
     uint32_t* d_exit = (uint32_t*)c->h_state.p;
     uint32_t* d_last = d_exit + n_sub;
     unsigned* d_nblocks = (unsigned*)(d_last + n_sub);
-    unsigned* d_changed = (unsigned*)c->h_small.p + 4;     // [0] lanes that moved, [1] lanes left pending (bytes 16..23 of h_small)
+    unsigned* d_changed = (unsigned*)c->h_small.p + 4;     // [0] lanes that moved, [1] lanes left pending, [2] moved workgroup boundaries (bytes 16..31 of h_small)
     unsigned* d_error = (unsigned*)c->h_small.p + 1;
     unsigned long long* d_lastbit = (unsigned long long*)c->h_small.p + 1;
-    HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)d_exit, (int)0x80000000u, n_sub, s));
-    HIP_TRY(hipMemsetAsync(d_last, 0xFF, (size_t)n_sub * 4, s));
-    HIP_TRY(hipMemsetAsync(d_nblocks, 0, (size_t)n_sub * 4, s));
     // speculation: every lane decodes through its own and the next 12 subsequences from a guess; the farthest-travelled
     // proposal for every boundary becomes the initial exit state (h_dc doubles as the proposal scratch)
     HIP_TRY(HD::launch_speculate((const HD::Setup*)c->h_setup.p, (const uint32_t*)c->h_U.p, u_bytes / 4, n_sub,
-                                 (unsigned long long*)c->h_dc.p, d_exit, s));
+                                 (unsigned long long*)c->h_dc.p, d_exit, d_last, d_nblocks, s));
     std::vector<uint32_t> dbg_spec;
     std::vector<unsigned> dbg_moved;
     const bool dbg = std::getenv("JPEZY_HUFFDEC_DEBUG") != nullptr;
@@ -1270,36 +1278,33 @@ try {
     }
     bool converged = false;
     int passes = 0;
-    // confirmation: every lane decodes its subsequence once from its predecessor's proposed exit state.  No state moves:
-    // the proposals are the sequential decode.  A few move: refinement launches (each resolves a workgroup's 256
-    // subsequences internally).  Many move -- periodic data such as a flat image never lets a wrong decoder fall into
-    // step -- or refinement does not settle quickly: the host decoder takes over.
+    // confirmation and refinement (RefineBudget above)
     {
-        unsigned moved = 0, mv[2] = { 0, 0 };
-        bool pending = false;        // lanes a max_inner cut-off left with a stale entry: not converged even if nothing moved
+        unsigned moved = 0, mv[4] = { 0, 0, 0, 0 };
+        bool pending = false;        // lanes left with a stale entry state, or a moved workgroup boundary: not the fixed point yet
         auto pass = [&](int max_inner) -> int {
-            HIP_TRY(hipMemsetAsync(d_changed, 0, 2 * sizeof(unsigned), s));
+            HIP_TRY(hipMemsetAsync(d_changed, 0, sizeof mv, s));
             HIP_TRY(HD::launch_sync((const HD::Setup*)c->h_setup.p, (const uint32_t*)c->h_U.p, u_bytes / 4, n_sub, d_exit, d_last, d_nblocks,
                                     d_changed, max_inner, s));
             HIP_TRY(hipMemcpyAsync(mv, d_changed, sizeof mv, hipMemcpyDeviceToHost, s));
             HIP_TRY(hipStreamSynchronize(s));
             moved = mv[0];
-            pending = mv[1] != 0;
+            pending = mv[1] != 0 || mv[2] != 0;
             ++passes;
             if (dbg) dbg_moved.push_back(moved);
             return JPEZY_OK;
         };
-        if (int r2 = pass(1)) return r2;
-        converged = moved == 0 && !pending;
-        // refinement, with a budget that follows the launches' progress (RefineBudget above)
+        if (int r2 = pass(RefineBudget::FIRST_STEPS)) return r2;
+        converged = !pending;
+        const unsigned wrong = mv[3];            // proposals the confirmation step did not bear out
         const bool patient = dbg && std::getenv("JPEZY_HUFFDEC_PATIENT") != nullptr;      // diagnostic: show where the launches would have led
-        if (!converged && (moved <= n_sub / 2 + 16 || patient)) {
+        if (!converged && (wrong <= n_sub / 2 + 16 || patient)) {
             RefineBudget budget;
             unsigned prev = moved;
             for (int it = 1; !converged && (patient ? it <= 40 : budget.go_on(it, prev, moved)); ++it) {
                 prev = moved;
-                if (int r2 = pass(RefineBudget::steps(it))) return r2;
-                converged = moved == 0 && !pending;
+                if (int r2 = pass(RefineBudget::STEPS)) return r2;
+                converged = !pending;
             }
         }
     }
@@ -1384,12 +1389,15 @@ try {
     rc = jpezy_read_jpeg_gpu(c, data, len, info, (int16_t*)c->out.p, ncoef);
     if (rc < 0) return rc;
     const size_t plane = (size_t)W * H, stride = (plane + 15) & ~(size_t)15;
+    uint8_t* dst[3] = { r, g, b };
+    // three plain copies into the caller's planes: measured against bands through the pinned ring of the host-buffer entry points
+    // (tools/measure_decode_single_raw.py, 4096 x 4096, planes the caller has touched before: 2.0 ms against 2.6 ms) -- the runtime's
+    // pageable path moves 50 MB in 0.9 ms when the pages exist; what a caller pays for fresh pages is page faults, in either form
     for (int k = 0; k < 3; ++k)
         if (int rc2 = c->in[k].reserve(stride)) return rc2;
     if (int rc2 = jpezy_dequant_idct_dev(c, (const int16_t*)c->out.p, info->qt, tq, stride, W, H, gray, 1, (uint8_t*)c->in[0].p,
                                          (uint8_t*)c->in[1].p, (uint8_t*)c->in[2].p, c->stream))
         return rc2;
-    uint8_t* dst[3] = { r, g, b };
     for (int k = 0; k < 3; ++k) HIP_TRY(hipMemcpyAsync(dst[k], c->in[k].p, plane, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return JPEZY_OK;
@@ -1549,22 +1557,22 @@ int decode_slice_fast(jpezy_ctx* c, const std::vector<FastFile>& files, const jp
         if (!any) break;
         HIP_TRY(hipMemcpyAsync(d_active, active.data(), (size_t)nf * 4, hipMemcpyHostToDevice, s));
         HIP_TRY(HD::launch_sync_batch(d_S, (const uint32_t*)c->b_U.p, d_F, d_wg_file, d_wg_first, n_wg, d_active, d_exit, d_last, d_nblocks,
-                                      pass == 0 ? 1 : RefineBudget::steps(pass), s));
+                                      pass == 0 ? RefineBudget::FIRST_STEPS : RefineBudget::STEPS, s));
         HIP_TRY(hipMemcpyAsync(F.data(), d_F, sizeof(HD::BatchFile) * nf, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
         for (unsigned k = 0; k < nf; ++k) {
             if (!active[k]) continue;
-            const unsigned moved = F[k].changed[0], pending = F[k].changed[1];
+            const unsigned moved = F[k].changed[0], pending = F[k].changed[1] + F[k].changed[2];
             if (F[k].n_sub == 0) { active[k] = 0; dead[k] = 1; continue; }
-            if (moved == 0 && pending == 0) { active[k] = 0; converged[k] = 1; continue; }
+            if (pending == 0) { active[k] = 0; converged[k] = 1; continue; }
             // many proposals moved at the first look (periodic data never falls into step), or the refinement launches have
             // stopped paying for this file (RefineBudget): per-file path
-            if (pass == 0 ? moved > F[k].n_sub / 2 + 16 : !budget.go_on(pass + 1, prev_moved[k], moved)) { active[k] = 0; dead[k] = 1; }
+            if (pass == 0 ? F[k].changed[3] > F[k].n_sub / 2 + 16 : !budget.go_on(pass + 1, prev_moved[k], moved)) { active[k] = 0; dead[k] = 1; }
             prev_moved[k] = moved;
         }
         // reset the per-pass counters of the files that go on
         for (unsigned k = 0; k < nf; ++k)
-            if (active[k]) HIP_TRY(hipMemsetAsync(&d_F[k].changed[0], 0, 2 * sizeof(unsigned), s));
+            if (active[k]) HIP_TRY(hipMemsetAsync(&d_F[k].changed[0], 0, 4 * sizeof(unsigned), s));
     }
     lap("confirm + refine");
     // 3. block index of every lane, coefficients, DC predictors -- for the files that converged

@@ -48,7 +48,8 @@ struct BatchFile {
     unsigned long long coeff_off;       // int16 offset of the file's coefficients
     unsigned total_blocks, nmcu, bpm, ncomp;
     unsigned cstart[3], ccount[3];      // component c owns blocks [cstart, cstart + ccount) of every MCU
-    unsigned changed[2];                // per pass: lanes that moved / lanes left pending (device)
+    unsigned changed[4];                // per launch: lanes that moved / lanes left pending / workgroup-last lanes among the moved /
+                                        // lanes that moved at the launch's first step (device)
     unsigned error, pad;
     unsigned long long last_bit;
 };
@@ -65,15 +66,22 @@ hipError_t launch_emit_batch(const Setup* setups, const uint32_t* U, BatchFile* 
                              const unsigned* active, const uint32_t* exit_state, const unsigned long long* blocks_before, int16_t* coeffs, hipStream_t s);
 hipError_t launch_dc_prefix_batch(int16_t* coeffs, const BatchFile* F, const unsigned* active, unsigned n_files, hipStream_t s);
 
-hipError_t launch_unstuff_count(const uint8_t* S, size_t n, uint32_t* counts, hipStream_t s);
-hipError_t launch_unstuff_copy(const uint8_t* S, size_t n, const unsigned long long* removed_before, uint8_t* U, hipStream_t s);
+// S: the file from the first byte of the scan on (n_max bytes).  The count launch also finds where the entropy-coded segment ends
+// (*first_marker, which the caller sets to all ones beforehand: offset of the first 0xFF that is followed by anything but 0x00 or is the last
+// byte; still all ones when there is none); the copy launch stops there and leaves the stuffing bytes it removed in totals[0] (the caller
+// sets it to 0 beforehand).
+hipError_t launch_unstuff_count(const uint8_t* S, size_t n_max, uint32_t* counts, unsigned long long* first_marker, hipStream_t s);
+hipError_t launch_unstuff_copy(const uint8_t* S, size_t n_max, const unsigned long long* first_marker, const unsigned long long* removed_before,
+                               uint8_t* U, unsigned long long* totals, hipStream_t s);
 // speculation pass: fills exit_state with the best available guess of every subsequence's true exit state
-// (proposal: n_sub uint64 of scratch)
+// (proposal: n_sub uint64 of scratch); also puts last_entry and nblocks into their state before the first synchronisation launch
 hipError_t launch_speculate(const Setup* S, const uint32_t* U, size_t u_words, unsigned n_sub, unsigned long long* proposal,
-                            uint32_t* exit_state, hipStream_t s);
+                            uint32_t* exit_state, uint32_t* last_entry, unsigned* nblocks, hipStream_t s);
 // u_words: 32-bit words of U that may be read (the rest of a workgroup's window reads as zero)
-// changed[0] += number of lanes whose exit state moved, changed[1] += lanes left pending by the max_inner cut-off.  max_inner: propagation steps inside a workgroup (1: every lane
-// decodes once from its predecessor's current exit state and nothing more)
+// changed[0] += number of lanes whose exit state moved, changed[1] += lanes left pending by the max_inner cut-off, changed[2] += moved lanes that
+// are a workgroup's last (the next workgroup may not have seen the new value), changed[3] += lanes whose first decode of the launch moved their state.  changed[1] == 0 && changed[2] == 0 after a launch: the states are
+// the fixed point, i.e. the sequential decode.  max_inner: propagation steps inside a workgroup (1: every lane decodes once from its
+// predecessor's current exit state and nothing more); a workgroup none of whose lanes has a new entry state leaves at once.
 hipError_t launch_sync(const Setup* S, const uint32_t* U, size_t u_words, unsigned n_sub, uint32_t* exit_state, uint32_t* last_entry,
                        unsigned* nblocks, unsigned* changed, int max_inner, hipStream_t s);
 hipError_t launch_emit(const Setup* S, const uint32_t* U, size_t u_words, unsigned n_sub, const uint32_t* exit_state,

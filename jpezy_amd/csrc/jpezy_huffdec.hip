@@ -178,6 +178,13 @@ __global__ __launch_bounds__(WGS) void spec_kernel(const Setup* gS, const uint32
     }
 }
 
+// state of the synchronisation phase before its first launch: no proposals, every lane still to decode, no blocks counted
+__global__ void init_state_kernel(unsigned long long* proposal, uint32_t* last_entry, unsigned* nblocks, unsigned n)
+{
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { proposal[i] = 0ull; last_entry[i] = 0xFFFFFFFFu; nblocks[i] = 0u; }
+}
+
 __global__ void adopt_proposals_kernel(const unsigned long long* proposal, unsigned n_sub, uint32_t* exit_state)
 {
     const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -194,9 +201,7 @@ __global__ __launch_bounds__(WGS) void sync_kernel(const Setup* gS, const uint32
     __shared__ Setup S;
     __shared__ uint32_t win[WINDOW_WORDS];
     __shared__ uint32_t sh_exit[WGS + 1];
-    load_setup(S, gS);
     const unsigned i0 = blockIdx.x * WGS, t = threadIdx.x, i = i0 + t;
-    load_window(win, U, i0, u_words);
     const bool live = i < n_sub;
     uint32_t my_last = live ? last_entry[i] : 0u, my_exit = live ? exit_state[i] : 0u;
     const uint32_t exit_before = my_exit;
@@ -204,8 +209,13 @@ __global__ __launch_bounds__(WGS) void sync_kernel(const Setup* gS, const uint32
     sh_exit[t + 1] = my_exit;
     if (t == 0) sh_exit[0] = i0 ? exit_state[i0 - 1] : pack_state(0, 0, 0);
     __syncthreads();
+    if (!__syncthreads_or(live && sh_exit[t] != my_last)) return;      // a quiet workgroup: nobody's entry state has changed
+    load_setup(S, gS);
+    load_window(win, U, i0, u_words);
+    __syncthreads();
     const uint16_t* tabs = reinterpret_cast<const uint16_t*>(&S);
     const unsigned bpm = (unsigned)S.bpm, tdmask = S.tdmask;
+    bool first_moved = false;                              // this lane's first decode of the launch left another state than it had
     for (int inner = 0; inner < max_inner; ++inner) {
         const uint32_t entry = sh_exit[t];
         bool redo = live && entry != my_last;
@@ -227,6 +237,7 @@ __global__ __launch_bounds__(WGS) void sync_kernel(const Setup* gS, const uint32
             }
             redo = sh_exit[t + 1] != my_exit;
             sh_exit[t + 1] = my_exit;
+            first_moved = first_moved || (inner == 0 && redo);
         }
         if (!__syncthreads_or(redo)) break;                // nothing changed inside the workgroup
     }
@@ -240,9 +251,12 @@ __global__ __launch_bounds__(WGS) void sync_kernel(const Setup* gS, const uint32
         if (my_exit != exit_before) {
             exit_state[i] = my_exit;
             atomicAdd(changed, 1u);                        // changed[0]: lanes whose exit state moved in this launch
-        } else if (pending) {
-            atomicAdd(changed + 1, 1u);                    // changed[1]: lanes that did not move but still have to re-decode
+            // changed[2]: ... among them a workgroup's last lane: the next workgroup may have read the old value at its start, so the
+            // launch cannot vouch for the fixed point across that boundary
+            if (t == WGS - 1 && i + 1 < n_sub) atomicAdd(changed + 2, 1u);
         }
+        if (pending) atomicAdd(changed + 1, 1u);           // changed[1]: lanes that still have to re-decode (cut off by max_inner)
+        if (first_moved) atomicAdd(changed + 3, 1u);       // changed[3]: lanes whose state moved at the launch's first step (first launch: wrong proposals)
     }
 }
 
@@ -296,34 +310,52 @@ __global__ void dc_scatter_kernel(int16_t* coeffs, unsigned bpm, unsigned start,
 
 // ---- 0xFF00 -> 0xFF ----
 constexpr int CHUNK = 64;
-__global__ __launch_bounds__(256) void unstuff_count_kernel(const uint8_t* S, size_t n, uint32_t* counts)
+// S holds everything from the first byte of the scan to the end of the file (n_max bytes).  The entropy-coded segment ends before the
+// first marker -- a 0xFF followed by anything but 0x00, or a 0xFF that is the file's last byte -- and the count kernel finds it on the
+// way (first_marker: atomicMin, initialised to all ones), so the host never walks the scan: a file goes up as it is.
+__global__ __launch_bounds__(256) void unstuff_count_kernel(const uint8_t* S, size_t n_max, uint32_t* counts, unsigned long long* first_marker)
 {
     const size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t b0 = c * CHUNK;
-    if (b0 >= n) return;
+    if (b0 >= n_max) return;
     unsigned cnt = 0;
     uint8_t prev = b0 ? S[b0 - 1] : 0;
-    const size_t e = b0 + CHUNK < n ? b0 + CHUNK : n;
+    const size_t e = b0 + CHUNK < n_max ? b0 + CHUNK : n_max;
+    unsigned long long marker = ~0ull;
     for (size_t i = b0; i < e; ++i) {
         const uint8_t v = S[i];
-        if (v == 0x00 && prev == 0xFF) { ++cnt; prev = 0x01; } else prev = v;   // FF 00 00: only the first zero is stuffing
+        if (v == 0x00 && prev == 0xFF) { ++cnt; prev = 0x01; }                  // FF 00 00: only the first zero is stuffing
+        else {
+            if (prev == 0xFF && marker == ~0ull) marker = i - 1;
+            prev = v;
+        }
     }
+    if (e == n_max && prev == 0xFF && marker == ~0ull) marker = n_max - 1;
+    // (counts of chunks behind the marker are never used: only prefix sums up to the marker's chunk are)
     counts[c] = cnt;
+    if (marker != ~0ull) atomicMin(first_marker, marker);
 }
-__global__ __launch_bounds__(256) void unstuff_copy_kernel(const uint8_t* S, size_t n, const unsigned long long* removed_before, uint8_t* U)
+// totals[0] = stuffing bytes removed in front of the marker
+__global__ __launch_bounds__(256) void unstuff_copy_kernel(const uint8_t* S, size_t n_max, const unsigned long long* first_marker,
+                                                           const unsigned long long* removed_before, uint8_t* U, unsigned long long* totals)
 {
     const size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t b0 = c * CHUNK;
+    const unsigned long long fm = *first_marker;
+    const size_t n = fm < n_max ? (size_t)fm : n_max;
     if (b0 >= n) return;
-    uint8_t* dst = U + b0 - removed_before[c];
+    const unsigned long long rb = removed_before[c];
+    uint8_t* dst = U + b0 - rb;
     uint8_t prev = b0 ? S[b0 - 1] : 0;
     const size_t e = b0 + CHUNK < n ? b0 + CHUNK : n;
+    unsigned cnt = 0;
     for (size_t i = b0; i < e; ++i) {
         const uint8_t v = S[i];
-        if (v == 0x00 && prev == 0xFF) { prev = 0x01; continue; }
+        if (v == 0x00 && prev == 0xFF) { prev = 0x01; ++cnt; continue; }
         *dst++ = v;
         prev = v;
     }
+    if (e == n) totals[0] = rb + cnt;
 }
 
 // ======================================================================================================
@@ -373,7 +405,7 @@ __global__ __launch_bounds__(256) void unstuff_copy_batch_kernel(const uint8_t* 
         const unsigned removed = (unsigned)(removed_before[F[f].chunk0 + F[f].n_chunks] - rb0);
         F[f].removed = removed;
         F[f].n_sub = (unsigned)((((unsigned long long)n - removed) * 8 + SUBSEQ_BITS - 1) / SUBSEQ_BITS);
-        F[f].changed[0] = F[f].changed[1] = 0;
+        F[f].changed[0] = F[f].changed[1] = F[f].changed[2] = F[f].changed[3] = 0;
         F[f].error = 0;
         F[f].last_bit = ~0ull;
     }
@@ -426,8 +458,6 @@ __global__ __launch_bounds__(WGS) void sync_batch_kernel(const Setup* setups, co
     __shared__ uint32_t sh_exit[WGS + 1];
     const unsigned f = wg_file[blockIdx.x], i0 = wg_first[blockIdx.x], n_sub = F[f].n_sub;
     if (i0 >= n_sub || !active[f]) return;                              // workgroup-uniform
-    load_setup(S, setups + f);
-    load_window(win, U + F[f].u_off / 4, i0, F[f].u_words);
     uint32_t* exit_state = exit_state_all + F[f].sub0;
     uint32_t* last_entry = last_entry_all + F[f].sub0;
     unsigned* nblocks_out = nblocks_all + F[f].sub0;
@@ -439,8 +469,13 @@ __global__ __launch_bounds__(WGS) void sync_batch_kernel(const Setup* setups, co
     sh_exit[t + 1] = my_exit;
     if (t == 0) sh_exit[0] = i0 ? exit_state[i0 - 1] : pack_state(0, 0, 0);
     __syncthreads();
+    if (!__syncthreads_or(live && sh_exit[t] != my_last)) return;      // a quiet workgroup
+    load_setup(S, setups + f);
+    load_window(win, U + F[f].u_off / 4, i0, F[f].u_words);
+    __syncthreads();
     const uint16_t* tabs = reinterpret_cast<const uint16_t*>(&S);
     const unsigned bpm = (unsigned)S.bpm, tdmask = S.tdmask;
+    bool first_moved = false;                              // this lane's first decode of the launch left another state than it had
     for (int inner = 0; inner < max_inner; ++inner) {
         const uint32_t entry = sh_exit[t];
         bool redo = live && entry != my_last;
@@ -462,6 +497,7 @@ __global__ __launch_bounds__(WGS) void sync_batch_kernel(const Setup* setups, co
             }
             redo = sh_exit[t + 1] != my_exit;
             sh_exit[t + 1] = my_exit;
+            first_moved = first_moved || (inner == 0 && redo);
         }
         if (!__syncthreads_or(redo)) break;
     }
@@ -472,9 +508,10 @@ __global__ __launch_bounds__(WGS) void sync_batch_kernel(const Setup* setups, co
         if (my_exit != exit_before) {
             exit_state[i] = my_exit;
             atomicAdd(&F[f].changed[0], 1u);
-        } else if (pending) {
-            atomicAdd(&F[f].changed[1], 1u);
+            if (t == WGS - 1 && i + 1 < n_sub) atomicAdd(&F[f].changed[2], 1u);
         }
+        if (pending) atomicAdd(&F[f].changed[1], 1u);
+        if (first_moved) atomicAdd(&F[f].changed[3], 1u);
     }
 }
 
@@ -568,25 +605,25 @@ __global__ __launch_bounds__(256) void dc_prefix_batch_kernel(int16_t* coeffs, c
 unsigned subseq_bits() { return SUBSEQ_BITS; }
 size_t chunk_bytes() { return CHUNK; }
 
-hipError_t launch_unstuff_count(const uint8_t* S, size_t n, uint32_t* counts, hipStream_t s)
+hipError_t launch_unstuff_count(const uint8_t* S, size_t n_max, uint32_t* counts, unsigned long long* first_marker, hipStream_t s)
 {
-    const size_t nc = (n + CHUNK - 1) / CHUNK;
+    const size_t nc = (n_max + CHUNK - 1) / CHUNK;
     if (!nc) return hipSuccess;
-    hipLaunchKernelGGL(unstuff_count_kernel, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, s, S, n, counts);
+    hipLaunchKernelGGL(unstuff_count_kernel, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, s, S, n_max, counts, first_marker);
     return hipGetLastError();
 }
-hipError_t launch_unstuff_copy(const uint8_t* S, size_t n, const unsigned long long* removed_before, uint8_t* U, hipStream_t s)
+hipError_t launch_unstuff_copy(const uint8_t* S, size_t n_max, const unsigned long long* first_marker, const unsigned long long* removed_before,
+                               uint8_t* U, unsigned long long* totals, hipStream_t s)
 {
-    const size_t nc = (n + CHUNK - 1) / CHUNK;
+    const size_t nc = (n_max + CHUNK - 1) / CHUNK;
     if (!nc) return hipSuccess;
-    hipLaunchKernelGGL(unstuff_copy_kernel, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, s, S, n, removed_before, U);
+    hipLaunchKernelGGL(unstuff_copy_kernel, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, s, S, n_max, first_marker, removed_before, U, totals);
     return hipGetLastError();
 }
 hipError_t launch_speculate(const Setup* S, const uint32_t* U, size_t u_words, unsigned n_sub, unsigned long long* proposal,
-                            uint32_t* exit_state, hipStream_t s)
+                            uint32_t* exit_state, uint32_t* last_entry, unsigned* nblocks, hipStream_t s)
 {
-    hipError_t e = hipMemsetAsync(proposal, 0, (size_t)n_sub * sizeof(unsigned long long), s);
-    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(init_state_kernel, dim3((n_sub + 255) / 256), dim3(256), 0, s, proposal, last_entry, nblocks, n_sub);
     static const unsigned overflow = [] {
         const char* e = std::getenv("JPEZY_HUFFDEC_OVERFLOW");      // development knob; the default covers what was measured
         const int v = e ? std::atoi(e) : OVERFLOW_DEFAULT;

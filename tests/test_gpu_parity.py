@@ -505,6 +505,27 @@ def test_bench_prints_one_contract_line():
     assert abs(d["value"] - 4096 * 4096 / (d["ms_per_step"] * 1e-3) / 1e6) / d["value"] < 0.01
 
 
+def test_bench_decode4096_jpg_line():
+    """the workload that starts from .jpg bytes (GPU Huffman decoder + fused IDCT): one contract line whose roofline object prices
+    jpezy_read_jpeg_gpu, the decoder really on the GPU (synchronisation launches > 0), value = pixels over the wall time of the K steps"""
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    r = subprocess.run([sys.executable, str(root / "bench.py"), "--workload", "decode4096_jpg", "--steps", "4", "--warmup", "1", "--no-cpu"],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["config"]["name"] == "decode4096_jpg" and d["unit"] == "Mpixels/s" and d["vs_baseline"] is None
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and "jpezy_read_jpeg_gpu" in rf["kernel"] and rf["sync_passes"] >= 1
+    assert rf["algorithmic_bytes_per_step"] == rf["jpg_bytes_per_frame"] + 4096 * 4096 * 3
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-4
+    assert abs(d["value"] - 4096 * 4096 / (d["ms_per_step"] * 1e-3) / 1e6) / d["value"] < 0.01
+
+
 def test_misaligned_coefficient_pointer_is_refused_not_faulted(J):
     """coefficients move as 16-byte accesses: a 2-byte-aligned slice must come back as JPEZY_E_BADARG (include/jpezy_hip.h)"""
     import torch

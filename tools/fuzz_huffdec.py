@@ -44,7 +44,7 @@ def main():
     mut_ok = mut_err = 0
     ctx = J.Context(0)
     ctx.set_huffdec_min_bytes(0)
-    rng = np.random.default_rng(2026)
+    rng = np.random.default_rng(int(sys.argv[3]) if len(sys.argv) > 3 else 2026)
     gpu = host = 0
     t_gpu, passes, fell = 0.0, {}, []
     for case in range(n_cases):

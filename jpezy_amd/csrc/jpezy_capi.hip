@@ -154,7 +154,8 @@ struct jpezy_ctx {
     size_t e_pinned_cap = 0;
     DevBuf h_scan, h_U, h_cnt, h_off, h_state, h_setup, h_small, h_dc;   // GPU Huffman decoder (jpezy_huffdec.hip)
     int h_last_passes = 0;         // synchronisation passes of the last jpezy_read_jpeg_gpu (0: the host decoder was used)
-    size_t h_min_bytes = 256 << 10;   // scans shorter than this are decoded on the host (the GPU path has ~3 ms of fixed cost)
+    size_t h_min_bytes = 64 << 10;    // scans shorter than this are decoded on the host: the GPU path has ~0.6 ms of fixed cost, the host decoder
+                                      // takes ~11 us per KiB of a dense scan (tools/huffdec_threshold.py: they cross at 56 KiB; round 2: 3 ms, 256 KiB)
     DevBuf b_scan, b_U, b_cnt, b_rb, b_state, b_prop, b_meta, b_coef, b_planes[2];   // jpezy_decode_jpeg_batch, batch form of the Huffman decoder
     int b_last_fast = 0;           // files of the last jpezy_decode_jpeg_batch call that took the batch form (diagnostic hook)
     uint8_t* b_pin = nullptr;      // pinned staging of the concatenated scans

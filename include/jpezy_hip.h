@@ -258,10 +258,12 @@ int jpezy_decode_jpeg(jpezy_ctx* ctx, const uint8_t* data, size_t len, int gray,
                       uint8_t* g, uint8_t* b, size_t plane_cap);
 /*
  * jpezy_decode_jpeg for n files at once (n decoder objects of the reference, decoder/jpezy_decoder.hpp:39-134, one per
- * file).  Files of jpezy's own layout (3 components sampled 2x2/1x1/1x1, 8 bit, no restart intervals) are grouped by size and
- * quantiser tables and decoded TOGETHER: one sequence of Huffman-decoder launches per slice of 16 scans (every file with its own
- * code tables), one IDCT launch per slice, the planes of a slice copied out while the next slice is decoded -- a single file keeps 80
- * waves busy for a chain of launches that is pure latency, a slice fills the chip for the same chain; a batch is bounded by PCIe.  Everything else (other layouts, irregular or non-converging streams, single files)
+ * file).  Files without restart intervals are grouped by size, layout (any the reference's decode_mcu handles: 1 or 3 components,
+ * sampling factors 1..4) and quantiser tables and decoded TOGETHER: one sequence of Huffman-decoder launches per slice of 16 scans
+ * (every file with its own code tables), one inverse-transform launch per slice (the fused kernel for jpezy's own 2x2/1x1/1x1 layout,
+ * the generic kernels for the others), the planes of a slice copied out while the next slice is decoded -- a single file keeps 80
+ * waves busy for a chain of launches that is pure latency, a slice fills the chip for the same chain; a batch is bounded by PCIe.
+ * Everything else (irregular or non-converging streams, single files)
  * is decoded file by file, up to 8 in flight on child contexts, with the host decoder as the last word, as before.  data[i] / len[i]: file i;
  * r[i], g[i], b[i]: its planes (plane_cap[i] >= width*height bytes each; sizes come from a header-only jpezy_decode_jpeg or
  * jpezy_read_jpeg call); info[i] and status[i] (JPEZY_OK or that file's negative error code) are written per file.

@@ -656,7 +656,7 @@ JPEZY_CATCH
 // uploaded synchronously when they changed since the last call)
 static int generic_dev_core(jpezy_ctx* c, const int16_t* d_coeffs, const uint16_t qt[4][64], int ncomp, const uint8_t comp_h[3],
                             const uint8_t comp_v[3], const uint8_t comp_tq[3], int W, int H, int gray, int precision, uint8_t* d_r,
-                            uint8_t* d_g, uint8_t* d_b, hipStream_t s, size_t* nblk_out)
+                            uint8_t* d_g, uint8_t* d_b, hipStream_t s, size_t* nblk_out, int n_frames = 1, size_t plane_stride = 0)
 {
     if (ncomp != 1 && ncomp != 3) return set_err(JPEZY_E_UNSUPPORTED, "dimension not supported (the reference accepts 1 or 3)");
     GenericDecParams p;
@@ -680,7 +680,11 @@ static int generic_dev_core(jpezy_ctx* c, const int16_t* d_coeffs, const uint16_
     const size_t nblk = (size_t)p.mcu_cols * p.mcu_rows * p.blocks_per_mcu;
     if (nblk_out) *nblk_out = nblk;
     if (!d_coeffs) return JPEZY_OK;                            // geometry only
-    if (int rc = c->scratch.reserve(nblk * 64 * sizeof(int))) return rc;
+    if (n_frames < 1 || (n_frames > 1 && (plane_stride < (size_t)W * H || (plane_stride & 3))))
+        return set_err(JPEZY_E_BADARG, "generic decoder, batch form: plane stride must hold a plane and be a multiple of 4");
+    if (int rc = c->scratch.reserve(nblk * 64 * sizeof(int) * (size_t)n_frames)) return rc;
+    p.n_frames = n_frames;
+    p.plane_stride = plane_stride;
     // per-component dequantiser constants (fast path) and integer quantisers (reference-order path), cached in the context
     const uint8_t tq3[3] = { comp_tq[0], (uint8_t)(ncomp > 1 ? comp_tq[1] : 0), (uint8_t)(ncomp > 2 ? comp_tq[2] : 0) };
     if (int rc = upload_dequant(c, qt, tq3, s)) return rc;
@@ -1415,8 +1419,9 @@ struct FastFile {
     size_t n;
 };
 
-// One slice of a group (same W x H, same quantiser tables, jpezy's own 2x2,1x1,1x1 layout): Huffman decoding of all files in one
-// sequence of launches (jpezy_huffdec.h, batch form), ONE dequant_idct launch over the slice, the planes copied out per file.
+// One slice of a group (same W x H, same layout, same quantiser tables): Huffman decoding of all files in one sequence of launches
+// (jpezy_huffdec.h, batch form), ONE inverse-transform launch over the slice -- the fused kernel for jpezy's own 2x2,1x1,1x1 layout, the
+// generic kernels' batch form for every other layout decode_mcu handles --, the planes copied out per file.
 // ok[k] = 1 for files decoded here; the others (not converged, irregular stream) are left to the per-file path, whose verdict --
 // host decoder included -- is the authoritative one.
 int decode_slice_fast(jpezy_ctx* c, const std::vector<FastFile>& files, const jpezy_frame_info& info, int gray, int plane_buf,
@@ -1429,7 +1434,10 @@ int decode_slice_fast(jpezy_ctx* c, const std::vector<FastFile>& files, const jp
     const unsigned L = HD::subseq_bits();
     const size_t chunk = HD::chunk_bytes();
     const int W = info.width, H = info.height;
-    const size_t nmcu = (size_t)info.mcu_cols * info.mcu_rows, cpf = nmcu * 6 * 64, plane = (size_t)W * H, pstride = (plane + 15) & ~(size_t)15;
+    const unsigned bpm = (unsigned)info.blocks_per_mcu;
+    const size_t nmcu = (size_t)info.mcu_cols * info.mcu_rows, cpf = nmcu * bpm * 64, plane = (size_t)W * H, pstride = (plane + 15) & ~(size_t)15;
+    const bool own_layout = info.ncomp == 3 && info.precision == 8 && info.H[0] == 2 && info.V[0] == 2 && info.H[1] == 1 && info.V[1] == 1 &&
+                            info.H[2] == 1 && info.V[2] == 1;
     ok.assign(nf, 0);
     const bool dbg = std::getenv("JPEZY_BATCH_DEBUG") != nullptr;
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -1461,9 +1469,12 @@ int decode_slice_fast(jpezy_ctx* c, const std::vector<FastFile>& files, const jp
         const size_t ub = (((size_t)f.n_sub_max * L / 8 + 64) + 3) & ~(size_t)3;
         f.u_words = (unsigned)(ub / 4);
         f.coeff_off = (unsigned long long)k * cpf;
-        f.total_blocks = (unsigned)(nmcu * 6);
-        f.nmcu = (unsigned)nmcu; f.bpm = 6; f.ncomp = 3;
-        f.cstart[0] = 0; f.ccount[0] = 4; f.cstart[1] = 4; f.ccount[1] = 1; f.cstart[2] = 5; f.ccount[2] = 1;
+        f.total_blocks = (unsigned)(nmcu * bpm);
+        f.nmcu = (unsigned)nmcu; f.bpm = bpm; f.ncomp = (unsigned)info.ncomp;
+        for (unsigned q = 0, at = 0; q < (unsigned)info.ncomp; ++q) {
+            f.cstart[q] = at; f.ccount[q] = (unsigned)(info.H[q] * info.V[q]);
+            at += f.ccount[q];
+        }
         total_chunks += f.n_chunks;
         total_slots += ((size_t)f.n_sub_max + 255) / 256 * 256;           // a workgroup never straddles two files
         u_bytes += ub;
@@ -1477,12 +1488,14 @@ int decode_slice_fast(jpezy_ctx* c, const std::vector<FastFile>& files, const jp
         }
         S.total_blocks = f.total_blocks;
         {
-            int seq[6] = { ff.setup.Td[0], ff.setup.Td[0], ff.setup.Td[0], ff.setup.Td[0], ff.setup.Td[1], ff.setup.Td[2] };
-            int period = 6;
-            for (int pd = 1; pd < 6; ++pd) {
-                if (6 % pd) continue;
+            int seq[48], nb = 0;                                       // (the caller admits at most 48 blocks per MCU)
+            for (int q = 0; q < info.ncomp; ++q)
+                for (int t = info.H[q] * info.V[q]; t > 0; --t) seq[nb++] = ff.setup.Td[q];
+            int period = nb;
+            for (int pd = 1; pd < nb; ++pd) {
+                if (nb % pd) continue;
                 bool same = true;
-                for (int i = pd; i < 6 && same; ++i) same = seq[i] == seq[i - pd];
+                for (int i = pd; i < nb && same; ++i) same = seq[i] == seq[i - pd];
                 if (same) { period = pd; break; }
             }
             S.bpm = period;
@@ -1591,9 +1604,17 @@ int decode_slice_fast(jpezy_ctx* c, const std::vector<FastFile>& files, const jp
     if (int rc = c->b_planes[plane_buf].reserve(3 * pstride * nf)) return rc;
     uint8_t* pl = (uint8_t*)c->b_planes[plane_buf].p;
     const uint8_t tq[3] = { (uint8_t)info.Tq[0], (uint8_t)info.Tq[1], (uint8_t)info.Tq[2] };
-    if (int rc = jpezy_dequant_idct_dev(c, (const int16_t*)c->b_coef.p, info.qt, tq, pstride, W, H, gray, (int)nf, pl, pl + pstride * nf,
-                                        pl + 2 * pstride * nf, s))
-        return rc;
+    if (own_layout) {
+        if (int rc = jpezy_dequant_idct_dev(c, (const int16_t*)c->b_coef.p, info.qt, tq, pstride, W, H, gray, (int)nf, pl, pl + pstride * nf,
+                                            pl + 2 * pstride * nf, s))
+            return rc;
+    } else {              // any other layout: the generic kernels over the slice (block loop over all frames, one plane launch with the frame as z)
+        const uint8_t hs[3] = { (uint8_t)info.H[0], (uint8_t)info.H[1], (uint8_t)info.H[2] };
+        const uint8_t vs[3] = { (uint8_t)info.V[0], (uint8_t)info.V[1], (uint8_t)info.V[2] };
+        if (int rc = generic_dev_core(c, (const int16_t*)c->b_coef.p, info.qt, info.ncomp, hs, vs, tq, W, H, gray, info.precision, pl,
+                                      pl + pstride * nf, pl + 2 * pstride * nf, s, nullptr, (int)nf, pstride))
+            return rc;
+    }
     HIP_TRY(hipStreamSynchronize(s));
     lap("IDCT");
     for (unsigned k = 0; k < nf; ++k) {
@@ -1615,9 +1636,10 @@ try {
     if (!c || n < 0 || (n > 0 && (!data || !len || !info || !r || !g || !b || !plane_cap || !status)))
         return set_err(JPEZY_E_BADARG, "decode_jpeg_batch: bad argument");
     if (n == 0) return JPEZY_OK;
-    // Fast path (round 3): files of jpezy's own layout are grouped by size and quantiser tables and go through the batch form of
-    // the GPU Huffman decoder and ONE IDCT launch per slice; whatever that path declines or cannot settle (other layouts, restart
-    // intervals, irregular streams, streams that do not converge) takes the per-file path below, file by file as before.
+    // Fast path (round 3): files are grouped by size, layout and quantiser tables and go through the batch form of the GPU Huffman
+    // decoder and ONE inverse-transform launch per slice (the fused kernel for jpezy's own layout, the generic kernels for the others);
+    // whatever that path declines or cannot settle (restart intervals, irregular streams, streams that do not converge) takes the
+    // per-file path below, file by file as before.
     std::vector<char> done((size_t)n, 0);
     c->b_last_fast = 0;
     HIP_TRY(hipSetDevice(c->device));
@@ -1631,17 +1653,20 @@ try {
             if (!data[i] || !r[i] || !g[i] || !b[i]) return;
             if (jpezy_host::parse_header(data[i], len[i], &cd.info, &cd.ff.setup, &err) < 0) return;
             const jpezy_frame_info& fi = cd.info;
-            const bool own = fi.ncomp == 3 && fi.precision == 8 && fi.H[0] == 2 && fi.V[0] == 2 && fi.H[1] == 1 && fi.V[1] == 1 && fi.H[2] == 1 &&
-                             fi.V[2] == 1 && fi.restart_interval == 0 && fi.width > 0 && fi.height > 0;
-            if (!own || cd.ff.setup.scan_pos >= len[i] || plane_cap[i] < (size_t)fi.width * fi.height) return;
+            // what the batch form takes: every baseline layout the reference's decode_mcu handles (1 or 3 components, sampling factors
+            // 1..4, at most 48 blocks per MCU), no restart intervals
+            bool fits = (fi.ncomp == 1 || fi.ncomp == 3) && fi.restart_interval == 0 && fi.width > 0 && fi.height > 0 &&
+                        fi.blocks_per_mcu >= 1 && fi.blocks_per_mcu <= 48 && fi.width <= 65535 && fi.height <= 65535;
+            for (int q = 0; q < fi.ncomp && fits; ++q) fits = fi.H[q] >= 1 && fi.H[q] <= 4 && fi.V[q] >= 1 && fi.V[q] <= 4;
+            if (!fits || cd.ff.setup.scan_pos >= len[i] || plane_cap[i] < (size_t)fi.width * fi.height) return;
             bool tabs = true;
-            for (int q = 0; q < 3 && tabs; ++q)
+            for (int q = 0; q < fi.ncomp && tabs; ++q)
                 tabs = cd.ff.setup.Td[q] >= 0 && cd.ff.setup.Td[q] <= 2 && cd.ff.setup.present[cd.ff.setup.Td[q]] && cd.ff.setup.present[4 + cd.ff.setup.Td[q]];
             if (!tabs) return;
             const uint8_t* scan = data[i] + cd.ff.setup.scan_pos;
             const size_t ns = jpezy_host::entropy_segment_length(scan, len[i] - cd.ff.setup.scan_pos);
-            const size_t nblk = (size_t)fi.mcu_cols * fi.mcu_rows * 6;
-            if (ns == 0 || nblk > 4 * len[i]) return;
+            const size_t nblk = (size_t)fi.mcu_cols * fi.mcu_rows * (size_t)fi.blocks_per_mcu;
+            if (ns == 0 || nblk > 4 * len[i] || nblk >= 0xFFFFFFFFull) return;
             cd.ff.index = i; cd.ff.scan = scan; cd.ff.n = ns;
             cd.good = true;
         };
@@ -1672,9 +1697,11 @@ try {
             // the group of cand[a]: same size, same quantiser tables for the three components
             std::vector<FastFile> grp;
             auto same_group = [&](const jpezy_frame_info& x, const jpezy_frame_info& y) {
-                if (x.width != y.width || x.height != y.height) return false;
-                for (int q = 0; q < 3; ++q)
+                if (x.width != y.width || x.height != y.height || x.ncomp != y.ncomp || x.precision != y.precision) return false;
+                for (int q = 0; q < x.ncomp; ++q) {
+                    if (x.H[q] != y.H[q] || x.V[q] != y.V[q]) return false;
                     if (std::memcmp(x.qt[x.Tq[q] & 3], y.qt[y.Tq[q] & 3], sizeof x.qt[0])) return false;
+                }
                 return true;
             };
             for (size_t k = a; k < cand.size(); ++k)
@@ -1682,7 +1709,8 @@ try {
             if (grp.size() < 2) continue;                                   // a single file gains nothing here
             const jpezy_frame_info& gi = cand[a]->info;
             // slices: at most 16 files (JPEZY_BATCH_SLICE: development knob) and ~1.5 GB of planes + coefficients at a time
-            const size_t per_file = (size_t)gi.width * gi.height * 3 + (size_t)gi.mcu_cols * gi.mcu_rows * 6 * 128;
+            // (planes + coefficients + the generic kernels' int samples)
+            const size_t per_file = (size_t)gi.width * gi.height * 3 + (size_t)gi.mcu_cols * gi.mcu_rows * (size_t)gi.blocks_per_mcu * (128 + 256);
             static const size_t slice_files = [] { const char* e = std::getenv("JPEZY_BATCH_SLICE"); const int v = e ? std::atoi(e) : 16; return (size_t)(v < 2 ? 2 : v > 512 ? 512 : v); }();
             const size_t per_slice = std::max<size_t>(2, std::min<size_t>(slice_files, ((size_t)3 << 29) / std::max<size_t>(per_file, 1)));
             const size_t plane = (size_t)gi.width * gi.height, pstride = (plane + 15) & ~(size_t)15;

@@ -138,6 +138,10 @@ struct GenericDecParams {
     int coef_limit;           // raw coefficients above it send their block to the reference-order path
     int force_exact;          // test hook: every block through the reference-order path
     unsigned long long* fallback_count;   // samples evaluated in reference order (sharded, COUNTER_SHARDS)
+    // batch form: n_frames frames of ONE layout, size and set of quantiser tables; frame f's coefficients at coeffs + f * blocks * 64,
+    // its samples at samples + f * blocks * 64, its planes at r/g/b + f * plane_stride (a multiple of 4)
+    int n_frames = 1;
+    size_t plane_stride = 0;
 };
 hipError_t launch_dequant_idct_generic(const GenericDecParams& p, hipStream_t stream);
 

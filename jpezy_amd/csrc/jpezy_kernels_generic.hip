@@ -176,6 +176,11 @@ __global__ __launch_bounds__(256) void generic_rgb_kernel(GenericDecParams p)
     const unsigned x0 = (blockIdx.x * 64u + (threadIdx.x & 63u)) * 4u;
     const unsigned y = blockIdx.y * 4u + (threadIdx.x >> 6);
     if (y >= (unsigned)p.H || x0 >= (unsigned)p.W) return;
+    {   // batch form: blockIdx.z is the frame
+        const size_t f = blockIdx.z;
+        p.samples += f * ((size_t)p.mcu_cols * p.mcu_rows * p.blocks_per_mcu * 64);
+        p.r += f * p.plane_stride; p.g += f * p.plane_stride; p.b += f * p.plane_stride;
+    }
     const unsigned mw = (unsigned)p.hmax * 8u, mh = (unsigned)p.vmax * 8u;
     const unsigned uy = gdiv(y, p.mh_magic, p.mh_shift), iy = y - uy * mh;
     // decode_mcu (ref :504-528) writes block (kx, ky) of a component at plane offset (kx*8, ky*8) -- not scaled by the
@@ -253,9 +258,10 @@ __global__ __launch_bounds__(256) void generic_rgb_kernel(GenericDecParams p)
 hipError_t launch_dequant_idct_generic(const GenericDecParams& p_in, hipStream_t s)
 {
     GenericDecParams p = p_in;
-    const long nblk = (long)p.mcu_cols * p.mcu_rows * p.blocks_per_mcu;
+    const int nfr = p.n_frames < 1 ? 1 : p.n_frames;
+    const long nblk = (long)p.mcu_cols * p.mcu_rows * p.blocks_per_mcu * nfr;       // the block loop does not care where a frame ends
     if (nblk <= 0) return hipSuccess;
-    if (nblk > 0x7FFFFFFFL) return hipErrorInvalidValue;
+    if (nblk > 0x7FFFFFFFL || nfr > 65535) return hipErrorInvalidValue;
     hipLaunchKernelGGL(generic::generic_idct_kernel, dim3((unsigned)((nblk + generic::G_BLOCKS - 1) / generic::G_BLOCKS)), dim3(64), 0, s, p, nblk);
     fast_div_setup((unsigned)p.hmax * 8u, &p.mw_magic, &p.mw_shift);
     fast_div_setup((unsigned)p.vmax * 8u, &p.mh_magic, &p.mh_shift);
@@ -264,7 +270,7 @@ hipError_t launch_dequant_idct_generic(const GenericDecParams& p_in, hipStream_t
         fast_div_setup((unsigned)(p.vmax / p.cv[c]), &p.dy_magic[c], &p.dy_shift[c]);
     }
     const unsigned gx = ((unsigned)p.W + 255u) / 256u, gy = ((unsigned)p.H + 3u) / 4u;
-    hipLaunchKernelGGL(generic::generic_rgb_kernel, dim3(gx, gy), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(generic::generic_rgb_kernel, dim3(gx, gy, (unsigned)nfr), dim3(256), 0, s, p);
     return hipGetLastError();
 }
 

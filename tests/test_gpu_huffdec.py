@@ -311,3 +311,46 @@ def test_decode_jpeg_batch_fast_path(J, ctx, oracle):
     for a, b_ in zip(exact, tol):
         for k in (1, 2, 3):
             assert int(np.abs(a[k].astype(np.int16) - b_[k].astype(np.int16)).max()) <= 1
+
+
+def test_decode_jpeg_batch_other_layouts(J, ctx, oracle):
+    """The batch form for the layouts that are not jpezy's own (ref decode_mcu, decoder/jpezy_decoder.hpp:504-528: any sampling
+    factors, one or three components): libjpeg 4:4:4, 4:2:2 and one-component files and synthetic 4x1 / 1x2-sampled files, several of
+    each in one call beside jpezy files -- grouped by size, layout and quantiser tables, decoded together by the batch form of the
+    Huffman decoder kernels and ONE launch of the generic inverse-transform kernels per group; every file equals the oracle's decoder,
+    colour and --gray, and the groups really took the batch form."""
+    from PIL import Image
+    from test_host_codec import ODD_LAYOUTS
+    from jpeg_synth import synth_jpeg
+    rng = np.random.default_rng(77)
+    W, H = 200, 136
+    files = []
+    for sub in (0, 1):                                   # 4:4:4 and 4:2:2, five files each
+        for k in range(5):
+            img = np.clip(rng.normal(128, 50, (H, W, 3)), 0, 255).astype(np.uint8)
+            buf = io.BytesIO()
+            Image.fromarray(img).save(buf, "JPEG", quality=80, subsampling=sub)
+            files.append(buf.getvalue())
+    for k in range(4):                                   # one component
+        img = np.clip(rng.normal(128, 60, (H, W)), 0, 255).astype(np.uint8)
+        buf = io.BytesIO()
+        Image.fromarray(img).save(buf, "JPEG", quality=70)
+        files.append(buf.getvalue())
+    n_pil = len(files)
+    for name in ("411", "h3_partial", "v4", "one_comp_2x2"):      # layouts libjpeg does not write by default (overlapping / partial planes included)
+        for k in range(3):
+            files.append(synth_jpeg(96, 80, ODD_LAYOUTS[name], seed=10 + k)[0])
+    for k in range(3):                                   # jpezy's own files in the same call
+        r, g, b = oracle.synth_rgb(W, H, frame=40 + k)
+        files.append(ctx.encode_jpeg(r, g, b, W, H))
+    ctx.set_huffdec_min_bytes(0)
+    for gray in (False, True):
+        got = ctx.decode_jpeg_batch(files, gray=gray)
+        assert ctx.last_batch_fast_count() >= n_pil + 3, ctx.last_batch_fast_count()      # (the synthetic streams may or may not settle)
+        for i, f in enumerate(files):
+            want = oracle.decode_jpeg(f, gray)
+            info, rr, gg, bb = got[i]
+            n = info.width * info.height
+            for a, e in zip((rr, gg, bb), want[-3:]):
+                assert np.array_equal(a, np.asarray(e).reshape(-1)[:n]), (i, gray)
+

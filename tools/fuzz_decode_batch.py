@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Differential fuzz of jpezy_decode_jpeg_batch's batch form (round 3) against the per-file decode: groups of libjpeg 4:2:0 files (jpezy's
-own layout, random qualities / optimised tables / contents) and jpezy files of one size, with damaged copies mixed into the groups.
+"""Differential fuzz of jpezy_decode_jpeg_batch's batch form (round 3) against the per-file decode: groups of libjpeg files (4:2:0 = jpezy's
+own layout, 4:4:4, 4:2:2, one component; random qualities / optimised tables / contents) and jpezy files of one size, with damaged copies mixed into the groups.
 Every file must get the verdict and the planes the single-file call gives it.   python tools/fuzz_decode_batch.py [groups] [seed]"""
 import io
 import sys
@@ -39,7 +39,11 @@ def main():
             img = content(rng, H, W, int(rng.integers(0, 5)))
             if rng.integers(0, 2):
                 buf = io.BytesIO()
-                Image.fromarray(img).save(buf, "JPEG", quality=quality, subsampling=2, optimize=bool(rng.integers(0, 2)))
+                sub = int(rng.choice([2, 2, 0, 1, 3]))                    # 4:2:0 (jpezy's own layout), 4:4:4, 4:2:2, one component
+                if sub == 3:
+                    Image.fromarray(img[..., 0]).save(buf, "JPEG", quality=quality, optimize=bool(rng.integers(0, 2)))
+                else:
+                    Image.fromarray(img).save(buf, "JPEG", quality=quality, subsampling=sub, optimize=bool(rng.integers(0, 2)))
                 files.append(buf.getvalue())
             else:
                 r, g, b = (np.ascontiguousarray(img[..., c]).reshape(-1) for c in range(3))

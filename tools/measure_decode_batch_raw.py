@@ -29,6 +29,19 @@ for name in ("random pixels", "smooth + noise"):
             planes = [p, p[::-1].copy(), np.roll(p, 77)]
         base.append(mk.encode_jpeg(*planes, W, H))
     sets[name] = [base[k % 16] for k in range(n)]
+# other layouts (libjpeg): 4:4:4 and 4:2:2 files of picture-like content -- the batch form of the generic kernels (round 3)
+import io  # noqa: E402
+from PIL import Image, ImageFile  # noqa: E402
+ImageFile.MAXBLOCK = 1 << 24
+for name, sub in (("libjpeg 4:4:4 smooth + noise", 0), ("libjpeg 4:2:2 smooth + noise", 1)):
+    base = []
+    for k in range(16):
+        rng = np.random.default_rng(2000 + k)
+        img = np.clip((np.sin(xx / (30.0 + k)) * 60 + np.cos(yy / 23.0) * 50 + 128)[..., None] + rng.normal(0, 8, (H, W, 3)), 0, 255).astype(np.uint8)
+        buf = io.BytesIO()
+        Image.fromarray(img).save(buf, "JPEG", quality=85, subsampling=sub)
+        base.append(buf.getvalue())
+    sets[name] = [base[k % 16] for k in range(n)]
 ref = {name: mk.decode_jpeg(fl[5]) for name, fl in sets.items()}
 mk.close()
 

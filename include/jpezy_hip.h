@@ -141,6 +141,16 @@ int jpezy_dequant_idct_generic_dev(jpezy_ctx* ctx, const int16_t* d_coeffs, cons
                                    const uint8_t comp_h[3], const uint8_t comp_v[3], const uint8_t comp_tq[3], int precision,
                                    int W, int H, int gray, uint8_t* d_r, uint8_t* d_g, uint8_t* d_b, void* stream);
 
+/*
+ * The same for n_frames frames of ONE layout, size and set of quantiser tables in one pair of launches (the loop a caller with many
+ * small files of a layout would otherwise run): frame f's coefficients at d_coeffs + f * (blocks of a frame) * 64, its planes at
+ * d_r/d_g/d_b + f * plane_stride (>= W*H, a multiple of 4).  jpezy_decode_jpeg_batch uses it for the layouts that are not jpezy's own.
+ */
+int jpezy_dequant_idct_generic_batch_dev(jpezy_ctx* ctx, const int16_t* d_coeffs, const uint16_t qt[4][64], int ncomp,
+                                         const uint8_t comp_h[3], const uint8_t comp_v[3], const uint8_t comp_tq[3], int precision,
+                                         int W, int H, int gray, int n_frames, size_t plane_stride, uint8_t* d_r, uint8_t* d_g,
+                                         uint8_t* d_b, void* stream);
+
 /* Test hook: route EVERY coefficient / sample through the kernels' exact-order fallback (the path a
  * guard-band hit takes).  0 = normal, 1 = reference-order path, 2 = (encode variant 1 only) the FP64 second
  * level, which may still defer to the reference-order path, 3 = (encode variant 1 only) the per-lane evaluator a

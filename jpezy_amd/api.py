@@ -56,6 +56,8 @@ ABI = [
     ("jpezy_dequant_idct_dev", C.c_int, [_vp, _vp, _QT, _TQ, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp]),
     ("jpezy_dequant_idct_generic", C.c_int, [_vp, _vp, _QT, C.c_int, _TQ, _TQ, _TQ, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp]),
     ("jpezy_dequant_idct_generic_dev", C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp]),
+    ("jpezy_dequant_idct_generic_batch_dev", C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_size_t,
+                                                       _vp, _vp, _vp, _vp]),
     ("jpezy_ctx_set_force_exact", None, [_vp, C.c_int]),
     ("jpezy_ctx_set_variant", C.c_int, [_vp, C.c_int]),
     ("jpezy_ctx_set_decode_tolerance", C.c_int, [_vp, C.c_int]),
@@ -217,17 +219,25 @@ class Context:
                                                          _np_ptr(planes[1]), _np_ptr(planes[2])))
         return planes
 
-    def dequant_idct_generic_dev(self, d_coeffs, info, d_r, d_g, d_b, gray=False, stream=None):
-        """any-layout decode on device memory (torch tensors): coefficients as read_jpeg_gpu leaves them -> planes"""
+    def dequant_idct_generic_dev(self, d_coeffs, info, d_r, d_g, d_b, gray=False, stream=None, n_frames=1, plane_stride=None):
+        """any-layout decode on device memory (torch tensors): coefficients as read_jpeg_gpu leaves them -> planes; n_frames > 1:
+        that many frames of the layout in one pair of launches (jpezy_dequant_idct_generic_batch_dev)"""
         import torch
         if stream is None:
             stream = torch.cuda.current_stream(d_coeffs.device).cuda_stream
         hs = (C.c_uint8 * 3)(*[max(1, info.H[i]) for i in range(3)])
         vs = (C.c_uint8 * 3)(*[max(1, info.V[i]) for i in range(3)])
         tq = (C.c_uint8 * 3)(*[info.Tq[i] for i in range(3)])
-        _check(load_library().jpezy_dequant_idct_generic_dev(self._h, d_coeffs.data_ptr(), C.byref(info.qt), info.ncomp, C.byref(hs),
-                                                             C.byref(vs), C.byref(tq), info.precision or 8, info.width, info.height,
-                                                             int(gray), d_r.data_ptr(), d_g.data_ptr(), d_b.data_ptr(), stream))
+        if n_frames == 1 and plane_stride is None:
+            _check(load_library().jpezy_dequant_idct_generic_dev(self._h, d_coeffs.data_ptr(), C.byref(info.qt), info.ncomp, C.byref(hs),
+                                                                 C.byref(vs), C.byref(tq), info.precision or 8, info.width, info.height,
+                                                                 int(gray), d_r.data_ptr(), d_g.data_ptr(), d_b.data_ptr(), stream))
+        else:       # n_frames frames of this layout: coefficients frame after frame, planes plane_stride apart
+            stride = plane_stride if plane_stride is not None else info.width * info.height
+            _check(load_library().jpezy_dequant_idct_generic_batch_dev(self._h, d_coeffs.data_ptr(), C.byref(info.qt), info.ncomp, C.byref(hs),
+                                                                       C.byref(vs), C.byref(tq), info.precision or 8, info.width, info.height,
+                                                                       int(gray), n_frames, stride, d_r.data_ptr(), d_g.data_ptr(),
+                                                                       d_b.data_ptr(), stream))
 
     # ---- device-pointer entry points (torch tensors on this context's device) ----
     def fdct_quant_dev(self, d_r, d_g, d_b, W, H, d_coeffs, gray=False, n_frames=1, plane_stride=None, stream=None):

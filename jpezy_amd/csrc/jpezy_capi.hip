@@ -712,6 +712,19 @@ int jpezy_dequant_idct_generic_dev(jpezy_ctx* c, const int16_t* d_coeffs, const 
                             nullptr);
 }
 
+int jpezy_dequant_idct_generic_batch_dev(jpezy_ctx* c, const int16_t* d_coeffs, const uint16_t qt[4][64], int ncomp, const uint8_t comp_h[3],
+                                         const uint8_t comp_v[3], const uint8_t comp_tq[3], int precision, int W, int H, int gray,
+                                         int n_frames, size_t plane_stride, uint8_t* d_r, uint8_t* d_g, uint8_t* d_b, void* stream)
+{
+    if (int rc = check_dims(c, W, H, n_frames)) return rc;
+    if (!d_coeffs || !qt || !comp_h || !comp_v || !comp_tq || !d_r || !d_g || !d_b) return set_err(JPEZY_E_BADARG, "null pointer");
+    if (!aligned16(d_coeffs)) return set_err(JPEZY_E_BADARG, "d_coeffs must be 16-byte aligned");
+    if (plane_stride < (size_t)W * H || (plane_stride & 3)) return set_err(JPEZY_E_BADARG, "plane_stride must hold a plane and be a multiple of 4");
+    HIP_TRY(hipSetDevice(c->device));
+    return generic_dev_core(c, d_coeffs, qt, ncomp, comp_h, comp_v, comp_tq, W, H, gray, precision, d_r, d_g, d_b, (hipStream_t)stream,
+                            nullptr, n_frames, plane_stride);
+}
+
 static int dequant_idct_generic_impl(jpezy_ctx* c, const int16_t* coeffs, const uint16_t qt[4][64], int ncomp, const uint8_t comp_h[3],
                                      const uint8_t comp_v[3], const uint8_t comp_tq[3], int W, int H, int gray, int precision,
                                      uint8_t* r, uint8_t* g, uint8_t* b, bool coeffs_on_device = false)

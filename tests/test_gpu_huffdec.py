@@ -198,6 +198,18 @@ def test_any_layout_pipeline_on_device_memory(J, ctx, oracle):
             want = oracle.decode_jpeg(data, gray)
             for a, e in zip(out, want[-3:]):
                 assert np.array_equal(a.cpu().numpy(), np.asarray(e).reshape(-1)[:n])
+            # the batch form: three frames of the layout (the file, a sign-flipped and a halved copy of its coefficients) in one call,
+            # planes a padded stride apart, against the single-frame call on each
+            stride = (n + 63) // 4 * 4
+            co3 = torch.stack([d_co.reshape(-1), -d_co.reshape(-1), d_co.reshape(-1) // 2]).contiguous()
+            pl = [torch.zeros(3 * stride, dtype=torch.uint8, device=d_co.device) for _ in range(3)]
+            ctx.dequant_idct_generic_dev(co3, info, pl[0], pl[1], pl[2], gray=gray, n_frames=3, plane_stride=stride)
+            for f in range(3):
+                one = [torch.empty(n, dtype=torch.uint8, device=d_co.device) for _ in range(3)]
+                ctx.dequant_idct_generic_dev(co3[f], info, one[0], one[1], one[2], gray=gray)
+                torch.cuda.synchronize()
+                for q in range(3):
+                    assert torch.equal(pl[q][f * stride: f * stride + n], one[q]), (f, q)
 
 
 def test_decode_jpeg_batch(J, ctx, oracle):

@@ -252,9 +252,10 @@ int jpezy_read_jpeg(const uint8_t* data, size_t len, jpezy_frame_info* info, int
  * The same head with the Huffman decoding on the GPU (decode side): the header is parsed on the
  * host, the entropy-coded segment is decoded by the self-synchronising parallel decoder of jpezy_huffdec.hip, the
  * coefficients ([mcu][block][64] zig-zag int16, coeff_cap elements) are left in DEVICE memory, ready for
- * jpezy_dequant_idct_dev / _generic.  Streams with restart intervals and anything irregular (invalid code, early end)
- * are decoded by jpezy_read_jpeg's host decoder instead and uploaded, so results and error codes are always those of
- * jpezy_read_jpeg.  d_coeffs may be NULL (header only).  Synchronous.
+ * jpezy_dequant_idct_dev / _generic.  A scan with restart intervals (DRI / RSTn, decoder/jpezy_decoder.hpp:152-163) is decoded as
+ * that many independent streams when it is regular -- one RSTn behind every interval but the last, nothing else.  Anything irregular
+ * (a missing or extra marker, an invalid code, an early end) is decoded by jpezy_read_jpeg's host decoder instead and uploaded, so
+ * results and error codes are always those of jpezy_read_jpeg.  d_coeffs may be NULL (header only).  Synchronous.
  */
 int jpezy_read_jpeg_gpu(jpezy_ctx* ctx, const uint8_t* data, size_t len, jpezy_frame_info* info, int16_t* d_coeffs,
                         size_t coeff_cap);

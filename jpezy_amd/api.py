@@ -276,7 +276,7 @@ class Context:
 
     def read_jpeg_gpu(self, data):
         """.jpg bytes -> (FrameInfo, torch int16 tensor [mcu_rows, mcu_cols, blocks_per_mcu, 64] on the device): header
-        parsed on the host, Huffman decoding on the GPU (host decoder for streams with restart markers)."""
+        parsed on the host, Huffman decoding on the GPU (restart intervals as independent streams; the host decoder for anything irregular)."""
         import torch
         lib = load_library()
         arr = np.frombuffer(bytes(data), dtype=np.uint8)

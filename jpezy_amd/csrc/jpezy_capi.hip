@@ -1177,6 +1177,231 @@ struct RefineBudget {
     }
 };
 
+namespace {
+
+// ---- the batch form of the GPU Huffman decoder over a list of independent streams (jpezy_huffdec.h) ----
+// A stream is an entropy-coded segment that starts in the known state (bit 0, block 0, DC, predictors 0): the scan of a file
+// (jpezy_decode_jpeg_batch: one stream per file, every file with its own tables) or one restart interval of a scan
+// (jpezy_read_jpeg_gpu: the intervals of a file share one set of tables).  All streams of a call have the same MCU structure.
+struct DevStream {
+    const uint8_t* scan;                // host memory: the segment, up to (not including) the marker that ends it
+    size_t n;
+    unsigned total_blocks;              // blocks the stream holds (whole MCUs)
+    unsigned long long coeff_off;       // int16 offset of its first coefficient in the output
+    unsigned setup;                     // index into the call's tables
+};
+struct StreamGeom {
+    unsigned bpm, ncomp, cstart[3], ccount[3];      // blocks per MCU; component q owns blocks [cstart, cstart + ccount) of every MCU
+};
+
+// Decodes the streams into d_coef (device, coef_elems int16, zeroed here): one sequence of launches for all of them.  ok[k] = 1 for the
+// streams that converged, decoded without an invalid code and ended inside their data; the others are the caller's to hand to the
+// host decoder, whose verdict is the authoritative one.  setup_usable[j] = 0: tables the device form cannot express.
+int huffdec_streams(jpezy_ctx* c, const std::vector<DevStream>& streams, const std::vector<jpezy_dev::huffdec::Setup>& setups,
+                    const std::vector<char>& setup_usable, const StreamGeom& geom, int16_t* d_coef, size_t coef_elems, std::vector<char>& ok,
+                    const std::function<void(const char*)>& lap, bool per_lane = false)
+{
+    namespace HD = jpezy_dev::huffdec;
+    namespace E = jpezy_dev::entropy;
+    hipStream_t s = c->stream;
+    const unsigned nf = (unsigned)streams.size();
+    const unsigned L = HD::subseq_bits();
+    const size_t chunk = HD::chunk_bytes();
+    ok.assign(nf, 0);
+
+    // geometry
+    std::vector<HD::BatchFile> F(nf);
+    std::vector<unsigned> wg_file, wg_first;
+    size_t total_chunks = 0, total_slots = 0, u_bytes = 0;
+    std::vector<char> usable(nf, 1);
+    for (unsigned k = 0; k < nf; ++k) {
+        const DevStream& st = streams[k];
+        HD::BatchFile& f = F[k];
+        std::memset(&f, 0, sizeof f);
+        f.chunk0 = (unsigned)total_chunks;
+        f.n_chunks = (unsigned)((st.n + chunk - 1) / chunk);
+        f.n_bytes = (unsigned)st.n;
+        f.sub0 = (unsigned)total_slots;
+        f.n_sub_max = (unsigned)((st.n * 8 + L - 1) / L);
+        f.u_off = u_bytes;
+        const size_t ub = (((size_t)f.n_sub_max * L / 8 + 64) + 3) & ~(size_t)3;
+        f.u_words = (unsigned)(ub / 4);
+        f.coeff_off = st.coeff_off;
+        f.total_blocks = st.total_blocks;
+        f.nmcu = st.total_blocks / geom.bpm; f.bpm = geom.bpm; f.ncomp = geom.ncomp;
+        for (unsigned q = 0; q < 3; ++q) { f.cstart[q] = geom.cstart[q]; f.ccount[q] = geom.ccount[q]; }
+        f.setup = st.setup;
+        usable[k] = setup_usable[st.setup];
+        total_chunks += f.n_chunks;
+        total_slots += ((size_t)f.n_sub_max + 255) / 256 * 256;           // a workgroup never straddles two streams
+        u_bytes += ub;
+        for (unsigned i0 = 0; i0 < f.n_sub_max; i0 += 256) { wg_file.push_back(k); wg_first.push_back(i0); }
+    }
+    if (total_chunks >= 0xFFFFFFFFull || total_slots >= 0xFFFFFFFFull) return set_err(JPEZY_E_BADARG, "GPU Huffman decoder: too much data for one call");
+    const unsigned n_wg = (unsigned)wg_file.size();
+    const unsigned ns = (unsigned)setups.size();
+
+    // buffers
+    const size_t scan_bytes = total_chunks * chunk;
+    if (c->b_pin_cap < scan_bytes) {
+        if (c->b_pin) (void)hipHostFree(c->b_pin);
+        c->b_pin = nullptr; c->b_pin_cap = 0;
+        HIP_TRY(hipHostMalloc((void**)&c->b_pin, scan_bytes + (scan_bytes >> 2) + 4096, hipHostMallocDefault));
+        c->b_pin_cap = scan_bytes + (scan_bytes >> 2) + 4096;
+    }
+    const size_t meta_F = (sizeof(HD::BatchFile) * nf + 255) & ~(size_t)255, meta_S = (sizeof(HD::Setup) * ns + 255) & ~(size_t)255;
+    const size_t meta_wg = ((size_t)n_wg * 4 + 255) & ~(size_t)255, meta_act = ((size_t)nf * 4 + 255) & ~(size_t)255;
+    if (int rc = c->b_scan.reserve(scan_bytes + 64)) return rc;
+    if (int rc = c->b_U.reserve(u_bytes + 64)) return rc;
+    if (int rc = c->b_cnt.reserve(std::max(total_chunks, total_slots) * sizeof(uint32_t))) return rc;
+    if (int rc = c->b_rb.reserve((std::max(total_chunks, total_slots) + 1) * sizeof(unsigned long long))) return rc;
+    if (int rc = c->b_state.reserve(total_slots * 3 * sizeof(uint32_t))) return rc;
+    if (int rc = c->b_prop.reserve((total_slots + 1) * sizeof(unsigned long long))) return rc;
+    if (int rc = c->b_meta.reserve(meta_F + meta_S + 2 * meta_wg + meta_act)) return rc;
+    if (int rc = c->e_tmp.reserve(E::scan_tmp_elems(std::max(total_chunks, total_slots)) * sizeof(unsigned long long))) return rc;
+    uint8_t* meta = (uint8_t*)c->b_meta.p;
+    HD::BatchFile* d_F = (HD::BatchFile*)meta;
+    HD::Setup* d_S = (HD::Setup*)(meta + meta_F);
+    unsigned* d_wg_file = (unsigned*)(meta + meta_F + meta_S);
+    unsigned* d_wg_first = (unsigned*)(meta + meta_F + meta_S + meta_wg);
+    unsigned* d_active = (unsigned*)(meta + meta_F + meta_S + 2 * meta_wg);
+
+    // segments side by side (64-byte aligned, zero padded) in pinned memory: one upload
+    for (unsigned k = 0; k < nf; ++k) {
+        uint8_t* dst = c->b_pin + (size_t)F[k].chunk0 * chunk;
+        std::memcpy(dst, streams[k].scan, streams[k].n);
+        std::memset(dst + streams[k].n, 0, (size_t)F[k].n_chunks * chunk - streams[k].n);
+    }
+    HIP_TRY(hipMemcpyAsync(c->b_scan.p, c->b_pin, scan_bytes, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d_F, F.data(), sizeof(HD::BatchFile) * nf, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d_S, setups.data(), sizeof(HD::Setup) * ns, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d_wg_file, wg_file.data(), (size_t)n_wg * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d_wg_first, wg_first.data(), (size_t)n_wg * 4, hipMemcpyHostToDevice, s));
+    lap("setup + scans up");
+
+    // 1. stuffing out
+    HIP_TRY(hipMemsetAsync(c->b_U.p, 0, u_bytes, s));
+    HIP_TRY(HD::launch_unstuff_count_batch((const uint8_t*)c->b_scan.p, d_F, nf, (unsigned)total_chunks, (uint32_t*)c->b_cnt.p, s));
+    HIP_TRY(E::launch_scan_u32((const uint32_t*)c->b_cnt.p, (unsigned long long*)c->b_rb.p, total_chunks, (unsigned long long*)c->e_tmp.p, s));
+    HIP_TRY(HD::launch_unstuff_copy_batch((const uint8_t*)c->b_scan.p, d_F, nf, (unsigned)total_chunks, (const unsigned long long*)c->b_rb.p,
+                                          (uint8_t*)c->b_U.p, s));
+    lap("unstuff");
+    if (per_lane) {
+        // short streams with one set of tables (restart intervals of a few MCUs): a lane walks a whole stream -- no speculation, no
+        // synchronisation launches, no scans; symbols, coefficients and DC predictors in one launch (jpezy_huffdec.hip)
+        HIP_TRY(hipMemsetAsync(d_coef, 0, coef_elems * sizeof(int16_t), s));
+        HIP_TRY(HD::launch_stream_per_lane(d_S, (const uint32_t*)c->b_U.p, d_F, nf, d_coef, s));
+        HIP_TRY(hipMemcpyAsync(F.data(), d_F, sizeof(HD::BatchFile) * nf, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        lap("decode (a lane per stream)");
+        for (unsigned k = 0; k < nf; ++k) {
+            const unsigned long long data_bits = ((unsigned long long)F[k].n_bytes - F[k].removed) * 8;
+            ok[k] = usable[k] && !F[k].error && F[k].last_bit <= data_bits;
+        }
+        return JPEZY_OK;
+    }
+    // 2. speculation, confirmation, refinement -- one loop for all streams
+    uint32_t* d_exit = (uint32_t*)c->b_state.p;
+    uint32_t* d_last = d_exit + total_slots;
+    unsigned* d_nblocks = (unsigned*)(d_last + total_slots);
+    HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)d_exit, (int)0x80000000u, total_slots, s));
+    HIP_TRY(hipMemsetAsync(d_last, 0xFF, total_slots * 4, s));
+    HIP_TRY(hipMemsetAsync(d_nblocks, 0, total_slots * 4, s));
+    HIP_TRY(HD::launch_speculate_batch(d_S, (const uint32_t*)c->b_U.p, d_F, d_wg_file, d_wg_first, n_wg, (unsigned)total_slots,
+                                       (unsigned long long*)c->b_prop.p, d_exit, s));
+    lap("speculate");
+    std::vector<unsigned> active(nf), prev_moved(nf, 0u);
+    std::vector<char> converged(nf, 0), dead(nf, 0);
+    for (unsigned k = 0; k < nf; ++k) { active[k] = usable[k] ? 1u : 0u; dead[k] = !usable[k]; }
+    RefineBudget budget;
+    for (int pass = 0; pass <= RefineBudget::MAX_LAUNCHES; ++pass) {
+        bool any = false;
+        for (unsigned k = 0; k < nf; ++k) any = any || active[k];
+        if (!any) break;
+        HIP_TRY(hipMemcpyAsync(d_active, active.data(), (size_t)nf * 4, hipMemcpyHostToDevice, s));
+        HIP_TRY(HD::launch_sync_batch(d_S, (const uint32_t*)c->b_U.p, d_F, d_wg_file, d_wg_first, n_wg, d_active, d_exit, d_last, d_nblocks,
+                                      pass == 0 ? RefineBudget::FIRST_STEPS : RefineBudget::STEPS, s));
+        HIP_TRY(hipMemcpyAsync(F.data(), d_F, sizeof(HD::BatchFile) * nf, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        for (unsigned k = 0; k < nf; ++k) {
+            if (!active[k]) continue;
+            const unsigned moved = F[k].changed[0], pending = F[k].changed[1] + F[k].changed[2];
+            if (F[k].n_sub == 0) { active[k] = 0; dead[k] = 1; continue; }
+            if (pending == 0) { active[k] = 0; converged[k] = 1; continue; }
+            // many proposals moved at the first look (periodic data never falls into step), or the refinement launches have
+            // stopped paying for this stream (RefineBudget): the caller's other path
+            if (pass == 0 ? F[k].changed[3] > F[k].n_sub / 2 + 16 : !budget.go_on(pass + 1, prev_moved[k], moved)) { active[k] = 0; dead[k] = 1; }
+            prev_moved[k] = moved;
+        }
+        // reset the per-pass counters of the streams that go on (one launch: there may be tens of thousands of streams)
+        bool any_left = false;
+        for (unsigned k = 0; k < nf; ++k) any_left = any_left || active[k];
+        if (any_left) {
+            HIP_TRY(hipMemcpyAsync(d_active, active.data(), (size_t)nf * 4, hipMemcpyHostToDevice, s));
+            HIP_TRY(HD::launch_reset_changed_batch(d_F, d_active, nf, s));
+        }
+    }
+    lap("confirm + refine");
+    // 3. block index of every lane, coefficients, DC predictors -- for the streams that converged
+    for (unsigned k = 0; k < nf; ++k) active[k] = converged[k] ? 1u : 0u;
+    HIP_TRY(hipMemcpyAsync(d_active, active.data(), (size_t)nf * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(c->b_cnt.p, d_nblocks, total_slots * 4, hipMemcpyDeviceToDevice, s));
+    unsigned long long* d_bb = (unsigned long long*)c->b_prop.p;          // (the proposals are dead: same buffer)
+    HIP_TRY(E::launch_scan_u32((const uint32_t*)c->b_cnt.p, d_bb, total_slots, (unsigned long long*)c->e_tmp.p, s));
+    HIP_TRY(hipMemsetAsync(d_coef, 0, coef_elems * sizeof(int16_t), s));
+    HIP_TRY(HD::launch_emit_batch(d_S, (const uint32_t*)c->b_U.p, d_F, d_wg_file, d_wg_first, n_wg, d_active, d_exit, d_bb, d_coef, s));
+    HIP_TRY(HD::launch_dc_prefix_batch(d_coef, d_F, d_active, nf, s));
+    HIP_TRY(hipMemcpyAsync(F.data(), d_F, sizeof(HD::BatchFile) * nf, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    lap("emit + DC");
+    for (unsigned k = 0; k < nf; ++k) {
+        const unsigned long long data_bits = ((unsigned long long)F[k].n_bytes - F[k].removed) * 8;
+        ok[k] = converged[k] && !F[k].error && F[k].last_bit <= data_bits;
+    }
+    return JPEZY_OK;
+}
+
+// the device tables of one scan: Huffman tables + the table sequence of an MCU; false: something the device form cannot express
+bool build_dev_setup(jpezy_dev::huffdec::Setup& S, const jpezy_host::ScanSetup& setup, const jpezy_frame_info& info, unsigned total_blocks)
+{
+    bool usable = true;
+    std::memset(&S, 0, sizeof S);
+    for (int td = 0; td < 3; ++td) {
+        if (setup.present[td]) usable = build_dev_table(S.dc[td], setup.bits[td], setup.vals[td], setup.nvals[td], true) && usable;
+        if (setup.present[4 + td]) usable = build_dev_table(S.ac[td], setup.bits[4 + td], setup.vals[4 + td], setup.nvals[4 + td], false) && usable;
+    }
+    S.total_blocks = total_blocks;
+    // The decoder's state carries the block's position inside the MCU only to pick the tables.  It counts modulo the
+    // PERIOD of the table sequence: with one table pair for every block (a one-component file, or all Td equal) a
+    // decoder that has found the right bit position is in the right state whatever MCU phase it guessed.
+    int seq[48], nb = 0;
+    for (int q = 0; q < info.ncomp; ++q)
+        for (int t = info.H[q] * info.V[q]; t > 0 && nb < 48; --t) seq[nb++] = setup.Td[q];
+    int period = nb;
+    for (int pd = 1; pd < nb; ++pd) {
+        if (nb % pd) continue;
+        bool same = true;
+        for (int i = pd; i < nb && same; ++i) same = seq[i] == seq[i - pd];
+        if (same) { period = pd; break; }
+    }
+    S.bpm = period;
+    return pack_td_sequence(seq, period, &S.tdmask) && usable;
+}
+
+StreamGeom stream_geom(const jpezy_frame_info& info)
+{
+    StreamGeom g;
+    std::memset(&g, 0, sizeof g);
+    g.bpm = (unsigned)info.blocks_per_mcu; g.ncomp = (unsigned)info.ncomp;
+    for (unsigned q = 0, at = 0; q < (unsigned)info.ncomp && q < 3; ++q) {
+        g.cstart[q] = at; g.ccount[q] = (unsigned)(info.H[q] * info.V[q]);
+        at += g.ccount[q];
+    }
+    return g;
+}
+
+}  // namespace
+
 int jpezy_read_jpeg_gpu(jpezy_ctx* c, const uint8_t* data, size_t len, jpezy_frame_info* info, int16_t* d_coeffs, size_t coeff_cap)
 try {
     namespace HD = jpezy_dev::huffdec;
@@ -1195,11 +1420,61 @@ try {
     if (coeff_cap < total) return set_err(JPEZY_E_NOSPACE, "read_jpeg_gpu: coefficient buffer too small");
     if (!aligned16(d_coeffs)) return set_err(JPEZY_E_BADARG, "read_jpeg_gpu: d_coeffs must be 16-byte aligned");
 
-    // what the GPU decoder takes: no restart intervals, at most 48 blocks per MCU (3 components of 4 x 4), every selected table present
-    bool gpu_ok = info->restart_interval == 0 && bpm <= 48 && total_blocks < 0xFFFFFFFFull && setup.scan_pos < len;
+    // what the GPU decoder takes: at most 48 blocks per MCU (3 components of 4 x 4), every selected table present
+    bool gpu_ok = bpm <= 48 && total_blocks < 0xFFFFFFFFull && setup.scan_pos < len;
     for (int i = 0; i < info->ncomp && gpu_ok; ++i)
         gpu_ok = setup.Td[i] >= 0 && setup.Td[i] <= 2 && setup.present[setup.Td[i]] && setup.present[4 + setup.Td[i]];
     if (!gpu_ok) return read_jpeg_host_to_device(c, data, len, info, d_coeffs, total);
+    if (info->restart_interval != 0) {
+        // Restart intervals (DRI / RSTn, ref decoder/jpezy_decoder.hpp:152-163): every interval starts byte aligned, at an MCU boundary, with
+        // the predictors at zero -- an entry point.  A scan that is REGULAR (exactly one RSTn behind every interval but the last, nothing else
+        // before the marker that ends the scan) is decoded as that many independent streams by the batch form of the kernels; anything else --
+        // a missing or extra marker, an interval that runs out of data, tables the device form cannot express -- is the host decoder's, whose
+        // reading of such files (markers swallowed as data, predictors kept) is the reference's and nobody else's.
+        const size_t Ri = (size_t)info->restart_interval, n_int = (nmcu + Ri - 1) / Ri;
+        const uint8_t* scan = data + setup.scan_pos;
+        const size_t n_all = len - setup.scan_pos;
+        // intervals of a few KB: a lane per interval; longer ones: subsequences, speculation and synchronisation inside every interval
+        // (a workgroup per 256 subsequences of an interval, so at most 65,536 of those)
+        const bool per_lane = n_all / n_int <= 4096;
+        bool regular = n_int >= 1 && n_int <= (per_lane ? (size_t)1 << 20 : (size_t)65536) && n_all >= c->h_min_bytes;
+        std::vector<DevStream> streams;
+        size_t at = 0;
+        while (regular) {
+            const size_t seg = jpezy_host::entropy_segment_length(scan + at, n_all - at);       // bytes up to the next marker
+            const size_t mk = at + seg;
+            const unsigned i = (unsigned)streams.size();
+            const size_t mcus = std::min(Ri, nmcu - (size_t)i * Ri);
+            streams.push_back({ scan + at, seg, (unsigned)(mcus * bpm), (unsigned long long)i * Ri * bpm * 64, 0u });
+            const bool rst = mk + 1 < n_all && scan[mk + 1] >= 0xD0 && scan[mk + 1] <= 0xD7;
+            if (!rst) break;                                  // the marker that ends the scan (or the end of the data)
+            at = mk + 2;
+            if (streams.size() == n_int) regular = false;     // one marker too many
+        }
+        regular = regular && streams.size() == n_int;
+        for (const DevStream& st : streams) regular = regular && st.n > 0;
+        if (regular) {
+            std::vector<HD::Setup> setups(1);
+            std::vector<char> usable(1, build_dev_setup(setups[0], setup, *info, (unsigned)(Ri * bpm)) ? 1 : 0);
+            std::vector<char> okv;
+            const bool dbg = std::getenv("JPEZY_BATCH_DEBUG") != nullptr;
+            auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+            double t_mark = now();
+            auto lap = [&](const char* what) {
+                if (!dbg) return;
+                (void)hipStreamSynchronize(c->stream);
+                const double t = now();
+                std::fprintf(stderr, "  restart intervals (%zu streams): %-28s %.3f ms\n", streams.size(), what, (t - t_mark) * 1e3);
+                t_mark = t;
+            };
+            if (usable[0] && huffdec_streams(c, streams, setups, usable, stream_geom(*info), d_coeffs, total, okv, lap, per_lane) == JPEZY_OK) {
+                bool all = true;
+                for (char v : okv) all = all && v;
+                if (all) { c->h_last_passes = 1; return JPEZY_OK; }
+            }
+        }
+        return read_jpeg_host_to_device(c, data, len, info, d_coeffs, total);
+    }
 
     // The entropy-coded segment ends at the first marker (0xFF followed by anything but 0x00).  The device finds it while it counts the
     // stuffing (jpezy_huffdec.hip): the file goes up from the first scan byte to its end and the host never walks it -- a pass over a
@@ -1433,19 +1708,16 @@ struct FastFile {
 };
 
 // One slice of a group (same W x H, same layout, same quantiser tables): Huffman decoding of all files in one sequence of launches
-// (jpezy_huffdec.h, batch form), ONE inverse-transform launch over the slice -- the fused kernel for jpezy's own 2x2,1x1,1x1 layout, the
-// generic kernels' batch form for every other layout decode_mcu handles --, the planes copied out per file.
+// (huffdec_streams: a stream per file), ONE inverse-transform launch over the slice -- the fused kernel for jpezy's own 2x2,1x1,1x1
+// layout, the generic kernels' batch form for every other layout decode_mcu handles --, the planes copied out per file.
 // ok[k] = 1 for files decoded here; the others (not converged, irregular stream) are left to the per-file path, whose verdict --
 // host decoder included -- is the authoritative one.
 int decode_slice_fast(jpezy_ctx* c, const std::vector<FastFile>& files, const jpezy_frame_info& info, int gray, int plane_buf,
                       std::vector<char>& ok)
 {
     namespace HD = jpezy_dev::huffdec;
-    namespace E = jpezy_dev::entropy;
     hipStream_t s = c->stream;
     const unsigned nf = (unsigned)files.size();
-    const unsigned L = HD::subseq_bits();
-    const size_t chunk = HD::chunk_bytes();
     const int W = info.width, H = info.height;
     const unsigned bpm = (unsigned)info.blocks_per_mcu;
     const size_t nmcu = (size_t)info.mcu_cols * info.mcu_rows, cpf = nmcu * bpm * 64, plane = (size_t)W * H, pstride = (plane + 15) & ~(size_t)15;
@@ -1462,158 +1734,16 @@ int decode_slice_fast(jpezy_ctx* c, const std::vector<FastFile>& files, const jp
         std::fprintf(stderr, "  batch slice (%u files): %-28s %.3f ms\n", nf, what, (t - t_mark) * 1e3);
         t_mark = t;
     };
-
-    // geometry of the slice
-    std::vector<HD::BatchFile> F(nf);
+    std::vector<DevStream> streams(nf);
     std::vector<HD::Setup> setups(nf);
-    std::vector<unsigned> wg_file, wg_first;
-    size_t total_chunks = 0, total_slots = 0, u_bytes = 0;
-    std::vector<char> usable(nf, 1);
+    std::vector<char> setup_usable(nf, 1);
     for (unsigned k = 0; k < nf; ++k) {
-        const FastFile& ff = files[k];
-        HD::BatchFile& f = F[k];
-        std::memset(&f, 0, sizeof f);
-        f.chunk0 = (unsigned)total_chunks;
-        f.n_chunks = (unsigned)((ff.n + chunk - 1) / chunk);
-        f.n_bytes = (unsigned)ff.n;
-        f.sub0 = (unsigned)total_slots;
-        f.n_sub_max = (unsigned)((ff.n * 8 + L - 1) / L);
-        f.u_off = u_bytes;
-        const size_t ub = (((size_t)f.n_sub_max * L / 8 + 64) + 3) & ~(size_t)3;
-        f.u_words = (unsigned)(ub / 4);
-        f.coeff_off = (unsigned long long)k * cpf;
-        f.total_blocks = (unsigned)(nmcu * bpm);
-        f.nmcu = (unsigned)nmcu; f.bpm = bpm; f.ncomp = (unsigned)info.ncomp;
-        for (unsigned q = 0, at = 0; q < (unsigned)info.ncomp; ++q) {
-            f.cstart[q] = at; f.ccount[q] = (unsigned)(info.H[q] * info.V[q]);
-            at += f.ccount[q];
-        }
-        total_chunks += f.n_chunks;
-        total_slots += ((size_t)f.n_sub_max + 255) / 256 * 256;           // a workgroup never straddles two files
-        u_bytes += ub;
-        for (unsigned i0 = 0; i0 < f.n_sub_max; i0 += 256) { wg_file.push_back(k); wg_first.push_back(i0); }
-        // tables (any DHT the file carries); one the device form cannot express sends the file to the per-file path
-        HD::Setup& S = setups[k];
-        std::memset(&S, 0, sizeof S);
-        for (int td = 0; td < 3; ++td) {
-            if (ff.setup.present[td]) usable[k] = build_dev_table(S.dc[td], ff.setup.bits[td], ff.setup.vals[td], ff.setup.nvals[td], true) && usable[k];
-            if (ff.setup.present[4 + td]) usable[k] = build_dev_table(S.ac[td], ff.setup.bits[4 + td], ff.setup.vals[4 + td], ff.setup.nvals[4 + td], false) && usable[k];
-        }
-        S.total_blocks = f.total_blocks;
-        {
-            int seq[48], nb = 0;                                       // (the caller admits at most 48 blocks per MCU)
-            for (int q = 0; q < info.ncomp; ++q)
-                for (int t = info.H[q] * info.V[q]; t > 0; --t) seq[nb++] = ff.setup.Td[q];
-            int period = nb;
-            for (int pd = 1; pd < nb; ++pd) {
-                if (nb % pd) continue;
-                bool same = true;
-                for (int i = pd; i < nb && same; ++i) same = seq[i] == seq[i - pd];
-                if (same) { period = pd; break; }
-            }
-            S.bpm = period;
-            usable[k] = pack_td_sequence(seq, period, &S.tdmask) && usable[k];
-        }
+        streams[k] = { files[k].scan, files[k].n, (unsigned)(nmcu * bpm), (unsigned long long)k * cpf, k };
+        setup_usable[k] = build_dev_setup(setups[k], files[k].setup, info, (unsigned)(nmcu * bpm));      // (any DHT the file carries)
     }
-    if (total_chunks >= 0xFFFFFFFFull || total_slots >= 0xFFFFFFFFull) return set_err(JPEZY_E_BADARG, "decode_jpeg_batch: slice too large");
-    const unsigned n_wg = (unsigned)wg_file.size();
-
-    // buffers
-    const size_t scan_bytes = total_chunks * chunk;
-    if (c->b_pin_cap < scan_bytes) {
-        if (c->b_pin) (void)hipHostFree(c->b_pin);
-        c->b_pin = nullptr; c->b_pin_cap = 0;
-        HIP_TRY(hipHostMalloc((void**)&c->b_pin, scan_bytes + (scan_bytes >> 2) + 4096, hipHostMallocDefault));
-        c->b_pin_cap = scan_bytes + (scan_bytes >> 2) + 4096;
-    }
-    const size_t meta_F = (sizeof(HD::BatchFile) * nf + 255) & ~(size_t)255, meta_S = (sizeof(HD::Setup) * nf + 255) & ~(size_t)255;
-    const size_t meta_wg = ((size_t)n_wg * 4 + 255) & ~(size_t)255, meta_act = ((size_t)nf * 4 + 255) & ~(size_t)255;
-    if (int rc = c->b_scan.reserve(scan_bytes + 64)) return rc;
-    if (int rc = c->b_U.reserve(u_bytes + 64)) return rc;
-    if (int rc = c->b_cnt.reserve(std::max(total_chunks, total_slots) * sizeof(uint32_t))) return rc;
-    if (int rc = c->b_rb.reserve((std::max(total_chunks, total_slots) + 1) * sizeof(unsigned long long))) return rc;
-    if (int rc = c->b_state.reserve(total_slots * 3 * sizeof(uint32_t))) return rc;
-    if (int rc = c->b_prop.reserve((total_slots + 1) * sizeof(unsigned long long))) return rc;
-    if (int rc = c->b_meta.reserve(meta_F + meta_S + 2 * meta_wg + meta_act)) return rc;
     if (int rc = c->b_coef.reserve((size_t)nf * cpf * sizeof(int16_t))) return rc;
-    if (int rc = c->e_tmp.reserve(E::scan_tmp_elems(std::max(total_chunks, total_slots)) * sizeof(unsigned long long))) return rc;
-    uint8_t* meta = (uint8_t*)c->b_meta.p;
-    HD::BatchFile* d_F = (HD::BatchFile*)meta;
-    HD::Setup* d_S = (HD::Setup*)(meta + meta_F);
-    unsigned* d_wg_file = (unsigned*)(meta + meta_F + meta_S);
-    unsigned* d_wg_first = (unsigned*)(meta + meta_F + meta_S + meta_wg);
-    unsigned* d_active = (unsigned*)(meta + meta_F + meta_S + 2 * meta_wg);
-
-    // scans side by side (64-byte aligned, zero padded) in pinned memory: one upload
-    for (unsigned k = 0; k < nf; ++k) {
-        uint8_t* dst = c->b_pin + (size_t)F[k].chunk0 * chunk;
-        std::memcpy(dst, files[k].scan, files[k].n);
-        std::memset(dst + files[k].n, 0, (size_t)F[k].n_chunks * chunk - files[k].n);
-    }
-    HIP_TRY(hipMemcpyAsync(c->b_scan.p, c->b_pin, scan_bytes, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(d_F, F.data(), sizeof(HD::BatchFile) * nf, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(d_S, setups.data(), sizeof(HD::Setup) * nf, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(d_wg_file, wg_file.data(), (size_t)n_wg * 4, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(d_wg_first, wg_first.data(), (size_t)n_wg * 4, hipMemcpyHostToDevice, s));
-    lap("setup + scans up");
-
-    // 1. stuffing out
-    HIP_TRY(hipMemsetAsync(c->b_U.p, 0, u_bytes, s));
-    HIP_TRY(HD::launch_unstuff_count_batch((const uint8_t*)c->b_scan.p, d_F, nf, (unsigned)total_chunks, (uint32_t*)c->b_cnt.p, s));
-    HIP_TRY(E::launch_scan_u32((const uint32_t*)c->b_cnt.p, (unsigned long long*)c->b_rb.p, total_chunks, (unsigned long long*)c->e_tmp.p, s));
-    HIP_TRY(HD::launch_unstuff_copy_batch((const uint8_t*)c->b_scan.p, d_F, nf, (unsigned)total_chunks, (const unsigned long long*)c->b_rb.p,
-                                          (uint8_t*)c->b_U.p, s));
-    lap("unstuff");
-    // 2. speculation, confirmation, refinement -- one loop for the whole slice
-    uint32_t* d_exit = (uint32_t*)c->b_state.p;
-    uint32_t* d_last = d_exit + total_slots;
-    unsigned* d_nblocks = (unsigned*)(d_last + total_slots);
-    HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)d_exit, (int)0x80000000u, total_slots, s));
-    HIP_TRY(hipMemsetAsync(d_last, 0xFF, total_slots * 4, s));
-    HIP_TRY(hipMemsetAsync(d_nblocks, 0, total_slots * 4, s));
-    HIP_TRY(HD::launch_speculate_batch(d_S, (const uint32_t*)c->b_U.p, d_F, d_wg_file, d_wg_first, n_wg, (unsigned)total_slots,
-                                       (unsigned long long*)c->b_prop.p, d_exit, s));
-    lap("speculate");
-    std::vector<unsigned> active(nf), prev_moved(nf, 0u);
-    std::vector<char> converged(nf, 0), dead(nf, 0);
-    for (unsigned k = 0; k < nf; ++k) { active[k] = usable[k] ? 1u : 0u; dead[k] = !usable[k]; }
-    RefineBudget budget;
-    for (int pass = 0; pass <= RefineBudget::MAX_LAUNCHES; ++pass) {
-        bool any = false;
-        for (unsigned k = 0; k < nf; ++k) any = any || active[k];
-        if (!any) break;
-        HIP_TRY(hipMemcpyAsync(d_active, active.data(), (size_t)nf * 4, hipMemcpyHostToDevice, s));
-        HIP_TRY(HD::launch_sync_batch(d_S, (const uint32_t*)c->b_U.p, d_F, d_wg_file, d_wg_first, n_wg, d_active, d_exit, d_last, d_nblocks,
-                                      pass == 0 ? RefineBudget::FIRST_STEPS : RefineBudget::STEPS, s));
-        HIP_TRY(hipMemcpyAsync(F.data(), d_F, sizeof(HD::BatchFile) * nf, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
-        for (unsigned k = 0; k < nf; ++k) {
-            if (!active[k]) continue;
-            const unsigned moved = F[k].changed[0], pending = F[k].changed[1] + F[k].changed[2];
-            if (F[k].n_sub == 0) { active[k] = 0; dead[k] = 1; continue; }
-            if (pending == 0) { active[k] = 0; converged[k] = 1; continue; }
-            // many proposals moved at the first look (periodic data never falls into step), or the refinement launches have
-            // stopped paying for this file (RefineBudget): per-file path
-            if (pass == 0 ? F[k].changed[3] > F[k].n_sub / 2 + 16 : !budget.go_on(pass + 1, prev_moved[k], moved)) { active[k] = 0; dead[k] = 1; }
-            prev_moved[k] = moved;
-        }
-        // reset the per-pass counters of the files that go on
-        for (unsigned k = 0; k < nf; ++k)
-            if (active[k]) HIP_TRY(hipMemsetAsync(&d_F[k].changed[0], 0, 4 * sizeof(unsigned), s));
-    }
-    lap("confirm + refine");
-    // 3. block index of every lane, coefficients, DC predictors -- for the files that converged
-    for (unsigned k = 0; k < nf; ++k) active[k] = converged[k] ? 1u : 0u;
-    HIP_TRY(hipMemcpyAsync(d_active, active.data(), (size_t)nf * 4, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(c->b_cnt.p, d_nblocks, total_slots * 4, hipMemcpyDeviceToDevice, s));
-    unsigned long long* d_bb = (unsigned long long*)c->b_prop.p;          // (the proposals are dead: same buffer)
-    HIP_TRY(E::launch_scan_u32((const uint32_t*)c->b_cnt.p, d_bb, total_slots, (unsigned long long*)c->e_tmp.p, s));
-    HIP_TRY(hipMemsetAsync(c->b_coef.p, 0, (size_t)nf * cpf * sizeof(int16_t), s));
-    HIP_TRY(HD::launch_emit_batch(d_S, (const uint32_t*)c->b_U.p, d_F, d_wg_file, d_wg_first, n_wg, d_active, d_exit, d_bb, (int16_t*)c->b_coef.p, s));
-    HIP_TRY(HD::launch_dc_prefix_batch((int16_t*)c->b_coef.p, d_F, d_active, nf, s));
-    HIP_TRY(hipMemcpyAsync(F.data(), d_F, sizeof(HD::BatchFile) * nf, hipMemcpyDeviceToHost, s));
-    lap("emit + DC");
-    // 4. dequantisation + IDCT + colour conversion of the whole slice in one launch (a file that failed decodes to garbage nobody reads)
+    if (int rc = huffdec_streams(c, streams, setups, setup_usable, stream_geom(info), (int16_t*)c->b_coef.p, (size_t)nf * cpf, ok, lap)) return rc;
+    // dequantisation + inverse transform + colour conversion of the whole slice in one launch (a file that failed decodes to garbage nobody reads)
     if (int rc = c->b_planes[plane_buf].reserve(3 * pstride * nf)) return rc;
     uint8_t* pl = (uint8_t*)c->b_planes[plane_buf].p;
     const uint8_t tq[3] = { (uint8_t)info.Tq[0], (uint8_t)info.Tq[1], (uint8_t)info.Tq[2] };
@@ -1630,10 +1760,6 @@ int decode_slice_fast(jpezy_ctx* c, const std::vector<FastFile>& files, const jp
     }
     HIP_TRY(hipStreamSynchronize(s));
     lap("IDCT");
-    for (unsigned k = 0; k < nf; ++k) {
-        const unsigned long long data_bits = ((unsigned long long)F[k].n_bytes - F[k].removed) * 8;
-        ok[k] = converged[k] && !F[k].error && F[k].last_bit <= data_bits;
-    }
     (void)plane;
     return JPEZY_OK;      // the planes of the files with ok[k] wait in b_planes[plane_buf]: [r | g | b][nf][pstride]
 }

@@ -37,7 +37,8 @@ size_t chunk_bytes();
 
 // ---- batch form (round 3): many files per launch.  Every kernel above exists once more with the file as an index: a file owns a
 // range of 64-byte chunks of the concatenated scans (unstuffing) and a range of subsequence slots (decoding); a workgroup never
-// straddles two files (wg_file / wg_first say whose subsequences it takes), every file brings its own tables. ----
+// straddles two files (wg_file / wg_first say whose subsequences it takes), every file names its tables (setup).  A "file" is any
+// independent stream that starts in the known state: a file's scan, or one restart interval of a scan. ----
 struct BatchFile {
     unsigned chunk0, n_chunks;          // 64-byte chunks of the concatenated scan buffer: bytes [chunk0 * 64, chunk0 * 64 + n_bytes)
     unsigned n_bytes;
@@ -50,7 +51,8 @@ struct BatchFile {
     unsigned cstart[3], ccount[3];      // component c owns blocks [cstart, cstart + ccount) of every MCU
     unsigned changed[4];                // per launch: lanes that moved / lanes left pending / workgroup-last lanes among the moved /
                                         // lanes that moved at the launch's first step (device)
-    unsigned error, pad;
+    unsigned error;
+    unsigned setup;                     // which of the call's tables the file / stream decodes with
     unsigned long long last_bit;
 };
 
@@ -62,8 +64,12 @@ hipError_t launch_speculate_batch(const Setup* setups, const uint32_t* U, const 
 // active[f] (host-written between the phases): refinement passes -- the file still has lanes to settle; emit / DC pass -- the file converged
 hipError_t launch_sync_batch(const Setup* setups, const uint32_t* U, BatchFile* F, const unsigned* wg_file, const unsigned* wg_first, unsigned n_wg,
                              const unsigned* active, uint32_t* exit_state, uint32_t* last_entry, unsigned* nblocks, int max_inner, hipStream_t s);
+hipError_t launch_reset_changed_batch(BatchFile* F, const unsigned* active, unsigned n_files, hipStream_t s);   // changed[] = 0 for the active files
 hipError_t launch_emit_batch(const Setup* setups, const uint32_t* U, BatchFile* F, const unsigned* wg_file, const unsigned* wg_first, unsigned n_wg,
                              const unsigned* active, const uint32_t* exit_state, const unsigned long long* blocks_before, int16_t* coeffs, hipStream_t s);
+// short streams that share ONE set of tables (setups[0]) and start in the known state: a lane walks a whole stream (symbols, coefficients, DC
+// predictors); needs the unstuffed streams (launch_unstuff_*_batch) and zeroed coefficients; sets F[].error / last_bit like the emit launch
+hipError_t launch_stream_per_lane(const Setup* setups, const uint32_t* U, BatchFile* F, unsigned n_files, int16_t* coeffs, hipStream_t s);
 hipError_t launch_dc_prefix_batch(int16_t* coeffs, const BatchFile* F, const unsigned* active, unsigned n_files, hipStream_t s);
 
 // S: the file from the first byte of the scan on (n_max bytes).  The count launch also finds where the entropy-coded segment ends

@@ -69,6 +69,49 @@ struct Cursor {
         const unsigned sh = pos & 31u;
         return (w0 << sh) | ((w1 >> 1) >> (31u - sh));
     }
+    __device__ __forceinline__ uint32_t prefetch() const { return w[pad_index(nxt)]; }     // issued at the top of a step, used at its bottom
+    __device__ __forceinline__ void advance(unsigned np, uint32_t ahead)               // np - pos <= 32: at most one word further
+    {
+        const bool adv = ((np ^ pos) >> 5) != 0u;
+        pos = np;
+        w0 = adv ? w1 : w0;
+        w1 = adv ? w2 : w1;
+        w2 = adv ? ahead : w2;
+        nxt += adv ? 1u : 0u;
+    }
+};
+
+// The same cursor over a stream in GLOBAL memory (the lane-per-stream kernel of short restart intervals: 256 streams per workgroup do not
+// fit LDS).  Four words in registers; the next one is requested when a word boundary is crossed and used at the boundary after it -- some
+// five symbols later --, so the load's latency is not in the symbol loop.  U holds bytes; words beyond the stream's buffer read as zero.
+struct GlobalCursor {
+    const uint32_t* g;
+    unsigned n_words;
+    unsigned pos;
+    uint32_t w0, w1, w2, w3;
+    unsigned nxt;
+    __device__ __forceinline__ uint32_t word(unsigned i) const { return i < n_words ? __builtin_bswap32(g[i]) : 0u; }
+    __device__ __forceinline__ void init(const uint32_t* U, unsigned u_words)
+    {
+        g = U; n_words = u_words; pos = 0;
+        w0 = word(0); w1 = word(1); w2 = word(2); w3 = word(3);
+        nxt = 4;
+    }
+    __device__ __forceinline__ uint32_t peek32() const
+    {
+        const unsigned sh = pos & 31u;
+        return (w0 << sh) | ((w1 >> 1) >> (31u - sh));
+    }
+    __device__ __forceinline__ uint32_t prefetch() const { return 0u; }
+    __device__ __forceinline__ void advance(unsigned np, uint32_t)
+    {
+        if (((np ^ pos) >> 5) != 0u) {
+            w0 = w1; w1 = w2; w2 = w3;
+            w3 = word(nxt);
+            ++nxt;
+        }
+        pos = np;
+    }
 };
 
 __device__ __forceinline__ void load_window(uint32_t* win, const uint32_t* U, unsigned first_sub, size_t u_words)
@@ -104,11 +147,11 @@ struct Walk {
 // synchronisation pass -- which may well be decoding from a wrong guess, i.e. garbage -- abandons the block, moves one bit on and
 // carries on, so that it can still fall into step further down.
 // EMIT: coefficients of blocks gidx + nblocks < total go to out (DC: the difference, made absolute by the DC pass).
-template <bool EMIT>
-__device__ __forceinline__ bool decode_step(const uint16_t* tabs, unsigned bpm, unsigned tdmask, Cursor& c, Walk& s,
+template <bool EMIT, class CursorT>
+__device__ __forceinline__ bool decode_step(const uint16_t* tabs, unsigned bpm, unsigned tdmask, CursorT& c, Walk& s,
                                             unsigned long long gidx, unsigned total, int16_t* out)
 {
-    const uint32_t ahead = c.w[pad_index(c.nxt)];                      // used only when this symbol crosses a word boundary
+    const uint32_t ahead = c.prefetch();                               // used only when this symbol crosses a word boundary
     const uint32_t bits = c.peek32();
     const unsigned tb = s.tdoff + (s.k ? 3u * TABLE_U16 : 0u);         // dc[td] or ac[td]
     const unsigned e1 = tabs[tb + (bits >> (32 - L1_BITS))];
@@ -132,13 +175,7 @@ __device__ __forceinline__ bool decode_step(const uint16_t* tabs, unsigned bpm, 
     const unsigned b1 = s.b + 1u == bpm ? 0u : s.b + 1u;
     s.b = endb ? b1 : s.b;
     s.tdoff = ((tdmask >> (2u * s.b)) & 3u) * TABLE_U16;
-    const unsigned np = c.pos + skip;
-    const bool adv = ((np ^ c.pos) >> 5) != 0u;                       // skip <= 32: at most one word further
-    c.pos = np;
-    c.w0 = adv ? c.w1 : c.w0;
-    c.w1 = adv ? c.w2 : c.w1;
-    c.w2 = adv ? ahead : c.w2;
-    c.nxt += adv ? 1u : 0u;
+    c.advance(c.pos + skip, ahead);
     return true;
 }
 
@@ -429,7 +466,7 @@ __global__ __launch_bounds__(WGS) void spec_batch_kernel(const Setup* setups, co
     __shared__ uint32_t win[WINDOW_WORDS];
     const unsigned f = wg_file[blockIdx.x], i0 = wg_first[blockIdx.x], n_sub = F[f].n_sub;
     if (i0 >= n_sub) return;                                            // (workgroup-uniform: the slots were sized before unstuffing)
-    load_setup(S, setups + f);
+    load_setup(S, setups + F[f].setup);
     load_window(win, U + F[f].u_off / 4, i0, F[f].u_words);
     __syncthreads();
     const unsigned i = i0 + threadIdx.x;
@@ -470,7 +507,7 @@ __global__ __launch_bounds__(WGS) void sync_batch_kernel(const Setup* setups, co
     if (t == 0) sh_exit[0] = i0 ? exit_state[i0 - 1] : pack_state(0, 0, 0);
     __syncthreads();
     if (!__syncthreads_or(live && sh_exit[t] != my_last)) return;      // a quiet workgroup
-    load_setup(S, setups + f);
+    load_setup(S, setups + F[f].setup);
     load_window(win, U + F[f].u_off / 4, i0, F[f].u_words);
     __syncthreads();
     const uint16_t* tabs = reinterpret_cast<const uint16_t*>(&S);
@@ -523,19 +560,19 @@ __global__ __launch_bounds__(WGS) void emit_batch_kernel(const Setup* setups, co
     __shared__ uint32_t win[WINDOW_WORDS];
     const unsigned f = wg_file[blockIdx.x], i0 = wg_first[blockIdx.x], n_sub = F[f].n_sub;
     if (i0 >= n_sub || !active[f]) return;                              // active: here "the file converged" (set by the host)
-    load_setup(S, setups + f);
+    load_setup(S, setups + F[f].setup);
     load_window(win, U + F[f].u_off / 4, i0, F[f].u_words);
     __syncthreads();
     const unsigned i = i0 + threadIdx.x;
     if (i >= n_sub) return;
     const uint32_t* exit_state = exit_state_all + F[f].sub0;
     const unsigned long long g0 = blocks_before_all[F[f].sub0 + i] - blocks_before_all[F[f].sub0];
-    if (g0 >= S.total_blocks) return;
+    if (g0 >= F[f].total_blocks) return;              // (the stream's own count: restart intervals share a Setup)
     const uint32_t entry = i ? exit_state[i - 1] : pack_state(0, 0, 0);
     if (entry & 0x40000000u) { F[f].error = 1u; return; }
     int16_t* out = coeffs + F[f].coeff_off;
     const uint16_t* tabs = reinterpret_cast<const uint16_t*>(&S);
-    const unsigned bpm = (unsigned)S.bpm, tdmask = S.tdmask, total = S.total_blocks;
+    const unsigned bpm = (unsigned)S.bpm, tdmask = S.tdmask, total = F[f].total_blocks;
     Cursor c;
     c.init(win, threadIdx.x * SUBSEQ_BITS + ((entry >> 16) & 0x3FFFu));
     Walk wk;
@@ -601,7 +638,48 @@ __global__ __launch_bounds__(256) void dc_prefix_batch_kernel(int16_t* coeffs, c
     }
 }
 
+// Lane-per-stream form for SHORT streams (restart intervals of a few MCUs: hardware encoders, libjpeg -restart N B): a stream that starts in
+// the known state needs no speculation when one lane walks all of it -- symbols, coefficients and DC predictors in one pass, straight from
+// the unstuffed stream in global memory, the tables in LDS.  256 streams per workgroup; worth it while a stream is a few KB (a lane decodes
+// ~3 MB/s), beyond that the subsequence form above wins.  F[f].error / last_bit as in the emit kernel.
+__global__ __launch_bounds__(WGS) void stream_per_lane_kernel(const Setup* setups, const uint32_t* U, BatchFile* F, unsigned n_files, int16_t* coeffs)
+{
+    __shared__ Setup S;
+    load_setup(S, setups);                                               // (one set of tables for the whole launch: the intervals of one scan)
+    __syncthreads();
+    const unsigned f = blockIdx.x * WGS + threadIdx.x;
+    if (f >= n_files) return;
+    const uint16_t* tabs = reinterpret_cast<const uint16_t*>(&S);
+    const unsigned bpm_period = (unsigned)S.bpm, tdmask = S.tdmask, total = F[f].total_blocks;
+    int16_t* out = coeffs + F[f].coeff_off;
+    GlobalCursor c;
+    c.init(U + F[f].u_off / 4, F[f].u_words);
+    Walk wk;
+    wk.init(0, 0, tdmask);
+    while (wk.nblocks < total) {
+        if (!decode_step<true>(tabs, bpm_period, tdmask, c, wk, 0ull, total, out)) { F[f].error = 1u; return; }
+        if (c.pos > F[f].u_words * 32u) { F[f].error = 1u; return; }     // (ran off the buffer on zeros: cannot be a complete stream)
+    }
+    F[f].last_bit = c.pos;
+    // DC differences -> values (pre_DC, ref :611-614), the predictors at zero at the start of the stream
+    const unsigned bpm = F[f].bpm, c1 = F[f].cstart[1], c2 = F[f].cstart[2], ncomp = F[f].ncomp;
+    int pred[3] = { 0, 0, 0 };
+    for (unsigned blk = 0, b = 0; blk < total; ++blk) {
+        const unsigned comp = (ncomp > 2 && b >= c2) ? 2u : (ncomp > 1 && b >= c1) ? 1u : 0u;
+        const int v = pred[comp] + out[(size_t)blk * 64];
+        pred[comp] = v;
+        out[(size_t)blk * 64] = (int16_t)v;
+        b = b + 1 == bpm ? 0 : b + 1;
+    }
+}
+
 // ---- launchers ----
+hipError_t launch_stream_per_lane(const Setup* setups, const uint32_t* U, BatchFile* F, unsigned n_files, int16_t* coeffs, hipStream_t s)
+{
+    if (!n_files) return hipSuccess;
+    hipLaunchKernelGGL(stream_per_lane_kernel, dim3((n_files + WGS - 1) / WGS), dim3(WGS), 0, s, setups, U, F, n_files, coeffs);
+    return hipGetLastError();
+}
 unsigned subseq_bits() { return SUBSEQ_BITS; }
 size_t chunk_bytes() { return CHUNK; }
 
@@ -693,6 +771,17 @@ hipError_t launch_speculate_batch(const Setup* setups, const uint32_t* U, const 
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(spec_batch_kernel, dim3(n_wg), dim3(WGS), 0, s, setups, U, F, wg_file, wg_first, proposal, spec_overflow());
     hipLaunchKernelGGL(adopt_proposals_kernel, dim3((n_slots + 255) / 256), dim3(256), 0, s, proposal, n_slots, exit_state);
+    return hipGetLastError();
+}
+__global__ void reset_changed_batch_kernel(BatchFile* F, const unsigned* active, unsigned n_files)
+{
+    const unsigned f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f < n_files && active[f]) F[f].changed[0] = F[f].changed[1] = F[f].changed[2] = F[f].changed[3] = 0;
+}
+hipError_t launch_reset_changed_batch(BatchFile* F, const unsigned* active, unsigned n_files, hipStream_t s)
+{
+    if (!n_files) return hipSuccess;
+    hipLaunchKernelGGL(reset_changed_batch_kernel, dim3((n_files + 255) / 256), dim3(256), 0, s, F, active, n_files);
     return hipGetLastError();
 }
 hipError_t launch_sync_batch(const Setup* setups, const uint32_t* U, BatchFile* F, const unsigned* wg_file, const unsigned* wg_first, unsigned n_wg,

@@ -81,7 +81,7 @@ def test_libjpeg_files(J, ctx):
                 Image.fromarray(pic).save(buf, "JPEG", **kw)
             except TypeError:
                 continue
-            info, _ = _same(J, ctx, buf.getvalue(), expect_gpu="restart_marker_blocks" not in kw)
+            info, _ = _same(J, ctx, buf.getvalue(), expect_gpu=True)      # (restart intervals too: test_restart_intervals_on_the_gpu)
             assert (info.restart_interval != 0) == ("restart_marker_blocks" in kw)
         buf = io.BytesIO()
         Image.fromarray(pic[..., 1]).save(buf, "JPEG", quality=70)
@@ -365,4 +365,63 @@ def test_decode_jpeg_batch_other_layouts(J, ctx, oracle):
             n = info.width * info.height
             for a, e in zip((rr, gg, bb), want[-3:]):
                 assert np.array_equal(a, np.asarray(e).reshape(-1)[:n]), (i, gray)
+
+
+
+
+def test_restart_intervals_on_the_gpu(J, ctx, oracle):
+    """DRI / RSTn (ref decoder/jpezy_decoder.hpp:152-163): every restart interval is an entry point -- byte aligned, MCU aligned,
+    predictors at zero -- so a REGULAR scan (one RSTn behind every interval but the last) is decoded on the device as that many
+    independent streams; anything else is the host decoder's, whose reading of irregular files is the reference's.  libjpeg files
+    with intervals of one MCU row, of a few MCUs and of several rows, three layouts: the GPU decoder ran and its coefficients are the
+    host decoder's; the end-to-end decode equals the oracle's.  Then irregular copies -- a marker removed, a marker doubled, an
+    interval cut short, a stray other marker inside -- same verdict and same coefficients as the host decoder (which decodes them)."""
+    from PIL import Image, ImageFile
+    ImageFile.MAXBLOCK = 1 << 22
+    rng = np.random.default_rng(31)
+    H, W = 232, 328
+    img = np.clip(rng.normal(128, 55, (H, W, 3)), 0, 255).astype(np.uint8)
+    regular = []
+    for kw in (dict(subsampling=2, quality=80, restart_marker_rows=1), dict(subsampling=0, quality=60, restart_marker_blocks=5),
+               dict(subsampling=1, quality=90, restart_marker_rows=3, optimize=True), dict(subsampling=2, quality=35, restart_marker_blocks=1)):
+        buf = io.BytesIO()
+        Image.fromarray(img).save(buf, "JPEG", **kw)
+        regular.append(buf.getvalue())
+    buf = io.BytesIO()
+    Image.fromarray(img[..., 0]).save(buf, "JPEG", quality=75, restart_marker_rows=2)
+    regular.append(buf.getvalue())
+    for data in regular:
+        info, _ = _same(J, ctx, data, expect_gpu=True)
+        assert info.restart_interval != 0
+        ginfo, rr, gg, bb = ctx.decode_jpeg(data)
+        want = oracle.decode_jpeg(data, False)
+        for a, e in zip((rr, gg, bb), want[-3:]):
+            assert np.array_equal(a, np.asarray(e).reshape(-1)[: W * H])
+
+    def rst_positions(d):
+        return [i for i in range(len(d) - 1) if d[i] == 0xFF and 0xD0 <= d[i + 1] <= 0xD7]
+    base = regular[0]
+    pos = rst_positions(base)
+    assert len(pos) >= 4
+    irregular = [
+        base[: pos[2]] + base[pos[2] + 2:],                                   # a marker removed: the host decoder reads on through the next interval
+        base[: pos[1]] + base[pos[1]: pos[1] + 2] + base[pos[1]:],           # a marker doubled
+        base[: pos[3] - 9] + base[pos[3]:],                                   # an interval cut short
+        base[: pos[2] - 5] + b"\xff\xc4" + base[pos[2] - 5:],               # another marker inside an interval
+        base[: pos[1]] + b"\xff" + base[pos[1]:],                            # a fill byte in front of a marker
+    ]
+    for data in irregular:
+        try:
+            _, want = J.read_jpeg(data)
+        except J.JpezyError:
+            want = None
+        try:
+            _, got = ctx.read_jpeg_gpu(data)
+            got = got.cpu().numpy()
+        except J.JpezyError:
+            got = None
+        assert (want is None) == (got is None)
+        if want is not None:
+            assert np.array_equal(got, want)
+            assert ctx.last_huffdec_passes() == 0         # the host decoder's file
 

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Differential fuzz of the GPU Huffman decoder against the host decoder (and of the GPU entropy coder against the host writer): random sizes, contents, qualities, sampling
-factors, optimised tables (libjpeg via PIL) and jpezy's own encoder; every scan goes to the GPU decoder (min_bytes 0)."""
+factors, optimised tables, restart intervals (libjpeg via PIL) and jpezy's own encoder; every scan goes to the GPU decoder (min_bytes 0)."""
 import io
 import os
 import sys
@@ -53,6 +53,11 @@ def main():
         img = content(rng, H, W, kind)
         files = []
         kw = dict(quality=int(rng.integers(5, 100)), subsampling=int(rng.integers(0, 3)), optimize=bool(rng.integers(0, 2)))
+        if rng.integers(0, 4) == 0:                                        # restart intervals: rows of MCUs or a few MCUs
+            if rng.integers(0, 2):
+                kw["restart_marker_rows"] = int(rng.integers(1, 4))
+            else:
+                kw["restart_marker_blocks"] = int(rng.integers(1, 40))
         buf = io.BytesIO(); Image.fromarray(img).save(buf, "JPEG", **kw); files.append(("pil", kw, buf.getvalue()))
         if rng.integers(0, 3) == 0:
             buf = io.BytesIO(); Image.fromarray(img[..., 0]).save(buf, "JPEG", quality=kw["quality"]); files.append(("pil-gray", kw, buf.getvalue()))

@@ -57,6 +57,24 @@ def main():
         te = (time.perf_counter() - t) / 3
         print(f"{W}x{H} libjpeg {name} ({len(data) / 1e6:.1f} MB): jpezy_decode_jpeg {te * 1e3:.2f} ms ({ctx.last_huffdec_passes()} passes)")
 
+    # restart intervals (DRI): every interval an independent stream on the device
+    for name, kw, im in (("4:2:0, an interval per MCU row", dict(subsampling=2, quality=90, restart_marker_rows=1), img),
+                         ("4:4:4, an interval per 8 MCUs", dict(subsampling=0, quality=90, restart_marker_blocks=8), img)):
+        buf = io.BytesIO()
+        Image.fromarray(im).save(buf, "JPEG", **kw)
+        data = buf.getvalue()
+        info, want = J.read_jpeg(data)
+        t = time.perf_counter(); J.read_jpeg(data); th = time.perf_counter() - t
+        ctx.read_jpeg_gpu(data); torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(5):
+            ginfo, got = ctx.read_jpeg_gpu(data)
+        torch.cuda.synchronize()
+        tg = (time.perf_counter() - t) / 5
+        ok = np.array_equal(got.cpu().numpy(), want)
+        print(f"{W}x{H} libjpeg {name} ({len(data) / 1e6:.1f} MB, restart interval {info.restart_interval}): GPU Huffman decode {tg * 1e3:.2f} ms "
+              f"({'GPU' if ctx.last_huffdec_passes() else 'HOST'}); host {th * 1e3:.1f} ms; identical: {ok}")
+
     # a batch of different 1080p files: one call per file vs jpezy_decode_jpeg_batch (up to 8 files in flight)
     W, H = 1920, 1080
     files = []

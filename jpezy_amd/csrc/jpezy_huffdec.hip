@@ -1,6 +1,8 @@
-// jpezy_huffdec.hip -- the decoder's serial head on the GPU (decode side): Huffman decoding of one
-// baseline scan without restart markers into zig-zagged int16 coefficients, same results as jpezy_host::read_jpeg / the
-// reference's decoder::decode_huffman (ref decoder/jpezy_decoder.hpp:583-642).
+// jpezy_huffdec.hip -- the decoder's serial head on the GPU (decode side): Huffman decoding of baseline
+// scans into zig-zagged int16 coefficients, same results as jpezy_host::read_jpeg / the reference's
+// decoder::decode_huffman (ref decoder/jpezy_decoder.hpp:583-642).  Three forms: one scan (the kernels right below), many
+// independent streams per launch (batch form: the scans of many files, or the restart intervals of one scan), and a lane per
+// stream for short restart intervals.
 //
 // A Huffman stream has no entry points, but it is self-synchronising: a decoder started at a wrong place falls into
 // step with the true one after a few symbols.  The scan (after removing the 0xFF00 stuffing) is cut into subsequences
@@ -13,8 +15,10 @@
 // Then: prefix sum of the blocks every lane completes -> global block index of every lane; one more pass that writes
 // the coefficients (DC still as differences); per component a prefix sum over the DC differences (pre_DC, ref :611).
 //
-// Anything irregular -- an invalid code, a run past the end of a block, a scan that ends early -- makes the caller
-// (jpezy_capi.hip) fall back to the host decoder, whose verdict is authoritative; so do restart intervals.
+// Anything irregular -- an invalid code, a run past the end of a block, a scan that ends early, restart markers that are
+// not exactly where they belong -- makes the caller (jpezy_capi.hip) fall back to the host decoder, whose verdict is
+// authoritative.  Round 3: two-level lookup tables and a branch-free decode step (jpezy_huffdec.h, decode_step below), one
+// confirmation + refinement launch with a fixed-point test, the end of the entropy-coded segment found by the stuffing count.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <cstdlib>

@@ -1084,60 +1084,6 @@ JPEZY_CATCH
 // ---- GPU Huffman decoding (decode side) ----
 namespace {
 
-// The device decoder's two-level table of one Huffman table (jpezy_huffdec.h).  dc: the symbol is the number of value bits.
-// false: the counts do not describe a prefix code (more codes of some length than the code space has left), or the long codes
-// spread over more 10-bit prefixes than the table has room for -- such a table is left to the host decoder, whose canonical loop
-// defines what it means.
-bool build_dev_table(jpezy_dev::huffdec::Table& t, const uint8_t bits[16], const uint8_t* vals, int n, bool dc)
-{
-    namespace HD = jpezy_dev::huffdec;
-    std::memset(&t, 0, sizeof t);
-    (void)n;
-    unsigned code = 0;
-    int p = 0, subs = 0;
-    long last_prefix = -1;
-    for (int l = 1; l <= 16; ++l) {
-        for (int c = 0; c < bits[l - 1]; ++c, ++p, ++code) {
-            if (code >= (1u << l)) return false;                     // more codes of this length than the code space has left
-            const unsigned sym = vals[p];
-            unsigned e = 0;
-            if (dc) {
-                if (sym <= 16) e = HD::E_VALID | (sym << 4) | (unsigned)(l - 1);           // a category above 16 is no symbol (entry 0)
-            } else {
-                e = HD::E_VALID | (sym == 0 ? HD::E_EOB : 0u) | ((sym >> 4) << 9) | ((sym & 15u) << 4) | (unsigned)(l - 1);
-            }
-            if (l <= HD::L1_BITS) {
-                const unsigned lo = code << (HD::L1_BITS - l);
-                for (unsigned f = 0; f < (1u << (HD::L1_BITS - l)); ++f) t.l1[lo + f] = (uint16_t)e;
-            } else {
-                const long prefix = (long)(code >> (l - HD::L1_BITS));
-                if (prefix != last_prefix) {                         // canonical codes ascend: so do the prefixes
-                    if (subs == HD::MAX_SUB) return false;
-                    t.l1[prefix] = (uint16_t)(HD::E_VALID | HD::E_LONG | (unsigned)(subs << HD::L2_BITS));
-                    last_prefix = prefix;
-                    ++subs;
-                }
-                const int rest = HD::L1_BITS + HD::L2_BITS - l;      // free bits behind the code inside the 16-bit index
-                const unsigned lo = ((code << rest) & ((1u << HD::L2_BITS) - 1u)) + (unsigned)((subs - 1) << HD::L2_BITS);
-                for (unsigned f = 0; f < (1u << rest); ++f) t.l2[lo + f] = (uint16_t)e;
-            }
-        }
-        if (code > (1u << l)) return false;
-        code <<= 1;
-    }
-    return true;
-}
-
-// the table selectors of the blocks of one period of the MCU's table sequence, two bits each (Setup::tdmask); false: period too long
-bool pack_td_sequence(const int* seq, int period, unsigned* mask)
-{
-    if (period > jpezy_dev::huffdec::MAX_PERIOD) return false;
-    unsigned m = 0;
-    for (int i = 0; i < period; ++i) m |= (unsigned)(seq[i] & 3) << (2 * i);
-    *mask = m;
-    return true;
-}
-
 // host decode + upload: the authoritative path for everything the GPU decoder does not take or is unsure about
 int read_jpeg_host_to_device(jpezy_ctx* c, const uint8_t* data, size_t len, jpezy_frame_info* info, int16_t* d_coeffs, size_t total)
 {
@@ -1385,7 +1331,7 @@ bool build_dev_setup(jpezy_dev::huffdec::Setup& S, const jpezy_host::ScanSetup& 
         if (same) { period = pd; break; }
     }
     S.bpm = period;
-    return pack_td_sequence(seq, period, &S.tdmask) && usable;
+    return jpezy_dev::huffdec::pack_td_sequence(seq, period, &S.tdmask) && usable;
 }
 
 StreamGeom stream_geom(const jpezy_frame_info& info)
@@ -1526,7 +1472,7 @@ try {
             if (ok) { period = pd; break; }
         }
         S.bpm = period;
-        if (!pack_td_sequence(seq, period, &S.tdmask)) return read_jpeg_host_to_device(c, data, len, info, d_coeffs, total);
+        if (!jpezy_dev::huffdec::pack_td_sequence(seq, period, &S.tdmask)) return read_jpeg_host_to_device(c, data, len, info, d_coeffs, total);
     }
     HIP_TRY(hipMemcpyAsync(c->h_setup.p, &S, sizeof S, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(c->h_scan.p, scan, n, hipMemcpyHostToDevice, s));

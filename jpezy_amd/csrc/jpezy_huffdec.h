@@ -4,33 +4,10 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include "jpezy_huffdec_core.h"     // tables, entry format, the decode step (shared with the CPU harness tests/fuzz/huffdec_core_fuzz.cpp)
+
 namespace jpezy_dev {
 namespace huffdec {
-
-// Decoding tables (round 3): two 16-bit lookups and no loop, no compare chain.  l1 is indexed by the next L1_BITS bits of the stream; a
-// code of at most L1_BITS bits is decoded by that entry alone, a longer one has E_LONG set and the entry's low 14 bits say where, in l2,
-// the 64 entries for the six bits after its 10-bit prefix start (canonical codes: the long codes sit at the top of the code space and share
-// a handful of prefixes -- five for the Annex K tables; a table that needs more than MAX_SUB of them is left to the host decoder).
-// An entry says everything the decoder's state machine needs: E_VALID | E_EOB (AC symbol 0x00) | run << 9 | s << 4 | (length - 1), with s
-// the number of value bits that follow the code (AC: low nibble of the symbol; DC: the symbol, a category above 16 has no entry).  An unused
-// slot is 0: not a code.
-constexpr int L1_BITS = 10, L2_BITS = 6, MAX_SUB = 16;
-constexpr unsigned E_VALID = 0x8000u, E_LONG = 0x4000u, E_EOB = 0x2000u;
-struct alignas(16) Table {
-    uint16_t l1[1 << L1_BITS];
-    uint16_t l2[MAX_SUB << L2_BITS];
-};
-constexpr unsigned TABLE_U16 = sizeof(Table) / 2;
-
-struct Setup {
-    Table dc[3], ac[3];       // indexed by the scan component's table selector Td (the reference uses Td for both)
-    int bpm;                  // period of the table sequence over the blocks of an MCU (divides the blocks per MCU; at most MAX_PERIOD)
-    unsigned tdmask;          // Td of block b of a period in bits [2 b + 1 : 2 b]
-    unsigned total_blocks;
-    unsigned pad;
-};
-constexpr int MAX_PERIOD = 16;
-static_assert(sizeof(Table) == 4096 && sizeof(Setup) % 16 == 0, "table layout the kernels index by hand");
 
 unsigned subseq_bits();
 size_t chunk_bytes();

@@ -132,57 +132,6 @@ __device__ __forceinline__ void load_setup(Setup& S, const Setup* g)
 }
 static_assert(sizeof(Setup) % 16 == 0, "Setup is copied in 16-byte pieces");
 
-__device__ __forceinline__ int extend(int v, int cat) { return (v & (1 << (cat - 1))) ? v : v - ((1 << cat) - 1); }
-
-// The decoder's state besides the cursor: block inside the table period, zig-zag index (0: a DC symbol comes next), and the
-// offset of the block's table pair inside the Setup (in uint16 units).
-struct Walk {
-    unsigned b, k, tdoff, nblocks;
-    __device__ __forceinline__ void init(unsigned b_, unsigned k_, unsigned tdmask)
-    {
-        b = b_; k = k_; nblocks = 0;
-        tdoff = ((tdmask >> (2u * b)) & 3u) * TABLE_U16;
-    }
-};
-
-// One symbol.  DC and AC symbols run through the same instructions (the lanes of a wave are at unrelated places of their blocks): a DC
-// symbol is a (run 0, size = category) symbol at k = 0 from the DC table.  Straight-line code: every decision is a select.
-// An invalid code, or a run past the end of the block: EMIT returns false (the true decode hit it: the stream is bad); a
-// synchronisation pass -- which may well be decoding from a wrong guess, i.e. garbage -- abandons the block, moves one bit on and
-// carries on, so that it can still fall into step further down.
-// EMIT: coefficients of blocks gidx + nblocks < total go to out (DC: the difference, made absolute by the DC pass).
-template <bool EMIT, class CursorT>
-__device__ __forceinline__ bool decode_step(const uint16_t* tabs, unsigned bpm, unsigned tdmask, CursorT& c, Walk& s,
-                                            unsigned long long gidx, unsigned total, int16_t* out)
-{
-    const uint32_t ahead = c.prefetch();                               // used only when this symbol crosses a word boundary
-    const uint32_t bits = c.peek32();
-    const unsigned tb = s.tdoff + (s.k ? 3u * TABLE_U16 : 0u);         // dc[td] or ac[td]
-    const unsigned e1 = tabs[tb + (bits >> (32 - L1_BITS))];
-    const bool lng = (e1 & E_LONG) != 0;
-    const unsigned i2 = lng ? (e1 & 0x3FFFu) + ((bits >> (32 - L1_BITS - L2_BITS)) & ((1u << L2_BITS) - 1u)) : 0u;
-    const unsigned e2 = tabs[tb + (1u << L1_BITS) + i2];
-    const unsigned e = lng ? e2 : e1;
-    const unsigned len = (e & 15u) + 1u, sz = (e >> 4) & 31u, run = (e >> 9) & 15u;
-    const unsigned kk = s.k + run + 1u;                               // zig-zag index after this symbol
-    const bool bad = !(e & E_VALID) || kk > 64u;
-    if (EMIT) {
-        if (bad) return false;
-        if (sz && gidx + s.nblocks < total)
-            out[(gidx + s.nblocks) * 64 + kk - 1u] = (int16_t)extend((int)((bits << len) >> (32u - sz)), (int)sz);
-    }
-    const unsigned skip = bad ? 1u : len + sz;
-    const unsigned kn = (bad || (e & E_EOB)) ? 64u : kk;
-    const bool endb = kn >= 64u;
-    s.k = endb ? 0u : kn;
-    s.nblocks += endb ? 1u : 0u;
-    const unsigned b1 = s.b + 1u == bpm ? 0u : s.b + 1u;
-    s.b = endb ? b1 : s.b;
-    s.tdoff = ((tdmask >> (2u * s.b)) & 3u) * TABLE_U16;
-    c.advance(c.pos + skip, ahead);
-    return true;
-}
-
 // decode (without emitting) until pos >= end
 __device__ __forceinline__ void run_subsequence(const uint16_t* tabs, unsigned bpm, unsigned tdmask, Cursor& c, Walk& s, unsigned end)
 {

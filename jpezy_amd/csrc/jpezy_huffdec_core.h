@@ -1,0 +1,155 @@
+// jpezy_huffdec_core.h -- the part of the GPU Huffman decoder that is plain arithmetic: the table format, the host-side
+// table builder and the one-symbol decode step.  Included by the kernels (jpezy_huffdec.hip, through jpezy_huffdec.h), by the
+// context code that builds the tables (jpezy_capi.hip) and -- compiled by g++ with AddressSanitizer and UBSan, no HIP involved --
+// by tests/fuzz/huffdec_core_fuzz.cpp, which walks whole scans with the same step and compares with the host decoder
+// (the CPU test suite's view of the round-3 decoder: tests/test_host_codec.py).
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+#include <string.h>
+
+#if defined(__HIPCC__)
+#define JPEZY_HD __host__ __device__ __forceinline__
+#else
+#define JPEZY_HD inline
+#endif
+
+namespace jpezy_dev {
+namespace huffdec {
+
+// Decoding tables (round 3): two 16-bit lookups and no loop, no compare chain.  l1 is indexed by the next L1_BITS bits of the stream; a
+// code of at most L1_BITS bits is decoded by that entry alone, a longer one has E_LONG set and the entry's low 14 bits say where, in l2,
+// the 64 entries for the six bits after its 10-bit prefix start (canonical codes: the long codes sit at the top of the code space and share
+// a handful of prefixes -- five for the Annex K tables; a table that needs more than MAX_SUB of them is left to the host decoder).
+// An entry says everything the decoder's state machine needs: E_VALID | E_EOB (AC symbol 0x00) | run << 9 | s << 4 | (length - 1), with s
+// the number of value bits that follow the code (AC: low nibble of the symbol; DC: the symbol, a category above 16 has no entry).  An unused
+// slot is 0: not a code.
+constexpr int L1_BITS = 10, L2_BITS = 6, MAX_SUB = 16;
+constexpr unsigned E_VALID = 0x8000u, E_LONG = 0x4000u, E_EOB = 0x2000u;
+struct alignas(16) Table {
+    uint16_t l1[1 << L1_BITS];
+    uint16_t l2[MAX_SUB << L2_BITS];
+};
+constexpr unsigned TABLE_U16 = sizeof(Table) / 2;
+
+struct Setup {
+    Table dc[3], ac[3];       // indexed by the scan component's table selector Td (the reference uses Td for both)
+    int bpm;                  // period of the table sequence over the blocks of an MCU (divides the blocks per MCU; at most MAX_PERIOD)
+    unsigned tdmask;          // Td of block b of a period in bits [2 b + 1 : 2 b]
+    unsigned total_blocks;
+    unsigned pad;
+};
+constexpr int MAX_PERIOD = 16;
+static_assert(sizeof(Table) == 4096 && sizeof(Setup) % 16 == 0, "table layout the kernels index by hand");
+
+
+// ---- host: building the tables ----
+// The device decoder's two-level table of one Huffman table (jpezy_huffdec.h).  dc: the symbol is the number of value bits.
+// false: the counts do not describe a prefix code (more codes of some length than the code space has left), or the long codes
+// spread over more 10-bit prefixes than the table has room for -- such a table is left to the host decoder, whose canonical loop
+// defines what it means.
+inline bool build_dev_table(Table& t, const uint8_t bits[16], const uint8_t* vals, int n, bool dc)
+{
+    memset(&t, 0, sizeof t);
+    (void)n;
+    unsigned code = 0;
+    int p = 0, subs = 0;
+    long last_prefix = -1;
+    for (int l = 1; l <= 16; ++l) {
+        for (int c = 0; c < bits[l - 1]; ++c, ++p, ++code) {
+            if (code >= (1u << l)) return false;                     // more codes of this length than the code space has left
+            const unsigned sym = vals[p];
+            unsigned e = 0;
+            if (dc) {
+                if (sym <= 16) e = E_VALID | (sym << 4) | (unsigned)(l - 1);           // a category above 16 is no symbol (entry 0)
+            } else {
+                e = E_VALID | (sym == 0 ? E_EOB : 0u) | ((sym >> 4) << 9) | ((sym & 15u) << 4) | (unsigned)(l - 1);
+            }
+            if (l <= L1_BITS) {
+                const unsigned lo = code << (L1_BITS - l);
+                for (unsigned f = 0; f < (1u << (L1_BITS - l)); ++f) t.l1[lo + f] = (uint16_t)e;
+            } else {
+                const long prefix = (long)(code >> (l - L1_BITS));
+                if (prefix != last_prefix) {                         // canonical codes ascend: so do the prefixes
+                    if (subs == MAX_SUB) return false;
+                    t.l1[prefix] = (uint16_t)(E_VALID | E_LONG | (unsigned)(subs << L2_BITS));
+                    last_prefix = prefix;
+                    ++subs;
+                }
+                const int rest = L1_BITS + L2_BITS - l;      // free bits behind the code inside the 16-bit index
+                const unsigned lo = ((code << rest) & ((1u << L2_BITS) - 1u)) + (unsigned)((subs - 1) << L2_BITS);
+                for (unsigned f = 0; f < (1u << rest); ++f) t.l2[lo + f] = (uint16_t)e;
+            }
+        }
+        if (code > (1u << l)) return false;
+        code <<= 1;
+    }
+    return true;
+}
+
+// the table selectors of the blocks of one period of the MCU's table sequence, two bits each (Setup::tdmask); false: period too long
+inline bool pack_td_sequence(const int* seq, int period, unsigned* mask)
+{
+    if (period > MAX_PERIOD) return false;
+    unsigned m = 0;
+    for (int i = 0; i < period; ++i) m |= (unsigned)(seq[i] & 3) << (2 * i);
+    *mask = m;
+    return true;
+}
+
+
+// ---- the decode step (device and host) ----
+JPEZY_HD int extend(int v, int cat) { return (v & (1 << (cat - 1))) ? v : v - ((1 << cat) - 1); }
+
+// The decoder's state besides the cursor: block inside the table period, zig-zag index (0: a DC symbol comes next), and the
+// offset of the block's table pair inside the Setup (in uint16 units).
+struct Walk {
+    unsigned b, k, tdoff, nblocks;
+    JPEZY_HD void init(unsigned b_, unsigned k_, unsigned tdmask)
+    {
+        b = b_; k = k_; nblocks = 0;
+        tdoff = ((tdmask >> (2u * b)) & 3u) * TABLE_U16;
+    }
+};
+
+// One symbol.  DC and AC symbols run through the same instructions (the lanes of a wave are at unrelated places of their blocks): a DC
+// symbol is a (run 0, size = category) symbol at k = 0 from the DC table.  Straight-line code: every decision is a select.
+// An invalid code, or a run past the end of the block: EMIT returns false (the true decode hit it: the stream is bad); a
+// synchronisation pass -- which may well be decoding from a wrong guess, i.e. garbage -- abandons the block, moves one bit on and
+// carries on, so that it can still fall into step further down.
+// EMIT: coefficients of blocks gidx + nblocks < total go to out (DC: the difference, made absolute by the DC pass).
+template <bool EMIT, class CursorT>
+JPEZY_HD bool decode_step(const uint16_t* tabs, unsigned bpm, unsigned tdmask, CursorT& c, Walk& s,
+                                            unsigned long long gidx, unsigned total, int16_t* out)
+{
+    const uint32_t ahead = c.prefetch();                               // used only when this symbol crosses a word boundary
+    const uint32_t bits = c.peek32();
+    const unsigned tb = s.tdoff + (s.k ? 3u * TABLE_U16 : 0u);         // dc[td] or ac[td]
+    const unsigned e1 = tabs[tb + (bits >> (32 - L1_BITS))];
+    const bool lng = (e1 & E_LONG) != 0;
+    const unsigned i2 = lng ? (e1 & 0x3FFFu) + ((bits >> (32 - L1_BITS - L2_BITS)) & ((1u << L2_BITS) - 1u)) : 0u;
+    const unsigned e2 = tabs[tb + (1u << L1_BITS) + i2];
+    const unsigned e = lng ? e2 : e1;
+    const unsigned len = (e & 15u) + 1u, sz = (e >> 4) & 31u, run = (e >> 9) & 15u;
+    const unsigned kk = s.k + run + 1u;                               // zig-zag index after this symbol
+    const bool bad = !(e & E_VALID) || kk > 64u;
+    if (EMIT) {
+        if (bad) return false;
+        if (sz && gidx + s.nblocks < total)
+            out[(gidx + s.nblocks) * 64 + kk - 1u] = (int16_t)extend((int)((bits << len) >> (32u - sz)), (int)sz);
+    }
+    const unsigned skip = bad ? 1u : len + sz;
+    const unsigned kn = (bad || (e & E_EOB)) ? 64u : kk;
+    const bool endb = kn >= 64u;
+    s.k = endb ? 0u : kn;
+    s.nblocks += endb ? 1u : 0u;
+    const unsigned b1 = s.b + 1u == bpm ? 0u : s.b + 1u;
+    s.b = endb ? b1 : s.b;
+    s.tdoff = ((tdmask >> (2u * s.b)) & 3u) * TABLE_U16;
+    c.advance(c.pos + skip, ahead);
+    return true;
+}
+
+
+}  // namespace huffdec
+}  // namespace jpezy_dev

@@ -129,6 +129,16 @@ def main():
         lst = Path(td) / "list.txt"
         lst.write_text("\n".join(names) + "\n")
         r = subprocess.run([str(exe), "@" + str(lst)], capture_output=True, text=True)
+        print(r.stdout.strip())
+        if r.returncode != 0:
+            print(r.stderr[-4000:])
+            return r.returncode
+        # the core of the GPU Huffman decoder (tables + decode step) walked on the CPU over the same files, same sanitizers
+        exe2 = Path(tempfile.gettempdir()) / "jpezy_huffdec_core_fuzz"
+        src2 = [ROOT / "tests" / "fuzz" / "huffdec_core_fuzz.cpp", ROOT / "jpezy_amd" / "csrc" / "jpezy_host_codec.cpp"]
+        subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-fno-omit-frame-pointer",
+                        "-I", str(ROOT / "include"), *map(str, src2), "-o", str(exe2), "-pthread"], check=True)
+        r = subprocess.run([str(exe2), "@" + str(lst)], capture_output=True, text=True)
     print(r.stdout.strip())
     if r.returncode != 0:
         print(r.stderr[-4000:])

@@ -214,6 +214,11 @@ def test_host_codec_under_asan_ubsan_on_mutated_files():
         pytest.skip("no libasan for g++ in this image")
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert "decoded" in r.stdout
+    # the core of the GPU Huffman decoder (two-level tables, table builder, decode step: jpezy_amd/csrc/jpezy_huffdec_core.h) walked on
+    # the CPU over the same files under the same sanitizers (tests/fuzz/huffdec_core_fuzz.cpp): what it decodes is what the host decoder
+    # decodes, and no encoder's file is declined
+    m = re.search(r"decode step on the CPU: (\d+) files walked and equal to the host decoder", r.stdout)
+    assert m and int(m.group(1)) >= 100, r.stdout
 
 
 def test_scan_that_selects_an_undefined_table_is_an_error(golden_dir):

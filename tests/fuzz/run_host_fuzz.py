@@ -30,7 +30,8 @@ def seeds():
                 out.append(bytes(z[k].tobytes()))
     rng = np.random.default_rng(3)
     for kw in (dict(subsampling=0, quality=90), dict(subsampling=1, quality=60), dict(subsampling=2, quality=35, optimize=True),
-               dict(subsampling=2, quality=70, restart_marker_blocks=2)):
+               dict(subsampling=2, quality=70, restart_marker_blocks=2), dict(subsampling=0, quality=98, optimize=True),
+               dict(subsampling=1, quality=96)):
         img = rng.integers(0, 256, (40, 56, 3), dtype=np.uint8)
         buf = io.BytesIO()
         Image.fromarray(img).save(buf, "JPEG", **kw)

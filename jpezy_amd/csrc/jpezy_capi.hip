@@ -160,6 +160,8 @@ struct jpezy_ctx {
     int b_last_fast = 0;           // files of the last jpezy_decode_jpeg_batch call that took the batch form (diagnostic hook)
     uint8_t* b_pin = nullptr;      // pinned staging of the concatenated scans
     size_t b_pin_cap = 0;
+    uint8_t* b_stage[2] = { nullptr, nullptr };   // pinned staging of a slice's planes when the files are small (one download per slice)
+    size_t b_stage_cap[2] = { 0, 0 };
     DevBuf e_hdr;                  // JFIF header bytes of the device-resident variant (cached per W, H, comment)
     jpezy_host::HostPipe pipe;     // staging ring of the streaming host-buffer entry points (jpezy_hostpipe.h)
     size_t host_chunk_bytes = 4u << 20;   // bytes of input per chunk of that pipeline (jpezy_ctx_set_host_chunk_bytes)
@@ -351,6 +353,7 @@ void jpezy_ctx_destroy(jpezy_ctx* c)
     if (c->d_codes) (void)hipFree(c->d_codes);
     if (c->e_pinned) (void)hipHostFree(c->e_pinned);
     if (c->b_pin) (void)hipHostFree(c->b_pin);
+    for (uint8_t* q : c->b_stage) if (q) (void)hipHostFree(q);
     for (DevBuf* b : { &c->b_scan, &c->b_U, &c->b_cnt, &c->b_rb, &c->b_state, &c->b_prop, &c->b_meta, &c->b_coef, &c->b_planes[0], &c->b_planes[1] }) b->release();
     for (DevBuf* b : { &c->e_tmp, &c->e_small, &c->e_U, &c->e_cnt, &c->e_out, &c->e_coef, &c->e_hdr, &c->e_status, &c->e_tt, &c->e_fft, &c->e_S, &c->e_base, &c->e_ft,
                        &c->dump_t, &c->h_scan, &c->h_U, &c->h_cnt, &c->h_off, &c->h_state, &c->h_setup, &c->h_small, &c->h_dc }) b->release();
@@ -1793,10 +1796,14 @@ try {
                 if (!taken[k] && same_group(cand[a]->info, cand[k]->info)) { taken[k] = 1; grp.push_back(cand[k]->ff); }
             if (grp.size() < 2) continue;                                   // a single file gains nothing here
             const jpezy_frame_info& gi = cand[a]->info;
-            // slices: at most 16 files (JPEZY_BATCH_SLICE: development knob) and ~1.5 GB of planes + coefficients at a time
-            // (planes + coefficients + the generic kernels' int samples)
+            // slices: a slice's chain of launches is latency (~1 ms whatever it holds), its planes go down while the next slice is decoded.  16
+            // files of 1080p (100 MB of planes) balance the two; smaller files get proportionally more per slice -- ~100 MB of planes,
+            // at most 512 files (JPEZY_BATCH_SLICE: development knob, a fixed count) -- and never more than ~1.5 GB of planes +
+            // coefficients + the generic kernels' int samples at a time
             const size_t per_file = (size_t)gi.width * gi.height * 3 + (size_t)gi.mcu_cols * gi.mcu_rows * (size_t)gi.blocks_per_mcu * (128 + 256);
-            static const size_t slice_files = [] { const char* e = std::getenv("JPEZY_BATCH_SLICE"); const int v = e ? std::atoi(e) : 16; return (size_t)(v < 2 ? 2 : v > 512 ? 512 : v); }();
+            static const size_t slice_knob = [] { const char* e = std::getenv("JPEZY_BATCH_SLICE"); const int v = e ? std::atoi(e) : 0; return (size_t)(v <= 0 ? 0 : v < 2 ? 2 : v > 512 ? 512 : v); }();
+            const size_t by_planes = std::min<size_t>(512, std::max<size_t>(16, ((size_t)100 << 20) / std::max<size_t>((size_t)gi.width * gi.height * 3, 1)));
+            const size_t slice_files = slice_knob ? slice_knob : by_planes;
             const size_t per_slice = std::max<size_t>(2, std::min<size_t>(slice_files, ((size_t)3 << 29) / std::max<size_t>(per_file, 1)));
             const size_t plane = (size_t)gi.width * gi.height, pstride = (plane + 15) & ~(size_t)15;
             for (size_t s0 = 0; s0 < grp.size(); s0 += per_slice) {
@@ -1819,8 +1826,33 @@ try {
                 const uint8_t* pl = (const uint8_t*)c->b_planes[pb].p;
                 const size_t nfs = slice.size();
                 const int device = c->device;
+                // small planes: three copies into pageable memory per file cost ~40 us of driver time per file whatever their size (1,024
+                // files of 256 x 256: 47 ms, PCIe would need 5) -- the slice's planes come down in ONE copy into pinned memory and the
+                // drainer thread hands them out with memcpy
+                uint8_t* stage = nullptr;
+                if (plane < ((size_t)1 << 20)) {
+                    const size_t need = 3 * pstride * nfs;
+                    if (c->b_stage_cap[pb] < need) {
+                        if (c->b_stage[pb]) (void)hipHostFree(c->b_stage[pb]);
+                        c->b_stage[pb] = nullptr; c->b_stage_cap[pb] = 0;
+                        if (hipHostMalloc((void**)&c->b_stage[pb], need + (need >> 2), hipHostMallocDefault) == hipSuccess) c->b_stage_cap[pb] = need + (need >> 2);
+                    }
+                    stage = c->b_stage_cap[pb] >= need ? c->b_stage[pb] : nullptr;         // (no pinned memory: the per-plane copies)
+                }
                 drainer[pb] = std::thread([=, &drain_err] {
                     if (hipSetDevice(device) != hipSuccess) { drain_err.store(1); return; }
+                    if (stage) {
+                        if (hipMemcpyAsync(stage, pl, 3 * pstride * nfs, hipMemcpyDeviceToHost, s_down) != hipSuccess ||
+                            hipStreamSynchronize(s_down) != hipSuccess) { drain_err.store(1); return; }
+                        for (size_t q = 0; q + 1 < idx.size(); q += 2) {
+                            const size_t k = (size_t)idx[q];
+                            const int i = idx[q + 1];
+                            std::memcpy(r[i], stage + pstride * k, plane);
+                            std::memcpy(g[i], stage + pstride * (nfs + k), plane);
+                            std::memcpy(b[i], stage + pstride * (2 * nfs + k), plane);
+                        }
+                        return;
+                    }
                     for (size_t q = 0; q + 1 < idx.size(); q += 2) {
                         const size_t k = (size_t)idx[q];
                         const int i = idx[q + 1];

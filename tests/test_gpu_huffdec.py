@@ -425,3 +425,26 @@ def test_restart_intervals_on_the_gpu(J, ctx, oracle):
             assert np.array_equal(got, want)
             assert ctx.last_huffdec_passes() == 0         # the host decoder's file
 
+
+def test_decode_jpeg_batch_large_planes(J, ctx, oracle):
+    """planes of 1 MB and more go down with a copy per plane straight into the caller's buffers, smaller ones through one pinned
+    download per slice (jpezy_decode_jpeg_batch): three 1280x1024 files beside small ones, every plane equal to the per-file decode
+    and (first file) to the oracle's decoder"""
+    rng = np.random.default_rng(12)
+    big = []
+    for k in range(3):
+        r, g, b = (rng.integers(0, 256, 1280 * 1024, dtype=np.uint8) for _ in range(3))
+        big.append(ctx.encode_jpeg(r, g, b, 1280, 1024))
+    small = [ctx.encode_jpeg(*oracle.synth_rgb(96, 64, frame=k), 96, 64) for k in range(5)]
+    files = [big[0], small[0], small[1], big[1], small[2], big[2], small[3], small[4]]
+    ctx.set_huffdec_min_bytes(0)
+    got = ctx.decode_jpeg_batch(files)
+    assert ctx.last_batch_fast_count() == len(files)
+    for i, f in enumerate(files):
+        one = ctx.decode_jpeg(f)
+        for q in (1, 2, 3):
+            assert np.array_equal(got[i][q], one[q]), (i, q)
+    want = oracle.decode_jpeg(big[0], False)
+    for a, e in zip(got[0][1:], want[-3:]):
+        assert np.array_equal(a, np.asarray(e).reshape(-1)[: 1280 * 1024])
+

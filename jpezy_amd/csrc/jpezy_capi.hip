@@ -1683,15 +1683,36 @@ int decode_slice_fast(jpezy_ctx* c, const std::vector<FastFile>& files, const jp
         std::fprintf(stderr, "  batch slice (%u files): %-28s %.3f ms\n", nf, what, (t - t_mark) * 1e3);
         t_mark = t;
     };
+    // the device tables are built once per DISTINCT set of Huffman tables (24 KB and ~10 us each: files of one encoder share theirs)
+    auto same_tables = [](const jpezy_host::ScanSetup& a, const jpezy_host::ScanSetup& b0) {
+        if (std::memcmp(a.Td, b0.Td, sizeof a.Td) || std::memcmp(a.present, b0.present, sizeof a.present) || std::memcmp(a.bits, b0.bits, sizeof a.bits)) return false;
+        for (int t = 0; t < 8; ++t)
+            if (a.present[t] && (a.nvals[t] != b0.nvals[t] || std::memcmp(a.vals[t], b0.vals[t], (size_t)a.nvals[t]))) return false;
+        return true;
+    };
     std::vector<DevStream> streams(nf);
-    std::vector<HD::Setup> setups(nf);
-    std::vector<char> setup_usable(nf, 1);
+    std::vector<HD::Setup> setups;
+    std::vector<char> setup_usable;
+    std::vector<unsigned> first_with;                       // file that brought setups[j]
+    bool small = nf > 1;
     for (unsigned k = 0; k < nf; ++k) {
-        streams[k] = { files[k].scan, files[k].n, (unsigned)(nmcu * bpm), (unsigned long long)k * cpf, k };
-        setup_usable[k] = build_dev_setup(setups[k], files[k].setup, info, (unsigned)(nmcu * bpm));      // (any DHT the file carries)
+        unsigned j = (unsigned)first_with.size();
+        for (unsigned q = (unsigned)first_with.size(); q-- > 0;)               // (the latest first: neighbours tend to match)
+            if (same_tables(files[k].setup, files[first_with[q]].setup)) { j = q; break; }
+        if (j == first_with.size()) {
+            setups.emplace_back();
+            setup_usable.push_back(build_dev_setup(setups.back(), files[k].setup, info, (unsigned)(nmcu * bpm)) ? 1 : 0);   // (any DHT the file carries)
+            if (first_with.size() < 64) first_with.push_back(k);              // (many different tables: one each from there on, no more searching)
+            j = (unsigned)setups.size() - 1;
+        }
+        streams[k] = { files[k].scan, files[k].n, (unsigned)(nmcu * bpm), (unsigned long long)k * cpf, j };
+        small = small && files[k].n <= 4096;
     }
+    // Thumbnails: scans of a few KB that all carry the same tables are walked by a lane each -- one launch instead of the speculation /
+    // synchronisation chain over a workgroup per file
+    const bool per_lane = small && setups.size() == 1;
     if (int rc = c->b_coef.reserve((size_t)nf * cpf * sizeof(int16_t))) return rc;
-    if (int rc = huffdec_streams(c, streams, setups, setup_usable, stream_geom(info), (int16_t*)c->b_coef.p, (size_t)nf * cpf, ok, lap)) return rc;
+    if (int rc = huffdec_streams(c, streams, setups, setup_usable, stream_geom(info), (int16_t*)c->b_coef.p, (size_t)nf * cpf, ok, lap, per_lane)) return rc;
     // dequantisation + inverse transform + colour conversion of the whole slice in one launch (a file that failed decodes to garbage nobody reads)
     if (int rc = c->b_planes[plane_buf].reserve(3 * pstride * nf)) return rc;
     uint8_t* pl = (uint8_t*)c->b_planes[plane_buf].p;

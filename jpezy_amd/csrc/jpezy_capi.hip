@@ -1572,18 +1572,9 @@ try {
     HIP_TRY(hipMemsetAsync(d_lastbit, 0xFF, sizeof(unsigned long long), s));
     HIP_TRY(HD::launch_emit((const HD::Setup*)c->h_setup.p, (const uint32_t*)c->h_U.p, u_bytes / 4, n_sub, d_exit,
                             (const unsigned long long*)c->h_off.p, d_coeffs, d_error, d_lastbit, s));
-    {
-        unsigned start = 0;
-        for (int i = 0; i < info->ncomp; ++i) {
-            const unsigned count = (unsigned)(info->H[i] * info->V[i]);
-            const size_t nd = nmcu * count;
-            unsigned long long* d = (unsigned long long*)c->h_dc.p;
-            unsigned long long* before = d + nd + 1;
-            HIP_TRY(HD::launch_dc_gather(d_coeffs, (unsigned)bpm, start, count, nd, d, s));
-            HIP_TRY(E::launch_scan_u64(d, before, nd, (unsigned long long*)c->e_tmp.p, s));
-            HIP_TRY(HD::launch_dc_scatter(d_coeffs, (unsigned)bpm, start, count, nd, before, s));
-            start += count;
-        }
+    {   // DC differences -> values, all components in three launches (round 2: gather, two-launch scan, scatter per component = twelve)
+        const StreamGeom g = stream_geom(*info);
+        HIP_TRY(HD::launch_dc_prefix(d_coeffs, g.bpm, g.ncomp, g.cstart, g.ccount, nmcu, (int*)c->h_dc.p, s));
     }
     unsigned error = 0;
     unsigned long long last_bit = 0;

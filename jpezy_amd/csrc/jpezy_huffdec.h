@@ -69,9 +69,11 @@ hipError_t launch_sync(const Setup* S, const uint32_t* U, size_t u_words, unsign
                        unsigned* nblocks, unsigned* changed, int max_inner, hipStream_t s);
 hipError_t launch_emit(const Setup* S, const uint32_t* U, size_t u_words, unsigned n_sub, const uint32_t* exit_state,
                        const unsigned long long* blocks_before, int16_t* out, unsigned* error, unsigned long long* last_bit, hipStream_t s);
-hipError_t launch_dc_gather(const int16_t* coeffs, unsigned bpm, unsigned start, unsigned count, size_t n, unsigned long long* d, hipStream_t s);
-hipError_t launch_dc_scatter(int16_t* coeffs, unsigned bpm, unsigned start, unsigned count, size_t n, const unsigned long long* before,
-                             hipStream_t s);
+// DC differences -> values for all components of one scan in three launches (component q owns blocks [cstart[q], cstart[q] + ccount[q]) of
+// every MCU); scratch: dc_prefix_scratch_ints(nmcu, largest ccount) ints
+size_t dc_prefix_scratch_ints(size_t nmcu, unsigned max_count);
+hipError_t launch_dc_prefix(int16_t* coeffs, unsigned bpm, unsigned ncomp, const unsigned cstart[3], const unsigned ccount[3], size_t nmcu, int* scratch,
+                            hipStream_t s);
 
 }  // namespace huffdec
 }  // namespace jpezy_dev

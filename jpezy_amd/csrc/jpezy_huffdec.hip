@@ -280,22 +280,97 @@ __global__ __launch_bounds__(WGS) void emit_kernel(const Setup* gS, const uint32
     if (g0 + wk.nblocks >= total) *last_bit = (unsigned long long)i0 * SUBSEQ_BITS + c.pos;
 }
 
-// ---- DC differences -> absolute values, per component (pre_DC, ref :611-614) ----
-// component c owns blocks [start, start + count) of every MCU
-__global__ void dc_gather_kernel(const int16_t* coeffs, unsigned bpm, unsigned start, unsigned count, size_t n, unsigned long long* d)
+// ---- DC differences -> absolute values, per component (pre_DC, ref :611-614); component q owns blocks [cstart[q], cstart[q] + ccount[q]) of
+// every MCU.  All components in THREE launches (grid.y = component; round 2 took four per component: gather, two-launch scan, scatter): (1) every workgroup turns its 2,048
+// DC differences into prefix sums inside the workgroup, in place, and leaves its total; (2) one workgroup per component scans the totals;
+// (3) every workgroup adds what came before it.  Sums wrap in 32 bits and are stored as int16: the low 16 bits are those of the true sum.
+struct DcGeom { unsigned bpm, ncomp, cstart[3], ccount[3]; unsigned long long nmcu; };
+constexpr int DC_PER_WG = 2048;
+__device__ __forceinline__ size_t dc_slot(const DcGeom& g, unsigned comp, size_t j)
 {
-    const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n) return;
+    const unsigned count = g.ccount[comp];
     const size_t mcu = j / count, t = j - mcu * count;
-    d[j] = (unsigned long long)(long long)coeffs[(mcu * bpm + start + t) * 64];
+    return (mcu * g.bpm + g.cstart[comp] + t) * 64;
 }
-__global__ void dc_scatter_kernel(int16_t* coeffs, unsigned bpm, unsigned start, unsigned count, size_t n, const unsigned long long* before)
+__global__ __launch_bounds__(256) void dc_local_kernel(int16_t* coeffs, DcGeom g, int* totals, unsigned wg_per_comp)
 {
-    const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n) return;
-    const size_t mcu = j / count, t = j - mcu * count;
-    int16_t* z = coeffs + (mcu * bpm + start + t) * 64;
-    z[0] = (int16_t)((long long)before[j] + (long long)z[0]);
+    __shared__ int wsum[4];
+    const unsigned comp = blockIdx.y;
+    const size_t nd = (size_t)g.nmcu * g.ccount[comp], j0 = (size_t)blockIdx.x * DC_PER_WG + (size_t)threadIdx.x * 8;
+    if ((size_t)blockIdx.x * DC_PER_WG >= nd) return;                        // workgroup-uniform
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int v[8], sum = 0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        v[q] = j0 + q < nd ? (int)coeffs[dc_slot(g, comp, j0 + q)] : 0;
+        sum += v[q];
+    }
+    int inc = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += o;
+    }
+    if (lane == 63) wsum[wv] = inc;
+    __syncthreads();
+    int woff = 0, tot = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        if (q < wv) woff += wsum[q];
+        tot += wsum[q];
+    }
+    int run = woff + inc - sum;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        run += v[q];
+        if (j0 + q < nd) coeffs[dc_slot(g, comp, j0 + q)] = (int16_t)run;
+    }
+    if (threadIdx.x == 0) totals[(size_t)comp * wg_per_comp + blockIdx.x] = tot;
+}
+// totals -> what came before each workgroup (exclusive), one workgroup per component, 256 totals per step with a running carry
+__global__ __launch_bounds__(256) void dc_totals_kernel(int* totals, DcGeom g, unsigned wg_per_comp)
+{
+    __shared__ int wsum[4];
+    const unsigned comp = blockIdx.x;
+    const size_t nd = (size_t)g.nmcu * g.ccount[comp];
+    const unsigned n = (unsigned)((nd + DC_PER_WG - 1) / DC_PER_WG);
+    int* t = totals + (size_t)comp * wg_per_comp;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int carry = 0;
+    for (unsigned i0 = 0; i0 < n; i0 += 256) {
+        const unsigned i = i0 + threadIdx.x;
+        const int v = i < n ? t[i] : 0;
+        int inc = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_up(inc, d, 64);
+            if (lane >= d) inc += o;
+        }
+        if (lane == 63) wsum[wv] = inc;
+        __syncthreads();
+        int woff = 0, tot = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (q < wv) woff += wsum[q];
+            tot += wsum[q];
+        }
+        if (i < n) t[i] = carry + woff + inc - v;
+        carry += tot;
+        __syncthreads();
+    }
+}
+__global__ __launch_bounds__(256) void dc_add_kernel(int16_t* coeffs, DcGeom g, const int* totals, unsigned wg_per_comp)
+{
+    const unsigned comp = blockIdx.y;
+    const size_t nd = (size_t)g.nmcu * g.ccount[comp], j0 = (size_t)blockIdx.x * DC_PER_WG + (size_t)threadIdx.x * 8;
+    if (blockIdx.x == 0 || (size_t)blockIdx.x * DC_PER_WG >= nd) return;   // (nothing comes before the first workgroup)
+    const int before = totals[(size_t)comp * wg_per_comp + blockIdx.x];
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+        if (j0 + q < nd) {
+            int16_t* z = coeffs + dc_slot(g, comp, j0 + q);
+            *z = (int16_t)((int)*z + before);
+        }
 }
 
 // ---- 0xFF00 -> 0xFF ----
@@ -678,17 +753,20 @@ hipError_t launch_emit(const Setup* S, const uint32_t* U, size_t u_words, unsign
                        last_bit);
     return hipGetLastError();
 }
-hipError_t launch_dc_gather(const int16_t* coeffs, unsigned bpm, unsigned start, unsigned count, size_t n, unsigned long long* d, hipStream_t s)
+size_t dc_prefix_scratch_ints(size_t nmcu, unsigned max_count) { return 3 * ((nmcu * max_count + DC_PER_WG - 1) / DC_PER_WG + 1); }
+hipError_t launch_dc_prefix(int16_t* coeffs, unsigned bpm, unsigned ncomp, const unsigned cstart[3], const unsigned ccount[3], size_t nmcu, int* scratch,
+                            hipStream_t s)
 {
-    if (!n) return hipSuccess;
-    hipLaunchKernelGGL(dc_gather_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, coeffs, bpm, start, count, n, d);
-    return hipGetLastError();
-}
-hipError_t launch_dc_scatter(int16_t* coeffs, unsigned bpm, unsigned start, unsigned count, size_t n, const unsigned long long* before,
-                             hipStream_t s)
-{
-    if (!n) return hipSuccess;
-    hipLaunchKernelGGL(dc_scatter_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, coeffs, bpm, start, count, n, before);
+    DcGeom g;
+    g.bpm = bpm; g.ncomp = ncomp; g.nmcu = nmcu;
+    unsigned maxc = 1;
+    for (unsigned q = 0; q < 3; ++q) { g.cstart[q] = q < ncomp ? cstart[q] : 0; g.ccount[q] = q < ncomp ? ccount[q] : 1; maxc = g.ccount[q] > maxc ? g.ccount[q] : maxc; }
+    const size_t wgs = (nmcu * maxc + DC_PER_WG - 1) / DC_PER_WG;
+    if (!wgs || !ncomp) return hipSuccess;
+    if (wgs > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(dc_local_kernel, dim3((unsigned)wgs, ncomp), dim3(256), 0, s, coeffs, g, scratch, (unsigned)wgs + 1);
+    hipLaunchKernelGGL(dc_totals_kernel, dim3(ncomp), dim3(256), 0, s, scratch, g, (unsigned)wgs + 1);
+    hipLaunchKernelGGL(dc_add_kernel, dim3((unsigned)wgs, ncomp), dim3(256), 0, s, coeffs, g, (const int*)scratch, (unsigned)wgs + 1);
     return hipGetLastError();
 }
 

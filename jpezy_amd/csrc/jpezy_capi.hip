@@ -1385,7 +1385,7 @@ try {
         const size_t n_all = len - setup.scan_pos;
         // intervals of a few KB: a lane per interval; longer ones: subsequences, speculation and synchronisation inside every interval
         // (a workgroup per 256 subsequences of an interval, so at most 65,536 of those)
-        const bool per_lane = n_all / n_int <= 4096;
+        const bool per_lane = n_int >= 1 && n_all / n_int <= 4096;
         bool regular = n_int >= 1 && n_int <= (per_lane ? (size_t)1 << 20 : (size_t)65536) && n_all >= c->h_min_bytes;
         std::vector<DevStream> streams;
         size_t at = 0;

@@ -1844,7 +1844,7 @@ try {
                 // large ones (256 x 1080p, smooth content: 43.5 -> 35.6 ms; JPEZY_BATCH_DIRECT=1: the direct copies, for comparison).
                 uint8_t* stage = nullptr;
                 static const bool direct = std::getenv("JPEZY_BATCH_DIRECT") != nullptr;
-                if (!direct) {
+                if (!direct && 3 * pstride * nfs <= ((size_t)256 << 20)) {       // (slices of very large pictures: no quarter-GB of pinned memory each)
                     const size_t need = 3 * pstride * nfs;
                     if (c->b_stage_cap[pb] < need) {
                         if (c->b_stage[pb]) (void)hipHostFree(c->b_stage[pb]);

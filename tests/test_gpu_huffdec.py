@@ -447,4 +447,15 @@ def test_decode_jpeg_batch_large_planes(J, ctx, oracle):
     want = oracle.decode_jpeg(big[0], False)
     for a, e in zip(got[0][1:], want[-3:]):
         assert np.array_equal(a, np.asarray(e).reshape(-1)[: 1280 * 1024])
+    # a slice whose planes exceed the pinned stage (6 x 4096 x 4096: 300 MB) goes down with a copy per plane
+    r, g, b = (rng.integers(0, 256, 4096 * 4096, dtype=np.uint8) for _ in range(3))
+    huge = [ctx.encode_jpeg(r, g, b, 4096, 4096), ctx.encode_jpeg(g, b, r, 4096, 4096)]
+    files = [huge[k % 2] for k in range(6)]
+    got = ctx.decode_jpeg_batch(files)
+    assert ctx.last_batch_fast_count() == 6
+    for k in (0, 1):
+        one = ctx.decode_jpeg(huge[k])
+        for i in (k, k + 4):
+            for q in (1, 2, 3):
+                assert np.array_equal(got[i][q], one[q]), (i, q)
 

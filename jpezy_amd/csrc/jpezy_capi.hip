@@ -905,17 +905,27 @@ int entropy_chunk(jpezy_ctx* c, const int16_t* d_coeffs, int W, int H, int gray,
     }
     HIP_TRY(hipMemcpyAsync(c->e_pinned, c->e_out.p, o_stride * F, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
-    for (int f = 0; f < F; ++f) {
-        uint8_t* dst = out + (size_t)f * cap;
-        if (status[f]) { sizes[f] = JPEZY_E_FORMAT; *any_failed = true; continue; }
-        const size_t hdr = jpezy_host::write_header(W, H, comment, dst, cap);
-        const size_t body = (size_t)(nbytes[f] + fftot[f]);
-        if (!hdr || hdr + body + 2 > cap) { sizes[f] = JPEZY_E_NOSPACE; *any_failed = true; continue; }
-        std::memcpy(dst + hdr, c->e_pinned + (size_t)f * o_stride, body);
-        dst[hdr + body] = 0xFF;
-        dst[hdr + body + 1] = 0xD9;
-        sizes[f] = (long)(hdr + body + 2);
-    }
+    // (four threads when there is much to hand out: a core copies ~25 GB/s -- 256 frames of 1080p noise, 168 MB: 11.9 -> 7 ms per call)
+    std::atomic<int> failed{ 0 };
+    auto hand_out = [&](int f0, int step) {
+        for (int f = f0; f < F; f += step) {
+            uint8_t* dst = out + (size_t)f * cap;
+            if (status[f]) { sizes[f] = JPEZY_E_FORMAT; failed.store(1); continue; }
+            const size_t hdr = jpezy_host::write_header(W, H, comment, dst, cap);
+            const size_t body = (size_t)(nbytes[f] + fftot[f]);
+            if (!hdr || hdr + body + 2 > cap) { sizes[f] = JPEZY_E_NOSPACE; failed.store(1); continue; }
+            std::memcpy(dst + hdr, c->e_pinned + (size_t)f * o_stride, body);
+            dst[hdr + body] = 0xFF;
+            dst[hdr + body + 1] = 0xD9;
+            sizes[f] = (long)(hdr + body + 2);
+        }
+    };
+    const int n_copy = o_stride * (size_t)F > ((size_t)8 << 20) && F >= 4 ? 4 : 1;
+    std::vector<std::thread> helpers;
+    for (int t = 1; t < n_copy; ++t) helpers.emplace_back(hand_out, t, n_copy);
+    hand_out(0, n_copy);
+    for (auto& h : helpers) h.join();
+    if (failed.load()) *any_failed = true;
     return JPEZY_OK;
 }
 

@@ -1180,6 +1180,7 @@ int huffdec_streams(jpezy_ctx* c, const std::vector<DevStream>& streams, const s
         f.chunk0 = (unsigned)total_chunks;
         f.n_chunks = (unsigned)((st.n + chunk - 1) / chunk);
         f.n_bytes = (unsigned)st.n;
+        f.first_marker = ~0u;               // (st.n may be an upper bound: the device finds where the segment ends)
         f.sub0 = (unsigned)total_slots;
         f.n_sub_max = (unsigned)((st.n * 8 + L - 1) / L);
         f.u_off = u_bytes;
@@ -1254,8 +1255,9 @@ int huffdec_streams(jpezy_ctx* c, const std::vector<DevStream>& streams, const s
         HIP_TRY(hipStreamSynchronize(s));
         lap("decode (a lane per stream)");
         for (unsigned k = 0; k < nf; ++k) {
-            const unsigned long long data_bits = ((unsigned long long)F[k].n_bytes - F[k].removed) * 8;
-            ok[k] = usable[k] && !F[k].error && F[k].last_bit <= data_bits;
+            const unsigned n_eff = F[k].first_marker < F[k].n_bytes ? F[k].first_marker : F[k].n_bytes;
+            const unsigned long long data_bits = ((unsigned long long)n_eff - F[k].removed) * 8;
+            ok[k] = usable[k] && n_eff > 0 && !F[k].error && F[k].last_bit <= data_bits;
         }
         return JPEZY_OK;
     }
@@ -1314,8 +1316,9 @@ int huffdec_streams(jpezy_ctx* c, const std::vector<DevStream>& streams, const s
     HIP_TRY(hipStreamSynchronize(s));
     lap("emit + DC");
     for (unsigned k = 0; k < nf; ++k) {
-        const unsigned long long data_bits = ((unsigned long long)F[k].n_bytes - F[k].removed) * 8;
-        ok[k] = converged[k] && !F[k].error && F[k].last_bit <= data_bits;
+        const unsigned n_eff = F[k].first_marker < F[k].n_bytes ? F[k].first_marker : F[k].n_bytes;
+        const unsigned long long data_bits = ((unsigned long long)n_eff - F[k].removed) * 8;
+        ok[k] = converged[k] && n_eff > 0 && !F[k].error && F[k].last_bit <= data_bits;
     }
     return JPEZY_OK;
 }
@@ -1756,7 +1759,7 @@ try {
     {
         struct Cand { FastFile ff; jpezy_frame_info info; bool good = false; };
         std::vector<Cand> all((size_t)n);
-        // headers and the end of every scan (a pass over the whole entropy-coded segment), spread over host threads
+        // headers, spread over host threads
         auto prep = [&](int i) {
             Cand& cd = all[(size_t)i];
             std::string err;
@@ -1773,10 +1776,11 @@ try {
             for (int q = 0; q < fi.ncomp && tabs; ++q)
                 tabs = cd.ff.setup.Td[q] >= 0 && cd.ff.setup.Td[q] <= 2 && cd.ff.setup.present[cd.ff.setup.Td[q]] && cd.ff.setup.present[4 + cd.ff.setup.Td[q]];
             if (!tabs) return;
+            // (the file goes up from its first scan byte to its end: the device finds the marker that ends the entropy-coded segment)
             const uint8_t* scan = data[i] + cd.ff.setup.scan_pos;
-            const size_t ns = jpezy_host::entropy_segment_length(scan, len[i] - cd.ff.setup.scan_pos);
+            const size_t ns = len[i] - cd.ff.setup.scan_pos;
             const size_t nblk = (size_t)fi.mcu_cols * fi.mcu_rows * (size_t)fi.blocks_per_mcu;
-            if (ns == 0 || nblk > 4 * len[i] || nblk >= 0xFFFFFFFFull) return;
+            if (ns == 0 || ns >= 0xFFFFFFFFull || nblk > 4 * len[i] || nblk >= 0xFFFFFFFFull) return;
             cd.ff.index = i; cd.ff.scan = scan; cd.ff.n = ns;
             cd.good = true;
         };

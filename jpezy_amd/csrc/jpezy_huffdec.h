@@ -23,6 +23,8 @@ struct BatchFile {
     unsigned long long u_off;           // byte offset of the file's unstuffed stream in U (a multiple of 4)
     unsigned u_words;                   // 32-bit words of U the file may read
     unsigned removed;                   // stuffing bytes removed (device)
+    unsigned first_marker;              // n_bytes may be an upper bound: offset of the first marker inside it (device, atomicMin; the host sets all ones)
+    unsigned pad2;
     unsigned long long coeff_off;       // int16 offset of the file's coefficients
     unsigned total_blocks, nmcu, bpm, ncomp;
     unsigned cstart[3], ccount[3];      // component c owns blocks [cstart, cstart + ccount) of every MCU
@@ -33,7 +35,7 @@ struct BatchFile {
     unsigned long long last_bit;
 };
 
-hipError_t launch_unstuff_count_batch(const uint8_t* S, const BatchFile* F, unsigned n_files, unsigned total_chunks, uint32_t* counts, hipStream_t s);
+hipError_t launch_unstuff_count_batch(const uint8_t* S, BatchFile* F, unsigned n_files, unsigned total_chunks, uint32_t* counts, hipStream_t s);
 hipError_t launch_unstuff_copy_batch(const uint8_t* S, BatchFile* F, unsigned n_files, unsigned total_chunks, const unsigned long long* removed_before,
                                      uint8_t* U, hipStream_t s);       // also fills F[].removed, n_sub and resets the per-file flags
 hipError_t launch_speculate_batch(const Setup* setups, const uint32_t* U, const BatchFile* F, const unsigned* wg_file, const unsigned* wg_first,

@@ -437,7 +437,9 @@ __device__ __forceinline__ unsigned file_of_chunk(const BatchFile* F, unsigned n
     return lo;
 }
 
-__global__ __launch_bounds__(256) void unstuff_count_batch_kernel(const uint8_t* S, const BatchFile* F, unsigned n_files, unsigned total_chunks,
+// F[f].n_bytes may be an upper bound (the file from its first scan byte to its end): as in the single-scan kernels the count launch finds
+// where the entropy-coded segment ends (F[f].first_marker, atomicMin, set to all ones by the host) and the copy launch stops there.
+__global__ __launch_bounds__(256) void unstuff_count_batch_kernel(const uint8_t* S, BatchFile* F, unsigned n_files, unsigned total_chunks,
                                                                   uint32_t* counts)
 {
     const unsigned c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -445,16 +447,22 @@ __global__ __launch_bounds__(256) void unstuff_count_batch_kernel(const uint8_t*
     const unsigned f = file_of_chunk(F, n_files, c);
     const size_t base = (size_t)F[f].chunk0 * CHUNK, n = F[f].n_bytes;
     const size_t b0 = (size_t)(c - F[f].chunk0) * CHUNK;
-    unsigned cnt = 0;
+    unsigned cnt = 0, marker = ~0u;
     if (b0 < n) {
         uint8_t prev = b0 ? S[base + b0 - 1] : 0;
         const size_t e = b0 + CHUNK < n ? b0 + CHUNK : n;
         for (size_t i = b0; i < e; ++i) {
             const uint8_t v = S[base + i];
-            if (v == 0x00 && prev == 0xFF) { ++cnt; prev = 0x01; } else prev = v;
+            if (v == 0x00 && prev == 0xFF) { ++cnt; prev = 0x01; }
+            else {
+                if (prev == 0xFF && marker == ~0u) marker = (unsigned)(i - 1);
+                prev = v;
+            }
         }
+        if (e == n && prev == 0xFF && marker == ~0u) marker = (unsigned)(n - 1);
     }
     counts[c] = cnt;
+    if (marker != ~0u) atomicMin(&F[f].first_marker, marker);
 }
 
 __global__ __launch_bounds__(256) void unstuff_copy_batch_kernel(const uint8_t* S, BatchFile* F, unsigned n_files, unsigned total_chunks,
@@ -463,26 +471,31 @@ __global__ __launch_bounds__(256) void unstuff_copy_batch_kernel(const uint8_t* 
     const unsigned c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= total_chunks) return;
     const unsigned f = file_of_chunk(F, n_files, c);
-    const size_t base = (size_t)F[f].chunk0 * CHUNK, n = F[f].n_bytes;
+    const size_t base = (size_t)F[f].chunk0 * CHUNK;
+    const size_t n = F[f].first_marker < F[f].n_bytes ? F[f].first_marker : F[f].n_bytes;       // the segment ends at its first marker
     const size_t b0 = (size_t)(c - F[f].chunk0) * CHUNK;
     const unsigned long long rb0 = removed_before[F[f].chunk0];
-    if (c == F[f].chunk0) {                          // the file's first chunk also publishes the file's totals and resets its flags
-        const unsigned removed = (unsigned)(removed_before[F[f].chunk0 + F[f].n_chunks] - rb0);
-        F[f].removed = removed;
-        F[f].n_sub = (unsigned)((((unsigned long long)n - removed) * 8 + SUBSEQ_BITS - 1) / SUBSEQ_BITS);
+    if (c == F[f].chunk0) {                          // the file's first chunk resets its flags (n_sub and removed stay 0 for an empty segment)
         F[f].changed[0] = F[f].changed[1] = F[f].changed[2] = F[f].changed[3] = 0;
         F[f].error = 0;
         F[f].last_bit = ~0ull;
     }
     if (b0 >= n) return;
-    uint8_t* dst = U + F[f].u_off + b0 - (removed_before[c] - rb0);
+    const unsigned long long rb = removed_before[c] - rb0;
+    uint8_t* dst = U + F[f].u_off + b0 - rb;
     uint8_t prev = b0 ? S[base + b0 - 1] : 0;
     const size_t e = b0 + CHUNK < n ? b0 + CHUNK : n;
+    unsigned cnt = 0;
     for (size_t i = b0; i < e; ++i) {
         const uint8_t v = S[base + i];
-        if (v == 0x00 && prev == 0xFF) { prev = 0x01; continue; }
+        if (v == 0x00 && prev == 0xFF) { prev = 0x01; ++cnt; continue; }
         *dst++ = v;
         prev = v;
+    }
+    if (e == n) {                                    // the chunk that holds the segment's last byte publishes the file's totals
+        const unsigned removed = (unsigned)rb + cnt;
+        F[f].removed = removed;
+        F[f].n_sub = (unsigned)((((unsigned long long)n - removed) * 8 + SUBSEQ_BITS - 1) / SUBSEQ_BITS);
     }
 }
 
@@ -781,7 +794,7 @@ static unsigned spec_overflow()
     return overflow;
 }
 
-hipError_t launch_unstuff_count_batch(const uint8_t* S, const BatchFile* F, unsigned n_files, unsigned total_chunks, uint32_t* counts, hipStream_t s)
+hipError_t launch_unstuff_count_batch(const uint8_t* S, BatchFile* F, unsigned n_files, unsigned total_chunks, uint32_t* counts, hipStream_t s)
 {
     if (!total_chunks) return hipSuccess;
     hipLaunchKernelGGL(unstuff_count_batch_kernel, dim3((total_chunks + 255) / 256), dim3(256), 0, s, S, F, n_files, total_chunks, counts);

@@ -156,12 +156,13 @@ struct jpezy_ctx {
     int h_last_passes = 0;         // synchronisation passes of the last jpezy_read_jpeg_gpu (0: the host decoder was used)
     size_t h_min_bytes = 64 << 10;    // scans shorter than this are decoded on the host: the GPU path has ~0.6 ms of fixed cost, the host decoder
                                       // takes ~11 us per KiB of a dense scan (tools/huffdec_threshold.py: they cross at 56 KiB; round 2: 3 ms, 256 KiB)
-    DevBuf b_scan, b_U, b_cnt, b_rb, b_state, b_prop, b_meta, b_coef, b_planes[2];   // jpezy_decode_jpeg_batch, batch form of the Huffman decoder
+    static constexpr int B_DEPTH = 3;   // slices of jpezy_decode_jpeg_batch whose planes may be on their way to the host while the next one is decoded
+    DevBuf b_scan, b_U, b_cnt, b_rb, b_state, b_prop, b_meta, b_coef, b_planes[B_DEPTH];   // jpezy_decode_jpeg_batch, batch form of the Huffman decoder
     int b_last_fast = 0;           // files of the last jpezy_decode_jpeg_batch call that took the batch form (diagnostic hook)
     uint8_t* b_pin = nullptr;      // pinned staging of the concatenated scans
     size_t b_pin_cap = 0;
-    uint8_t* b_stage[2] = { nullptr, nullptr };   // pinned staging of a slice's planes when the files are small (one download per slice)
-    size_t b_stage_cap[2] = { 0, 0 };
+    uint8_t* b_stage[B_DEPTH] = {};               // pinned staging of a slice's planes (one download per slice)
+    size_t b_stage_cap[B_DEPTH] = {};
     DevBuf e_hdr;                  // JFIF header bytes of the device-resident variant (cached per W, H, comment)
     jpezy_host::HostPipe pipe;     // staging ring of the streaming host-buffer entry points (jpezy_hostpipe.h)
     size_t host_chunk_bytes = 4u << 20;   // bytes of input per chunk of that pipeline (jpezy_ctx_set_host_chunk_bytes)
@@ -354,7 +355,8 @@ void jpezy_ctx_destroy(jpezy_ctx* c)
     if (c->e_pinned) (void)hipHostFree(c->e_pinned);
     if (c->b_pin) (void)hipHostFree(c->b_pin);
     for (uint8_t* q : c->b_stage) if (q) (void)hipHostFree(q);
-    for (DevBuf* b : { &c->b_scan, &c->b_U, &c->b_cnt, &c->b_rb, &c->b_state, &c->b_prop, &c->b_meta, &c->b_coef, &c->b_planes[0], &c->b_planes[1] }) b->release();
+    for (DevBuf* b : { &c->b_scan, &c->b_U, &c->b_cnt, &c->b_rb, &c->b_state, &c->b_prop, &c->b_meta, &c->b_coef }) b->release();
+    for (DevBuf& b : c->b_planes) b.release();
     for (DevBuf* b : { &c->e_tmp, &c->e_small, &c->e_U, &c->e_cnt, &c->e_out, &c->e_coef, &c->e_hdr, &c->e_status, &c->e_tt, &c->e_fft, &c->e_S, &c->e_base, &c->e_ft,
                        &c->dump_t, &c->h_scan, &c->h_U, &c->h_cnt, &c->h_off, &c->h_state, &c->h_setup, &c->h_small, &c->h_dc }) b->release();
     delete c;
@@ -1801,7 +1803,9 @@ try {
         // (two plane buffers): a 1080p file is 6.2 MB of planes, PCIe is what bounds a batch
         hipStream_t s_down = nullptr;
         HIP_TRY(hipStreamCreateWithFlags(&s_down, hipStreamNonBlocking));
-        std::thread drainer[2];
+        // (three plane buffers: with two, slice k waits for the planes of slice k - 2 to be delivered, and a slice of 1080p noise -- 1.7 ms of
+        // decoding, 2.8 ms of download and hand-out -- then takes (1.7 + 2.8) / 2 = 2.25 ms; with three the link's 1.8 ms is the bound)
+        std::thread drainer[jpezy_ctx::B_DEPTH];
         std::atomic<int> drain_err{ 0 };
         int slice_no = 0;
         auto join_all = [&] { for (auto& t : drainer) if (t.joinable()) t.join(); };
@@ -1835,7 +1839,7 @@ try {
             for (size_t s0 = 0; s0 < grp.size(); s0 += per_slice) {
                 std::vector<FastFile> slice(grp.begin() + s0, grp.begin() + std::min(grp.size(), s0 + per_slice));
                 std::vector<char> okv;
-                const int pb = slice_no & 1;
+                const int pb = slice_no % jpezy_ctx::B_DEPTH;
                 if (drainer[pb].joinable()) drainer[pb].join();             // the slice that used this plane buffer has been delivered
                 if (decode_slice_fast(c, slice, gi, gray, pb, okv) != JPEZY_OK) continue;      // (the per-file path reports what is wrong)
                 ++slice_no;

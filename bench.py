@@ -815,7 +815,7 @@ def run_rank(args):
         metric = {"encode": "Mpixels/s encode (FDCT+quant)", "decode": "Mpixels/s decode (dequant+IDCT)",
                   "encode+entropy": "Mpixels/s encode (FDCT+quant + GPU Huffman stage)",
                   "entropy+decode": "Mpixels/s decode (GPU Huffman decoder + dequant+IDCT)"}[direction]
-        kernel = {None: "f32::fdct_quant_f32_kernel", 1: "f32::fdct_quant_f32_kernel", 2: "f32::fdct_quant_mfma_kernel",
+        kernel = {None: "f32::fdct_quant_f32_kernel", 1: "f32::fdct_quant_f32_kernel",
                   0: "fdct_quant_kernel"}[args.variant] if direction.startswith("encode") else "dequant_idct_kernel"
         out = {
             "metric": metric,
@@ -835,8 +835,7 @@ def run_rank(args):
             # the arithmetic the path computes in: encode variant 1 = FP32 first level (FP64 only on guard-band hits),
             # encode variant 0 and decode = FP64; either way the results are the reference's FP64 results bit for bit
             "dtype": ("f32 luma + f64 chroma (tolerance mode, within 1 LSB)" if args.tolerant and direction == "decode" else
-                      "f64" if not direction.startswith("encode") or args.variant == 0 else
-                      "f16-limb MFMA (luma) + f32, f64 guard" if args.variant == 2 else "f32+f64 guard"),
+                      "f64" if not direction.startswith("encode") or args.variant == 0 else "f32+f64 guard"),
             "data": "synthetic",
             "config": {"workload": desc, "name": args.workload, "width": W, "height": H, "mode": "gray" if gray else "color",
                        "frames_per_step": fps, "ring_batches": ring, "pixels_per_step_per_gpu": px_per_step,
@@ -888,8 +887,7 @@ def parse_args(argv=None):
                     "(each repetition then is `W warm-up steps, K timed steps`, as the first one is); 0: once, before the first")
     ap.add_argument("--workload", default="encode4096", choices=sorted(WORKLOADS))
     ap.add_argument("--ring", type=int, default=0, help="distinct batches in the ring (0 = enough to exceed 512 MiB)")
-    ap.add_argument("--variant", type=int, default=None, help="encode kernel variant (0 FP64 butterflies, 1 FP32 first level [default], "
-                                                                 "2 = 1 with the luma transforms on the matrix pipe, opt-in)")
+    ap.add_argument("--variant", type=int, default=None, help="encode kernel variant (0 FP64 butterflies, 1 packed-FP32 first level [default])")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--batch", action="store_true", help="measure the configs[3] batch pipeline also at N = 1")
     ap.add_argument("--no-batch", action="store_true", help="N > 1: skip the configs[3] batch measurement")

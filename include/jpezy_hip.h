@@ -157,12 +157,9 @@ int jpezy_dequant_idct_generic_batch_dev(jpezy_ctx* ctx, const int16_t* d_coeffs
  * quad falls back to when it has more guard-band hits than its queue holds.  Exists so the rare branches have
  * parity tests. */
 void jpezy_ctx_set_force_exact(jpezy_ctx* ctx, int on);
-/* Encode kernel variant: 0 = FP64 butterflies (round-1 kernel), 1 = FP32 first level + FP64 second level +
- * reference-order third level (default), 2 = variant 1 with the luma transforms of a quad as one f16-limb matrix product on
- * the matrix pipe.  All produce identical coefficients in every test; they differ in speed -- and in what the exactness
- * rests on: variants 0 and 1 on proven error bounds, variant 2 on a MEASURED model of the undocumented accumulation inside
- * v_mfma_f32_16x16x32_f16 (opt-in for that reason): variant 2 is BEST-EFFORT parity -- identical on everything
- * tested (parity suite, adversarial near-integer soak), not proven. */
+/* Encode kernel variant: 0 = FP64 butterflies (round-1 kernel), 1 = packed-FP32 first level + FP64 second level +
+ * reference-order third level (default).  Two independently written kernels with proven error bounds that must agree bit
+ * for bit (tests/test_gpu_parity.py runs every case through both). */
 int jpezy_ctx_set_variant(jpezy_ctx* ctx, int variant);
 /*
  * Decode tolerance (opt-in; default 0).  BASELINE.json's north_star asks of the decoder "PPM output within +-1 LSB per

@@ -138,7 +138,7 @@ struct jpezy_ctx {
     bool dq_valid = false;
     int force_exact = 0;           // 0 normal, 1 everything through the reference-order path, 2 (f32 variant) through level 2,
                                    // 3 (f32 variant) through the per-lane evaluator of the queue-overflow case
-    int variant = 1;               // encode kernel: 0 = FP64 butterflies, 1 = FP32 first level (default), 2 = 1 with the luma transforms on the matrix pipe (opt-in)
+    int variant = 1;               // encode kernel: 0 = FP64 butterflies, 1 = FP32 first level (default)
 #ifdef JPEZY_TRACE
     unsigned long long* d_trace = nullptr;
 #endif
@@ -221,6 +221,8 @@ jpezy_ctx* jpezy_ctx_create(int device)
     std::vector<DeviceTables> hbuf(1); // 33 KB: off the stack, and private to this call (contexts may be created concurrently)
     DeviceTables& h = hbuf[0];
     const double S = JPEZY_INV_SQRT2;
+    int pos_of_row[8];                 // inverse of kPairRow: where the f32 kernel keeps coefficient row i of a block column
+    for (int pp = 0; pp < 8; ++pp) pos_of_row[kPairRow[pp]] = pp;
     for (int t = 0; t < 2; ++t) {
         for (int j = 0; j < 8; ++j)
             for (int i = 0; i < 8; ++i) {
@@ -237,7 +239,7 @@ jpezy_ctx* jpezy_ctx_create(int device)
                 const double cu = j ? 1.0 : S, cv = i ? 1.0 : S;
                 // the f32 kernel's 8-point transform leaves output 4 without its factor cos(pi/4); it is applied here
                 const double k4 = 0x1.6a09e667f3bcdp-1;      // cos(pi/4), correctly rounded
-                h.f32col[t][j].ks[i] = (float)(cu * cv / (4.0 * kQt[t][i * 8 + j]) * (i == 4 ? k4 : 1.0) * (j == 4 ? k4 : 1.0));
+                h.f32col[t][j].ks[pos_of_row[i]] = (float)(cu * cv / (4.0 * kQt[t][i * 8 + j]) * (i == 4 ? k4 : 1.0) * (j == 4 ? k4 : 1.0));
             }
     }
     for (int t = 0; t < 2; ++t)
@@ -249,7 +251,8 @@ jpezy_ctx* jpezy_ctx_create(int device)
     {
         // f32 kernel, level 1: |t_fp32 - t| <= gamma_13 * S_i * S_j * 128 * ks + 2^-23 * |t|max, S_u = sum_x |cos_u(x)|
         // (13 roundings at most on any input->output path of the two butterfly passes; ks rounded to FP32 and the
-        // product rounded: 2 * 2^-24 relative to |t| <= 128 * S_i * S_j * ks).  tests/test_f32_error_bound.py re-derives it.
+        // fused product-and-bias fma(F, ks, delta1) rounded once: 2 * 2^-24 relative to |t| + delta1 <= 128 * S_i * S_j * ks
+        // -- the few 1e-12 that delta1 adds to that rounding disappear in the 25 % margin).  tests/test_f32_error_bound.py re-derives it.
         static const double kCos[64] = JPEZY_COS_INIT;
         double S1[8];
         for (int u = 0; u < 8; ++u) {
@@ -267,54 +270,15 @@ jpezy_ctx* jpezy_ctx_create(int device)
                     const double bound = 13.0 * 0x1p-24 * amp + 0x1p-23 * amp;
                     if (bound > worst) worst = bound;
                 }
-                h.f32col[t][j].delta1 = (float)(1.25 * worst);
-            }
-    }
-    {
-        // encode variant 2: G as two f16 limbs in the fragment layout of v_mfma_f32_16x16x32_f16, and its guard bands.
-        // Error model (MEASURED, tools/ubench/mfma_f16_numerics.hip -- the accumulation of this instruction is undocumented):
-        // one instruction errs by at most 3.9 x 2^-24 x (|C| + sum |a b|); a coefficient is a chain of 4 instructions over
-        // sum |x G| <= amp = 128 S_i S_j cu cv / (4Q), the limb split drops at most 2^-22 amp.  bound = 40 x 2^-24 x amp
-        // (twice the measured worst case), guard band 1.25 x bound as for variant 1.
-        static const double kCos[64] = JPEZY_COS_INIT;
-        static const int kZz[64] = JPEZY_ZZ_INIT;
-        double S1[8];
-        for (int u = 0; u < 8; ++u) {
-            S1[u] = 0;
-            for (int x = 0; x < 8; ++x) S1[u] += std::fabs(kCos[u * 8 + x]);
-        }
-        auto f16_bits = [](double v) { const _Float16 hv = (_Float16)v; uint16_t b; std::memcpy(&b, &hv, 2); return b; };
-        auto f16_val = [](double v) { return (double)(_Float16)v; };
-        for (int limb = 0; limb < 2; ++limb)
-            for (int ks = 0; ks < 2; ++ks)
-                for (int mt = 0; mt < 4; ++mt)
-                    for (int l = 0; l < 64; ++l)
-                        for (int jj = 0; jj < 8; ++jj) {
-                            const int pz = 16 * mt + (l & 15), k = 32 * ks + 8 * (l >> 4) + jj, y = k >> 3, x = k & 7;
-                            const int nat = kZz[pz], i = nat >> 3, j = nat & 7;
-                            const double cu = j ? 1.0 : S, cv = i ? 1.0 : S;
-                            const double G = pz == 0 ? 1.0 : kCos[i * 8 + y] * kCos[j * 8 + x] * cu * cv / (4.0 * kQt[0][nat]);
-                            const double scaled = G * 4096.0, hi = f16_val(scaled);
-                            h.mfma_a[(limb * 2 + ks) * 4 + mt][l][jj] = limb ? f16_bits(scaled) : f16_bits(scaled - hi);
-                        }
-        for (int mt = 0; mt < 4; ++mt)
-            for (int g = 0; g < 4; ++g) {
-                double worst = 0;
-                for (int r = 0; r < 4; ++r) {
-                    const int pz = 16 * mt + 4 * g + r;
-                    if (pz == 0) continue;
-                    const int nat = kZz[pz], i = nat >> 3, j = nat & 7;
-                    const double cu = j ? 1.0 : S, cv = i ? 1.0 : S;
-                    const double amp = 128.0 * S1[i] * S1[j] * cu * cv / (4.0 * kQt[0][nat]);
-                    worst = std::max(worst, 40.0 * 0x1p-24 * amp);
-                }
-                h.mfma_delta[mt][g] = (float)(1.25 * worst);
+                const float d1 = (float)(1.25 * worst);
+                h.f32col[t][j].delta1[0] = h.f32col[t][j].delta1[1] = d1;
+                h.f32col[t][j].th = d1 + d1;               // exact: a doubling
             }
     }
     for (int j = 0; j < 8; ++j)
         for (int hh = 0; hh < 2; ++hh) {
             uint32_t w = 0;
-            for (int k = 0; k < 4; ++k) w |= (uint32_t)(2 * kZzInv[(4 * hh + k) * 8 + j]) << (8 * k);
+            for (int k = 0; k < 4; ++k) w |= (uint32_t)(2 * kZzInv[kPairRow[4 * hh + k] * 8 + j]) << (8 * k);
             for (int t = 0; t < 2; ++t) (hh ? h.f32col[t][j].zz_hi : h.f32col[t][j].zz_lo) = w;
         }
     bool ok = hipSetDevice(device) == hipSuccess;
@@ -389,7 +353,7 @@ int jpezy_ctx_set_decode_tolerance(jpezy_ctx* c, int on)
 int jpezy_ctx_set_variant(jpezy_ctx* c, int variant)
 {
     if (!c) return set_err(JPEZY_E_BADARG, "null context");
-    if (variant < 0 || variant > 2) return set_err(JPEZY_E_BADARG, "unknown kernel variant");
+    if (variant < 0 || variant > 1) return set_err(JPEZY_E_BADARG, "unknown kernel variant");
     c->variant = variant;
     return JPEZY_OK;
 }
@@ -434,12 +398,8 @@ int jpezy_fdct_quant_dev(jpezy_ctx* c, const uint8_t* d_r, const uint8_t* d_g, c
     p.dcq_chroma = c->d_tab->dcq[1];
     p.fallback_count = c->d_counter;
 #ifdef JPEZY_TRACE
-    if (!c->d_trace) HIP_TRY(hipMalloc((void**)&c->d_trace, sizeof(unsigned long long) * 4 * 65536));
+    if (!c->d_trace) HIP_TRY(hipMalloc((void**)&c->d_trace, sizeof(unsigned long long) * 13 * 65536));   // 4 words per wave + 9 phase stamps (JPEZY_TRACE=3)
     p.trace = c->d_trace;
-#endif
-#ifdef JPEZY_DEFER_PROBE
-    if (int rc = c->dump_t.reserve((size_t)64 * 4096 * 8)) return rc;
-    p.defer_list = c->dump_t.p;
 #endif
 #ifdef JPEZY_DUMP_T
     if (int rc = c->dump_t.reserve(p.coeffs_per_frame * (size_t)n_frames * sizeof(float))) return rc;
@@ -459,9 +419,7 @@ int jpezy_fdct_quant_dev(jpezy_ctx* c, const uint8_t* d_r, const uint8_t* d_g, c
         q.n_frames = n_frames - f0 < kMaxFramesPerLaunch ? n_frames - f0 : kMaxFramesPerLaunch;
         q.r += (size_t)f0 * plane_stride; q.g += (size_t)f0 * plane_stride; q.b += (size_t)f0 * plane_stride;
         q.coeffs += (size_t)f0 * p.coeffs_per_frame;
-        if (c->variant == 2)
-            HIP_TRY(launch_fdct_quant_mfma(q, gray != 0, c->force_exact, s));
-        else if (c->variant == 1)
+        if (c->variant == 1)
             HIP_TRY(launch_fdct_quant_f32(q, gray != 0, c->force_exact, s));
         else
             HIP_TRY(launch_fdct_quant(q, gray != 0, c->force_exact != 0, s));

@@ -12,16 +12,21 @@ namespace jpezy_dev {
 constexpr int QFRAC_BITS = 24;
 
 // Per (table, block column j) record of the f32 encode kernel: one 64-byte line per lane, three loads off one address.
+// The kernel's packed 8-point transform delivers its outputs as the pairs (0,4) (2,6) (1,3) (5,7): everything indexed by
+// the coefficient row is stored in that order, position p <-> row kPairRow[p].
+constexpr int kPairRow[8] = { 0, 4, 2, 6, 1, 3, 5, 7 };
 struct F32Column {
-    float ks[8];              // ks[i] = cu(j) * cv(i) / (4 * Q_t[i*8+j]) * cos(pi/4)^[i == 4] * cos(pi/4)^[j == 4]
-    // level-1 guard band: 1.25 x max over i of the worst-case FP32 error of t[i][j] = F[i][j] * ks[i]
-    // (jpezy_capi.hip; tests/test_f32_error_bound.py re-derives it)
-    float delta1;
-    // byte k of zz_lo / zz_hi = 2 * (zig-zag position of natural coefficient (i = k / 4 + k, j)): the byte offsets of one
-    // block column inside a staged block, packed so the kernel spends two registers on them instead of eight
+    float ks[8];              // ks[p] = cu(j) * cv(i) / (4 * Q_t[i*8+j]) * cos(pi/4)^[i == 4] * cos(pi/4)^[j == 4], i = kPairRow[p]
+    // level-1 guard band: 1.25 x max over i of the worst-case FP32 error of t[i][j] = F[i][j] * ks
+    // (jpezy_capi.hip; tests/test_f32_error_bound.py re-derives it); twice, as the addend pair of a v_pk_fma_f32
+    float delta1[2];
+    float th;                 // 2 * delta1: the kernel's test is fract(F * ks + delta1) < th
+    // byte p of zz_lo (p < 4) / zz_hi (p - 4) = 2 * (zig-zag position of natural coefficient (kPairRow[p], j)): the byte
+    // offsets of one block column inside a staged block, packed so the kernel spends two registers on them instead of eight
     uint32_t zz_lo, zz_hi;
-    uint32_t pad[5];
+    uint32_t pad[3];
 };
+static_assert(sizeof(F32Column) == 64, "one record per 64-byte line");
 
 // Device-resident tables built by the host at context creation (jpezy_capi.hip).
 struct DeviceTables {
@@ -35,14 +40,6 @@ struct DeviceTables {
     double rq_dc[2];          // 1 / Q_t[0]
     int qt[2][64];            // natural order
     double qinv[2][64];       // 1.0 / Q_t[k] (levels 2/3 of the f32 kernel)
-    // encode variant 2 (luma transforms on the matrix pipe): A operands of v_mfma_f32_16x16x32_f16.  Fragment
-    // f = (limb * 2 + kstep) * 4 + mtile (limb 0 = low); lane l holds the 8 f16 values
-    //   G[p = 16 mtile + (l & 15)][k = 32 kstep + 8 (l >> 4) + jj] * 2^12,  jj = 0..7,  k = 8 y + x,
-    //   G[p][k] = cos_i(y) cos_j(x) cu(j) cv(i) / (4 Q_luma[i*8+j]) for the coefficient (i, j) at zig-zag position p,
-    //   G[0][k] = 1 (the DC row delivers the exact sample sum for the dcq lookup); the samples are scaled by 2^-12.
-    uint16_t mfma_a[16][64][8];
-    // guard band of the four coefficients p = 16 mtile + 4 g .. + 3 a lane (g = lane >> 4) receives per row tile
-    float mfma_delta[4][4];
 };
 
 // The exact-path counter is sharded over COUNTER_SHARDS words: thousands of waves adding to ONE word serialise
@@ -69,12 +66,11 @@ struct EncParams {
     const signed char* dcq_chroma;   // DC lookups are scalar-base + 32-bit-offset loads
     unsigned long long* fallback_count;
     int W, H, mcu_cols, mcu_rows, quads_per_row, n_frames;
-    unsigned qpr_magic, qpr_shift;   // fast_div by quads_per_row (f32 kernel)
+    unsigned qpr_magic, qpr_shift;   // fast_div by quads_per_row
+    int groups_per_row;              // f32 kernel: workgroups per MCU row, and fast_div by it (set by its launcher)
+    unsigned gpr_magic, gpr_shift;
 #ifdef JPEZY_TRACE
     unsigned long long* trace;       // development builds only (tools/wave_trace.py): 4 words per wave
-#endif
-#ifdef JPEZY_DEFER_PROBE
-    void* defer_list;                // timing probe only (jpezy_kernels_f32.hip)
 #endif
 #ifdef JPEZY_DUMP_T
     float* dump_t;                   // development builds only (tools/check_level1_bound.py): the f32 kernel's level-1
@@ -115,8 +111,6 @@ hipError_t launch_fdct_quant(const EncParams& p, bool gray, bool force_exact, hi
 // coefficient through the reference-order chain, 2 every coefficient through the FP64 second level, 3 every quad
 // through the per-lane evaluator of the queue-overflow case.
 hipError_t launch_fdct_quant_f32(const EncParams& p, bool gray, int force, hipStream_t stream);
-// variant 2: variant 1 with the luma transforms on the matrix pipe (opt-in: measured error model, jpezy_kernels_f32.hip)
-hipError_t launch_fdct_quant_mfma(const EncParams& p, bool gray, int force, hipStream_t stream);
 // tolerant: luma in FP32 without guard band (samples within one of the reference's, jpezy_kernels.hip); chroma stays exact
 hipError_t launch_dequant_idct(const DecParams& p, bool gray, bool force_exact, bool tolerant, hipStream_t stream);
 

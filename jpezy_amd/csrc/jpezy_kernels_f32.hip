@@ -1,15 +1,20 @@
 // jpezy_kernels_f32.hip -- encode kernel, variant 1: three precision levels, same bits as the reference.
 //
 // Level 1 (every coefficient): colour conversion as an FP32 estimate with a guard band (below), separable 8-point
-//   butterflies in FP32.  A quantised coefficient t = F*cu*cv/(4Q) is accepted when it is further than delta1 from every
-//   non-zero integer; delta1 = 1.25 x the worst-case FP32 error of t over the coefficients of the lane's block column
-//   (DeviceTables::delta1, at most 1.06e-4 luma / 5.8e-5 chroma with the Annex-K tables; DESIGN.md "exactness").
+//   butterflies in FP32, written as PACKED FP32 instructions (v_pk_add/mul/fma_f32 with op_sel / neg modifiers: one
+//   instruction produces the sum AND the difference of a butterfly, or one product term for two outputs): 17
+//   instructions per 8-point transform instead of 34.  Every result is the same IEEE operation on the same operands as
+//   in the scalar form, so the error bound is the scalar form's.  A quantised coefficient t = F*cu*cv/(4Q) is accepted
+//   when it is further than delta1 from every non-zero integer; delta1 = 1.25 x the worst-case FP32 error of t over the
+//   coefficients of the lane's block column (DeviceTables::delta1, at most 1.06e-4 luma / 5.8e-5 chroma with the
+//   Annex-K tables; DESIGN.md "exactness").  The test is one-sided: the kernel forms t' = fma(F, ks, delta1) and looks
+//   at fract(t') < 2 delta1 (t within delta1 of an integer on either side <=> t' in [n, n + 2 delta1)).
 // Level 2 (guard-band hits, ~0.1 per quad): the 8 lanes holding the block's rows recompute that one coefficient in FP64
 //   from the integer samples; accepted when further than 1e-6 from every boundary m*Q, m != 0.
 // Level 3 (true boundary cases, ~0.2 per quad): the 64 terms are added in the reference's exact order.
-// Colour conversion: Y = trunc(fma chain in FP32) is exact unless the estimate is within 2^-12 of an integer, which
-//   happens exactly when 299R+587G+114B is a multiple of 1000 (1 pixel in 1000): there the reference's own FP64
-//   rounding decides and the FP64 formula is evaluated.  Same for Cb/Cr (multiples of 10000, 2^-14).
+// Colour conversion: Y = trunc(fma chain in FP32) is exact unless the exact value is an integer, which happens exactly
+//   when 299R+587G+114B is a multiple of 1000 (1 pixel in 1000): there the reference's own FP64 rounding decides and the
+//   FP64 formula is evaluated.  Same for Cb/Cr (multiples of 10000).  Also one-sided: the chain starts from a bias.
 // The DC coefficient is a sum of integers (exact in FP32) and is read from a table built in the reference's FP64 order.
 // Compiled with -ffp-contract=off; every FMA below is explicit.
 #include "jpezy_device.h"
@@ -25,23 +30,55 @@ __constant__ unsigned char c_zzinv[64] = JPEZY_ZZ_INV_INIT;
 #define K1 0x1.f6297cff75cb0p-1f
 #define K2 0x1.d906bcf328d46p-1f
 #define K3 0x1.a9b66290ea1a3p-1f
-#define K4 0x1.6a09e667f3bcdp-1f
 #define K5 0x1.1c73b39ae68c8p-1f
 #define K6 0x1.87de2a6aea963p-2f
 #define K7 0x1.8f8b83c69a60bp-3f
-#define FMAF(a, b, c) __builtin_fmaf((a), (b), (c))
 #ifndef JPEZY_F32_WAVES
 #define JPEZY_F32_WAVES 5
 #endif
+// instruction-selection switches (same arithmetic, same results): packed FP32 forms of the transform / of the fused
+// multiply-adds of the luma and chroma estimates / of the quantiser's product-and-bias
+#ifndef JPEZY_PK_TRANSFORM
+#define JPEZY_PK_TRANSFORM 1
+#endif
+#ifndef JPEZY_PK_LUMA
+#define JPEZY_PK_LUMA 1
+#endif
+#ifndef JPEZY_PK_CHROMA
+#define JPEZY_PK_CHROMA 1
+#endif
+#ifndef JPEZY_PK_QUANT
+#define JPEZY_PK_QUANT 1
+#endif
+#ifndef JPEZY_PIN_CONSTANTS
+#define JPEZY_PIN_CONSTANTS 1
+#endif
+
+typedef float f2 __attribute__((ext_vector_type(2)));   // an aligned VGPR (or SGPR) pair: the operand of v_pk_*_f32
+
+// Workgroup = EWPB waves = EWPB horizontally adjacent quads (4: 256 pixels x 16 rows).  The waves share nothing but the
+// pixel load: with JPEZY_COOP_LOAD the workgroup fetches its rows in whole 256-byte pieces (16 lanes per row, 4 rows per
+// wave instruction, LDS-DMA) and every wave then picks its quad's 64-byte row segments out of LDS; without it each wave
+// loads its own 64-byte segments of 16 rows per instruction straight into registers -- the shape the texture addresser
+// handles worst (tools/ubench/mem_pattern.hip: the kernel's memory pattern alone, no arithmetic, 22.4 us per 4096^2
+// frame in that shape against 19.4 us in whole 256-byte pieces).
+#ifndef JPEZY_EWPB
+#define JPEZY_EWPB 4
+#endif
+#ifndef JPEZY_COOP_LOAD
+#define JPEZY_COOP_LOAD 1
+#endif
+constexpr int EWPB = JPEZY_EWPB;
+static_assert(!JPEZY_COOP_LOAD || EWPB == 4, "the cooperative load is written for 4 waves: 4 x 4 rows of 256 bytes");
 
 // Level-1 guard bands on t = v/Q: DeviceTables::delta1[table][j].  Norm-wise bound of the FP32 error of F[i][j]:
 // gamma_13 * sum|cos_i| * sum|cos_j| * 128 (at most 13 roundings on any input->output path, u = 2^-24), times the
-// coefficient's scale factor cu*cv/(4Q), plus the roundings of ks and of the product.  tests/test_f32_error_bound.py
-// recomputes the table and measures errors 10x smaller on adversarial blocks.
+// coefficient's scale factor cu*cv/(4Q), plus the roundings of ks and of the fused product-and-bias.
+// tests/test_f32_error_bound.py recomputes the table and measures errors 10x smaller on adversarial blocks.
 constexpr double DELTA2 = 1e-6;             // level-2 guard band on v (FP64 tree-sum error < 1e-9)
 
 // LDS geometry in dwords (floats).  Column reads are ds_read_b32 over 32-lane groups (32 banks): conflict free
-// when the per-MCU stride == 8 (mod 32); row writes are ds_write_b128 over 8-lane groups: pitch 20 keeps them apart.
+// when the per-MCU stride == 8 (mod 32); row writes are 16-byte stores over 8-lane groups: pitch 20 keeps them apart.
 constexpr int Y_PITCH = 20;
 constexpr int Y_MCU = 16 * Y_PITCH + 8;     // 328
 constexpr int C_PITCH = 8;
@@ -73,22 +110,67 @@ __device__ __forceinline__ void wave_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// X[u] = sum_x x[x] * cos((2x+1)u*pi/16), except X[4], which is left WITHOUT its factor cos(pi/4): both passes'
-// factors are folded into the quantiser scale ks (F32Column::ks carries cos(pi/4) per index 4).  X[0] is the plain
-// sum (exact for integers below 2^24).
-__device__ __forceinline__ void fdct8f(const float* x, float* X)
+// ---- the 8-point transform in packed FP32 ----------------------------------------------------------------------------
+// VOP3P on 64-bit operands: op_sel[i] picks the dword of source i that feeds the LOW result, op_sel_hi[i] the one that
+// feeds the HIGH result, neg_lo/neg_hi negate a source per half.  Written as inline asm: hipcc folds neither the negations
+// nor the two-sided broadcasts into the modifiers (it builds the pairs with v_mov / v_xor instead).  The statements are
+// not volatile: the scheduler interleaves them like any other instruction.
+#define PK_ADD(d, a, b, MODS) asm("v_pk_add_f32 %0, %1, %2 " MODS : "=v"(d) : "v"(a), "v"(b))
+#define PK_MULS(d, a, k, MODS) asm("v_pk_mul_f32 %0, %1, %2 " MODS : "=v"(d) : "v"(a), "s"(k))
+#define PK_FMAS(d, a, k, c, MODS) asm("v_pk_fma_f32 %0, %1, %2, %3 " MODS : "=v"(d) : "v"(a), "s"(k), "v"(c))
+
+struct PkCos {             // five SGPR pairs; every other constant pair of the transform is one of these with its halves
+    f2 k13, k37, k51, k75, k26;   // swapped and / or negated by the modifiers
+};
+__device__ __forceinline__ PkCos pk_cos()
 {
-    const float s0 = x[0] + x[7], s1 = x[1] + x[6], s2 = x[2] + x[5], s3 = x[3] + x[4];
-    const float d0 = x[0] - x[7], d1 = x[1] - x[6], d2 = x[2] - x[5], d3 = x[3] - x[4];
+    return PkCos{ f2{ K1, K3 }, f2{ K3, K7 }, f2{ K5, K1 }, f2{ K7, K5 }, f2{ K2, K6 } };
+}
+
+// Output order of fdct8p as a sequence of eight values: position p holds coefficient pair_row(p).  Tiles, quantiser
+// records and zig-zag offsets are laid out in this order, so no value is ever moved between registers to re-pair it.
+__device__ __forceinline__ constexpr int pair_row(int p) { return (int)((0x75316240u >> (4 * p)) & 7u); }   // 0,4,2,6,1,3,5,7
+
+// A[k] = (x[k], x[7-k]), k = 0..3.  X[0] = (X0, X4), X[1] = (X2, X6), X[2] = (X1, X3), X[3] = (X5, X7) with
+// X[u] = sum_x x[x] * cos((2x+1)u*pi/16), except X4, which is left WITHOUT its factor cos(pi/4): both passes' factors
+// are folded into the quantiser scale ks (F32Column::ks carries cos(pi/4) per index 4).  X0 is the plain sum (exact
+// for integers below 2^24).  Operation for operation the scalar sequence
+//   s_k = x_k + x_{7-k}, d_k = x_k - x_{7-k}; e0 = s0 + s3, e2 = s0 - s3, e1 = s1 + s2, e3 = s1 - s2;
+//   X0 = e0 + e1, X4 = e0 - e1; X2 = fma(e3, K6, e2*K2), X6 = fma(-e3, K2, e2*K6);
+//   X1 = fma(d3,K7, fma(d2,K5, fma(d1,K3, d0*K1))), X3 = fma(-d3,K5, fma(-d2,K1, fma(-d1,K7, d0*K3))),
+//   X5 = fma(d3,K3, fma(d2,K7, fma(-d1,K1, d0*K5))), X7 = fma(-d3,K1, fma(d2,K3, fma(-d1,K5, d0*K7)))
+// (tests/test_f32_error_bound.py emulates exactly this), two results per instruction: 17 instructions.
+#define FMAF(a, b, c) __builtin_fmaf((a), (b), (c))
+__device__ __forceinline__ void fdct8p(const f2* A, f2* X, const PkCos& c)
+{
+#if !JPEZY_PK_TRANSFORM
+    const float s0 = A[0].x + A[0].y, s1 = A[1].x + A[1].y, s2 = A[2].x + A[2].y, s3 = A[3].x + A[3].y;
+    const float d0 = A[0].x - A[0].y, d1 = A[1].x - A[1].y, d2 = A[2].x - A[2].y, d3 = A[3].x - A[3].y;
     const float e0 = s0 + s3, e1 = s1 + s2, e2 = s0 - s3, e3 = s1 - s2;
-    X[0] = e0 + e1;
-    X[4] = e0 - e1;
-    X[2] = FMAF(e3, K6, e2 * K2);
-    X[6] = FMAF(-e3, K2, e2 * K6);
-    X[1] = FMAF(d3, K7, FMAF(d2, K5, FMAF(d1, K3, d0 * K1)));
-    X[3] = FMAF(-d3, K5, FMAF(-d2, K1, FMAF(-d1, K7, d0 * K3)));
-    X[5] = FMAF(d3, K3, FMAF(d2, K7, FMAF(-d1, K1, d0 * K5)));
-    X[7] = FMAF(-d3, K1, FMAF(d2, K3, FMAF(-d1, K5, d0 * K7)));
+    X[0] = f2{ e0 + e1, e0 - e1 };
+    X[1] = f2{ FMAF(e3, K6, e2 * K2), FMAF(-e3, K2, e2 * K6) };
+    X[2] = f2{ FMAF(d3, K7, FMAF(d2, K5, FMAF(d1, K3, d0 * K1))), FMAF(-d3, K5, FMAF(-d2, K1, FMAF(-d1, K7, d0 * K3))) };
+    X[3] = f2{ FMAF(d3, K3, FMAF(d2, K7, FMAF(-d1, K1, d0 * K5))), FMAF(-d3, K1, FMAF(d2, K3, FMAF(-d1, K5, d0 * K7))) };
+    return;
+#endif
+    f2 P0, P1, P2, P3, Q0, Q1, t, u;
+    PK_ADD(P0, A[0], A[0], "op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[0,1]");   // (s0, d0) = x0 +- x7
+    PK_ADD(P1, A[1], A[1], "op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[0,1]");
+    PK_ADD(P2, A[2], A[2], "op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[0,1]");
+    PK_ADD(P3, A[3], A[3], "op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[0,1]");
+    PK_ADD(Q0, P0, P3, "op_sel:[0,0] op_sel_hi:[0,0] neg_hi:[0,1]");       // (e0, e2) = s0 +- s3
+    PK_ADD(Q1, P1, P2, "op_sel:[0,0] op_sel_hi:[0,0] neg_hi:[0,1]");       // (e1, e3) = s1 +- s2
+    PK_ADD(X[0], Q0, Q1, "op_sel:[0,0] op_sel_hi:[0,0] neg_hi:[0,1]");     // (X0, X4) = e0 +- e1
+    PK_MULS(t, Q0, c.k26, "op_sel:[1,0] op_sel_hi:[1,1]");                                         // e2 * (K2, K6)
+    PK_FMAS(X[1], Q1, c.k26, t, "op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_hi:[0,1,0]");                // + e3 * (K6, -K2)
+    PK_MULS(t, P0, c.k13, "op_sel:[1,0] op_sel_hi:[1,1]");                                         // d0 * (K1, K3)
+    PK_FMAS(t, P1, c.k37, t, "op_sel:[1,0,0] op_sel_hi:[1,1,1] neg_hi:[0,1,0]");                   // + d1 * (K3, -K7)
+    PK_FMAS(t, P2, c.k51, t, "op_sel:[1,0,0] op_sel_hi:[1,1,1] neg_hi:[0,1,0]");                   // + d2 * (K5, -K1)
+    PK_FMAS(X[2], P3, c.k75, t, "op_sel:[1,0,0] op_sel_hi:[1,1,1] neg_hi:[0,1,0]");                // + d3 * (K7, -K5)
+    PK_MULS(u, P0, c.k75, "op_sel:[1,1] op_sel_hi:[1,0]");                                         // d0 * (K5, K7)
+    PK_FMAS(u, P1, c.k51, u, "op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0] neg_hi:[0,1,0]");    // + d1 * (-K1, -K5)
+    PK_FMAS(u, P2, c.k37, u, "op_sel:[1,1,0] op_sel_hi:[1,0,1]");                                  // + d2 * (K7, K3)
+    PK_FMAS(X[3], P3, c.k13, u, "op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_hi:[0,1,0]");                // + d3 * (K3, -K1)
 }
 
 // ---- colour conversion in the reference's exact FP64 order (ref encoder/jpezy_encoder.hpp:244-256) ----
@@ -112,107 +194,88 @@ __device__ __forceinline__ float ubyte(uint32_t w)
 }
 
 // Colour conversion, level 1.  Y = trunc(y*) with y* = (299R + 587G + 114B - 128000) / 1000.  The FP32 estimate
-//   t = fma(.114f, B, fma(.587f, G, fma(.299f, R, -128)))
-// is within 2.4e-5 of y* (three roundings of at most 2^-18 each, three constants rounded to FP32: 1.2e-5), and y* is
-// either an integer or at least 1e-3 away from one.  So trunc(t) = trunc(y*) unless t is within LUMA_EPS = 2^-12 of an
-// integer -- exactly the pixels with y* integral (1 in 1000), where the reference's own FP64 rounding sequence decides
-// and the FP64 formula is evaluated instead.  The test costs one subtraction and one add per pixel: d = t - trunc(t)
-// is exact, e = |d| - 1/2, near an integer <=> |e| > 1/2 - eps; the eight |e| of a half row are reduced with v_max3.
-// Chroma: c* = N / 10000 (N integer), FP32 error 1.7e-5, non-integral c* at least 1e-4 from an integer, CHROMA_EPS 2^-14.
-constexpr float LUMA_EPS = 0x1p-12f;
-constexpr float CHROMA_EPS = 0x1p-14f;
+//   t' = fma(.114f, B, fma(.587f, G, fma(.299f, R, -128 + eps)))
+// is within 2.4e-5 of y* + eps (three roundings of at most 2^-18 each, three constants rounded to FP32: 1.2e-5), and y* is
+// either an integer or at least 1e-3 away from one.  With eps = LUMA_EPS = 2^-12 (2.4e-4): y* integral <=> fract(t')
+// in [eps - 2.4e-5, eps + 2.4e-5], inside [0, 2 eps); y* not integral => fract(t') in [1e-3 + eps - 2.4e-5, 1 - 1e-3 +
+// eps + 2.4e-5], above 2 eps and below 1, and t' lies strictly between the same two integers as y*: trunc(t') =
+// trunc(y*).  So the test is ONE comparison of fract(t') (v_fract_f32: x - floor(x), exact, either sign) against 2 eps,
+// reduced over a half row with v_min3; the flagged pixels -- exactly the 1-in-1000 with y* integral, where the
+// reference's own FP64 rounding sequence decides -- evaluate the FP64 formula.  Chroma: c* = N / 10000 (N integer),
+// FP32 error 1.7e-5, non-integral c* at least 1e-4 from an integer; bias 3 * 2^-16 (4.6e-5), threshold 3 * 2^-15: margins
+// of 2.9e-5 / 3.7e-5 on the three inequalities.  tests/test_f32_error_bound.py checks all 2^24 RGB triples.
+constexpr float LUMA_EPS = 0x1p-12f, LUMA_TH = 0x1p-11f;
+constexpr float CHROMA_EPS = 0x1.8p-15f, CHROMA_TH = 0x1.8p-14f;
 
-template <int B>
-__device__ __forceinline__ float luma_px(uint32_t wr, uint32_t wg, uint32_t wb, float& e)
-{
-    const float t = FMAF(0.114f, ubyte<B>(wb), FMAF(0.587f, ubyte<B>(wg), FMAF(0.299f, ubyte<B>(wr), -128.f)));
-    const float Yt = __builtin_truncf(t);
-    e = __builtin_fabsf(t - Yt) - 0.5f;
-    return Yt;
-}
-// two pixels at once: the three FMAs of the estimate as v_pk_fma_f32 (2.2 ns for two results against 2 x 1.4)
-typedef float float2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+
+// two luma samples (byte B0 of the first word triple, byte B1 of the second): y = trunc(t'), fr = fract(t')
 template <int B0, int B1>
-__device__ __forceinline__ void luma_px2(uint32_t wr, uint32_t wg, uint32_t wb, float& y0, float& y1, float& e0, float& e1)
+__device__ __forceinline__ void luma_px2(uint32_t r0, uint32_t g0, uint32_t b0, uint32_t r1, uint32_t g1, uint32_t b1, f2& y, f2& fr)
 {
-#ifdef JPEZY_NO_PK
-    y0 = luma_px<B0>(wr, wg, wb, e0);
-    y1 = luma_px<B1>(wr, wg, wb, e1);
+    const f2 r = { ubyte<B0>(r0), ubyte<B1>(r1) }, g = { ubyte<B0>(g0), ubyte<B1>(g1) }, b = { ubyte<B0>(b0), ubyte<B1>(b1) };
+#if JPEZY_PK_LUMA
+    const f2 c1 = { 0.299f, 0.299f }, c2 = { 0.587f, 0.587f }, c3 = { 0.114f, 0.114f }, c0 = { -128.f + LUMA_EPS, -128.f + LUMA_EPS };
+    const f2 t = pk_fma(c3, b, pk_fma(c2, g, pk_fma(c1, r, c0)));
 #else
-    const float2_t r = { ubyte<B0>(wr), ubyte<B1>(wr) }, g = { ubyte<B0>(wg), ubyte<B1>(wg) }, b = { ubyte<B0>(wb), ubyte<B1>(wb) };
-    const float2_t c1 = { 0.299f, 0.299f }, c2 = { 0.587f, 0.587f }, c3 = { 0.114f, 0.114f }, c0 = { -128.f, -128.f };
-    const float2_t t = __builtin_elementwise_fma(c3, b, __builtin_elementwise_fma(c2, g, __builtin_elementwise_fma(c1, r, c0)));
-    y0 = __builtin_truncf(t.x);
-    y1 = __builtin_truncf(t.y);
-    e0 = __builtin_fabsf(t.x - y0) - 0.5f;
-    e1 = __builtin_fabsf(t.y - y1) - 0.5f;
+    const f2 t = { FMAF(0.114f, b.x, FMAF(0.587f, g.x, FMAF(0.299f, r.x, -128.f + LUMA_EPS))),
+                   FMAF(0.114f, b.y, FMAF(0.587f, g.y, FMAF(0.299f, r.y, -128.f + LUMA_EPS))) };
 #endif
+    y = f2{ __builtin_truncf(t.x), __builtin_truncf(t.y) };
+    fr = f2{ __builtin_amdgcn_fractf(t.x), __builtin_amdgcn_fractf(t.y) };
 }
 template <int B>
 __device__ __forceinline__ float luma_px_ref(uint32_t wr, uint32_t wg, uint32_t wb)
 {
     return (float)ref_y((double)ubyte<B>(wr), (double)ubyte<B>(wg), (double)ubyte<B>(wb));
 }
-__device__ __forceinline__ float absmax8(const float* e)
+__device__ __forceinline__ float min8(const f2* e)
 {
-    return __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(e[0]), __builtin_fabsf(e[1])),
-                                           __builtin_fmaxf(__builtin_fabsf(e[2]), __builtin_fabsf(e[3]))),
-                           __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(e[4]), __builtin_fabsf(e[5])),
-                                           __builtin_fmaxf(__builtin_fabsf(e[6]), __builtin_fabsf(e[7]))));
+    return __builtin_fminf(__builtin_fminf(__builtin_fminf(e[0].x, e[0].y), __builtin_fminf(e[1].x, e[1].y)),
+                           __builtin_fminf(__builtin_fminf(e[2].x, e[2].y), __builtin_fminf(e[3].x, e[3].y)));
 }
 
-// 8 luma samples of words wr[0..1] etc. (pixels 0..7 of a half row)
-__device__ __forceinline__ void luma8(const uint32_t* wr, const uint32_t* wg, const uint32_t* wb, float* y)
+// The 8 luma samples of one block row: words w[0..1] of the three planes (pixels 0..7) -> A[k] = (Y[k], Y[7-k]),
+// the input form of fdct8p.  Pixel k is byte k of word 0, pixel 7-k byte 3-k of word 1.
+__device__ __forceinline__ void luma8(const uint32_t* wr, const uint32_t* wg, const uint32_t* wb, f2* A)
 {
-    float e[8];
-    luma_px2<0, 1>(wr[0], wg[0], wb[0], y[0], y[1], e[0], e[1]);
-    luma_px2<2, 3>(wr[0], wg[0], wb[0], y[2], y[3], e[2], e[3]);
+    f2 e[4];
+    luma_px2<0, 3>(wr[0], wg[0], wb[0], wr[1], wg[1], wb[1], A[0], e[0]);
+    luma_px2<1, 2>(wr[0], wg[0], wb[0], wr[1], wg[1], wb[1], A[1], e[1]);
     __builtin_amdgcn_sched_barrier(0);   // 4 pixels at a time: more in flight only costs registers
-    luma_px2<0, 1>(wr[1], wg[1], wb[1], y[4], y[5], e[4], e[5]);
-    luma_px2<2, 3>(wr[1], wg[1], wb[1], y[6], y[7], e[6], e[7]);
-    constexpr float TH = 0.5f - LUMA_EPS;
+    luma_px2<2, 1>(wr[0], wg[0], wb[0], wr[1], wg[1], wb[1], A[2], e[2]);
+    luma_px2<3, 0>(wr[0], wg[0], wb[0], wr[1], wg[1], wb[1], A[3], e[3]);
 #ifdef JPEZY_ABL_NOCFLAG    // timing probe (wrong results, tools/ab_build.py): what the colour guard tests and their rare path cost
     if (false) {
 #else
-    if (wave_any(absmax8(e) > TH)) {   // one pixel in 1000: the reference's FP64 rounding decides
+    if (wave_any(min8(e) < LUMA_TH)) {   // one pixel in 1000: the reference's FP64 rounding decides
 #endif
         bool f;
-        f = __builtin_fabsf(e[0]) > TH; if (wave_any(f)) { if (f) y[0] = luma_px_ref<0>(wr[0], wg[0], wb[0]); }
-        f = __builtin_fabsf(e[1]) > TH; if (wave_any(f)) { if (f) y[1] = luma_px_ref<1>(wr[0], wg[0], wb[0]); }
-        f = __builtin_fabsf(e[2]) > TH; if (wave_any(f)) { if (f) y[2] = luma_px_ref<2>(wr[0], wg[0], wb[0]); }
-        f = __builtin_fabsf(e[3]) > TH; if (wave_any(f)) { if (f) y[3] = luma_px_ref<3>(wr[0], wg[0], wb[0]); }
-        f = __builtin_fabsf(e[4]) > TH; if (wave_any(f)) { if (f) y[4] = luma_px_ref<0>(wr[1], wg[1], wb[1]); }
-        f = __builtin_fabsf(e[5]) > TH; if (wave_any(f)) { if (f) y[5] = luma_px_ref<1>(wr[1], wg[1], wb[1]); }
-        f = __builtin_fabsf(e[6]) > TH; if (wave_any(f)) { if (f) y[6] = luma_px_ref<2>(wr[1], wg[1], wb[1]); }
-        f = __builtin_fabsf(e[7]) > TH; if (wave_any(f)) { if (f) y[7] = luma_px_ref<3>(wr[1], wg[1], wb[1]); }
+        f = e[0].x < LUMA_TH; if (wave_any(f)) { if (f) A[0].x = luma_px_ref<0>(wr[0], wg[0], wb[0]); }
+        f = e[1].x < LUMA_TH; if (wave_any(f)) { if (f) A[1].x = luma_px_ref<1>(wr[0], wg[0], wb[0]); }
+        f = e[2].x < LUMA_TH; if (wave_any(f)) { if (f) A[2].x = luma_px_ref<2>(wr[0], wg[0], wb[0]); }
+        f = e[3].x < LUMA_TH; if (wave_any(f)) { if (f) A[3].x = luma_px_ref<3>(wr[0], wg[0], wb[0]); }
+        f = e[3].y < LUMA_TH; if (wave_any(f)) { if (f) A[3].y = luma_px_ref<0>(wr[1], wg[1], wb[1]); }
+        f = e[2].y < LUMA_TH; if (wave_any(f)) { if (f) A[2].y = luma_px_ref<1>(wr[1], wg[1], wb[1]); }
+        f = e[1].y < LUMA_TH; if (wave_any(f)) { if (f) A[1].y = luma_px_ref<2>(wr[1], wg[1], wb[1]); }
+        f = e[0].y < LUMA_TH; if (wave_any(f)) { if (f) A[0].y = luma_px_ref<3>(wr[1], wg[1], wb[1]); }
     }
 }
 
-// chroma sample (Cb on even-row lanes, Cr on odd-row lanes) of pixel byte B; k1..k3: this lane's three coefficients
-template <int B>
-__device__ __forceinline__ float chroma_px(uint32_t wr, uint32_t wg, uint32_t wb, float k1, float k2, float k3, float& e)
-{
-    const float t = FMAF(k3, ubyte<B>(wb), FMAF(k2, ubyte<B>(wg), k1 * ubyte<B>(wr)));
-    const float Ct = __builtin_truncf(t);
-    e = __builtin_fabsf(t - Ct) - 0.5f;
-    return Ct;
-}
+// two chroma samples (Cb on even-row lanes, Cr on odd-row lanes); k1..k3: this lane's three coefficients
 template <int B0, int B1>
-__device__ __forceinline__ void chroma_px2(uint32_t wr0, uint32_t wg0, uint32_t wb0, uint32_t wr1, uint32_t wg1, uint32_t wb1, float k1,
-                                           float k2, float k3, float& c0, float& c1, float& e0, float& e1)
+__device__ __forceinline__ void chroma_px2(uint32_t r0, uint32_t g0, uint32_t b0, uint32_t r1, uint32_t g1, uint32_t b1, float k1,
+                                           float k2, float k3, f2& c, f2& fr)
 {
-#ifdef JPEZY_NO_PK
-    c0 = chroma_px<B0>(wr0, wg0, wb0, k1, k2, k3, e0);
-    c1 = chroma_px<B1>(wr1, wg1, wb1, k1, k2, k3, e1);
+    const f2 r = { ubyte<B0>(r0), ubyte<B1>(r1) }, g = { ubyte<B0>(g0), ubyte<B1>(g1) }, b = { ubyte<B0>(b0), ubyte<B1>(b1) };
+#if JPEZY_PK_CHROMA
+    const f2 q1 = { k1, k1 }, q2 = { k2, k2 }, q3 = { k3, k3 }, q0 = { CHROMA_EPS, CHROMA_EPS };
+    const f2 t = pk_fma(q3, b, pk_fma(q2, g, pk_fma(q1, r, q0)));
 #else
-    const float2_t r = { ubyte<B0>(wr0), ubyte<B1>(wr1) }, g = { ubyte<B0>(wg0), ubyte<B1>(wg1) }, b = { ubyte<B0>(wb0), ubyte<B1>(wb1) };
-    const float2_t q1 = { k1, k1 }, q2 = { k2, k2 }, q3 = { k3, k3 };
-    const float2_t t = __builtin_elementwise_fma(q3, b, __builtin_elementwise_fma(q2, g, q1 * r));
-    c0 = __builtin_truncf(t.x);
-    c1 = __builtin_truncf(t.y);
-    e0 = __builtin_fabsf(t.x - c0) - 0.5f;
-    e1 = __builtin_fabsf(t.y - c1) - 0.5f;
+    const f2 t = { FMAF(k3, b.x, FMAF(k2, g.x, FMAF(k1, r.x, CHROMA_EPS))), FMAF(k3, b.y, FMAF(k2, g.y, FMAF(k1, r.y, CHROMA_EPS))) };
 #endif
+    c = f2{ __builtin_truncf(t.x), __builtin_truncf(t.y) };
+    fr = f2{ __builtin_amdgcn_fractf(t.x), __builtin_amdgcn_fractf(t.y) };
 }
 template <int B>
 __device__ __forceinline__ float chroma_px_ref(uint32_t wr, uint32_t wg, uint32_t wb, bool odd)
@@ -273,93 +336,140 @@ __device__ __forceinline__ int resolve_coef(const float* w, bool part, int y, in
     return dct / Q;
 }
 
-// Quantised DC of a block from the exact table (DeviceTables::dcq): sum8 = this lane's column sum of eight samples
-// after the row pass -- on the j == 0 lane that is the block's integer sample sum (exact in FP32).  Issued right after
-// the column reads, long before the value is needed, so the L2 latency never sits on a wave's critical path; written
-// with fdct8f's own association so that the adds are shared with it.
-__device__ __forceinline__ int dc_lookup(const float* x, const signed char* dcq)
+// Quantised DC of a block from the exact table (DeviceTables::dcq): sum = the lane's X0 of the column pass -- on the
+// j == 0 lane that is the block's integer sample sum (exact in FP32).  Issued right after the first adds of the column
+// pass, long before the value is needed, so the L2 latency never sits on a wave's critical path.
+__device__ __forceinline__ int dc_lookup(float sum, const signed char* dcq)
 {
-    const float s0 = x[0] + x[7], s1 = x[1] + x[6], s2 = x[2] + x[5], s3 = x[3] + x[4];
-    const float sum8 = (s0 + s3) + (s1 + s2);
     // index = sum + 8192, formed in FP32 (exact) and clamped there (non-DC lanes carry arbitrary values); an
     // unsigned index keeps the lookup a scalar-base + 32-bit-offset load
-    const unsigned si = (unsigned)(__builtin_fminf(__builtin_fmaxf(sum8, -8192.f), 8192.f) + 8192.f);
+    const unsigned si = (unsigned)(__builtin_amdgcn_fmed3f(sum, -8192.f, 8192.f) + 8192.f);
     return dcq[si];
 }
 
-// quantise 8 coefficients of one block column.  Returns the smallest distance |t - rint(t)| over the column (the DC
-// lane skips i == 0): below DELTA1 some coefficient MAY need level 2 -- the caller then looks coefficient by coefficient
-// (a distance below DELTA1 around rint(t) == 0 is not a truncation boundary and is sorted out there, off the hot path).
-// dc: the block's quantised DC (dc_lookup below) -- only the j == 0 lane uses it.
-__device__ __forceinline__ float quant8f(const float* F, const float* ks, bool dc_lane, int dc, int* q)
-{
-    float d[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const float t = F[i] * ks[i];
-        q[i] = (int)t;                                                    // v_cvt_i32_f32 truncates toward zero
-        d[i] = __builtin_fabsf(t - __builtin_rintf(t));
-    }
-    if (dc_lane) { q[0] = dc; d[0] = 1.f; }
-    // v_min3_f32: 3.5 instructions for 8 values
-    return __builtin_fminf(__builtin_fminf(__builtin_fminf(d[0], d[1]), __builtin_fminf(d[2], d[3])),
-                           __builtin_fminf(__builtin_fminf(d[4], d[5]), __builtin_fminf(d[6], d[7])));
-}
-
-// base: LDS address of this lane's FIRST block; blk_off: byte offset of the block to write (an immediate after inlining)
-// delta1: this lane's level-1 guard band (DeviceTables::delta1, a function of the table and of the column j)
-__device__ __forceinline__ void quant_block_column(const float* F, const float* ks, float delta1, int j, int dc,
+// Quantise one block column and stage it in zig-zag order.  F: the column pass' four output pairs (order pair_row);
+// ks: the quantiser scales in the same order; dd = (delta1, delta1), th = 2 delta1; j: natural column; dc: the block's
+// quantised DC (only the j == 0 lane uses it); base: LDS address of this lane's FIRST block, blk_off the byte offset of
+// the block to write (an immediate after inlining); zz_lo/zz_hi: byte p = LDS byte offset of the coefficient at pair
+// position p inside a block (2 * zig-zag index < 128), packed so that the eight addresses cost two registers.
+__device__ __forceinline__ void quant_block_column(const f2* F, const f2* ks, f2 dd, float th, int j, int dc,
                                                    bool live, char* base, uint32_t zz_lo, uint32_t zz_hi, int blk_off, int blk,
                                                    unsigned* queue, bool force
+#ifdef JPEZY_ZZ_HOIST
+                                                   , const unsigned* zaddr
+#endif
 #ifdef JPEZY_DUMP_T
                                                    , float* dump_quad
 #endif
-                                                   , int qcap = QUEUE_CAP)
+                                                   )
 {
-#ifdef JPEZY_DUMP_T   // diagnostic build: the level-1 values exactly as the guard test sees them
+    // t' = F * ks + delta1 (one rounding); q = (int)t' truncates toward zero like the reference's integer division;
+    // fr = fract(t') < 2 delta1 <=> the unbiased t is within delta1 of an integer (header comment)
+    f2 t[4];
+#pragma unroll
+#if JPEZY_PK_QUANT
+    for (int p = 0; p < 4; ++p) t[p] = pk_fma(F[p], ks[p], dd);
+#else
+    for (int p = 0; p < 4; ++p) t[p] = f2{ FMAF(F[p].x, ks[p].x, dd.x), FMAF(F[p].y, ks[p].y, dd.x) };
+#endif
+#ifdef JPEZY_DUMP_T   // diagnostic build: the level-1 values as the guard test sees them, bias removed
     if (live && dump_quad)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) dump_quad[blk * 64 + i * 8 + j] = F[i] * ks[i];
+        for (int p = 0; p < 8; ++p) dump_quad[blk * 64 + pair_row(p) * 8 + j] = (p & 1 ? t[p >> 1].y : t[p >> 1].x) - dd.x;
 #endif
     int q[8];
-    const float dmin = quant8f(F, ks, j == 0, dc, q);
+    float fr[8];
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+        const float tp = p & 1 ? t[p >> 1].y : t[p >> 1].x;
+        q[p] = (int)tp;                                                   // v_cvt_i32_f32 truncates toward zero
+        fr[p] = __builtin_amdgcn_fractf(tp);
+    }
+    if (j == 0) { q[0] = dc; fr[0] = 1.f; }                               // the DC term: exact table, no guard band
+    // v_min3_f32: 3.5 instructions for 8 values
+    const float fmin = __builtin_fminf(__builtin_fminf(__builtin_fminf(fr[0], fr[1]), __builtin_fminf(fr[2], fr[3])),
+                                       __builtin_fminf(__builtin_fminf(fr[4], fr[5]), __builtin_fminf(fr[6], fr[7])));
 #ifdef JPEZY_ABL_NOGUARD    // timing probe (wrong results): what the coefficient guard tests and levels 2/3 cost
     const bool cand = false;
 #else
-    const bool cand = force || dmin < delta1;
+    const bool cand = force || fmin < th;
 #endif
     // rare on noisy content; flat content (exact zeros) enters and finds nothing to queue.  (Lanes that are not live
     // repeat the quad's last MCU, so leaving them in the vote changes nothing and keeps it a bare v_cmp + s_cmp.)
     if (wave_any(cand)) {
-        if (cand && live) {       // Fully unrolled: a runtime index into F/ks would send both arrays to scratch
+        if (cand && live) {       // Fully unrolled: a runtime index into the arrays would send them to scratch
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const float t = F[i] * ks[i];
-                bool f = __builtin_fabsf(t - __builtin_rintf(t)) < delta1 && __builtin_fabsf(t) > 0.5f && !(i == 0 && j == 0);
+            for (int p = 0; p < 8; ++p) {
+                const float tp = p & 1 ? t[p >> 1].y : t[p >> 1].x;
+                // near an integer other than zero (a band around zero is not a truncation boundary)
+                bool f = fr[p] < th && __builtin_fabsf(tp) > 0.5f && !(p == 0 && j == 0);
                 if (force) f = true;
                 if (f) {
                     const unsigned slot = atomicAdd(&queue[0], 1u);
-                    if (slot < (unsigned)qcap)
-                        reinterpret_cast<unsigned short*>(queue + 1)[slot] = (unsigned short)((blk << 6) | (i * 8 + j));
+                    if (slot < (unsigned)QUEUE_CAP)
+                        reinterpret_cast<unsigned short*>(queue + 1)[slot] = (unsigned short)((blk << 6) | (pair_row(p) * 8 + j));
                 }
             }
         }
     }
-    // zz_lo/zz_hi: byte i = LDS byte offset of natural coefficient (i, j) inside a block (2 * zig-zag index < 128);
-    // packed so that the eight addresses cost two registers (one SDWA add per store instead)
 #pragma unroll
-    for (int ii = 1; ii <= 8; ++ii) {      // i = 0 last: it waits for the DC lookup
-        const int i = ii & 7;
-        const uint32_t off = ((i < 4 ? zz_lo : zz_hi) >> (8 * (i & 3))) & 0xFFu;
-        *reinterpret_cast<int16_t*>(base + off + blk_off) = (int16_t)q[i];
+    for (int pp = 1; pp <= 8; ++pp) {      // p = 0 last: it waits for the DC lookup
+        const int p = pp & 7;
+#ifdef JPEZY_ZZ_HOIST
+        typedef __attribute__((address_space(3))) int16_t lds_i16;
+        *reinterpret_cast<lds_i16*>(zaddr[p] + (unsigned)blk_off) = (int16_t)q[p];
+#else
+        const uint32_t off = ((p < 4 ? zz_lo : zz_hi) >> (8 * (p & 3))) & 0xFFu;
+        *reinterpret_cast<int16_t*>(base + off + blk_off) = (int16_t)q[p];
+#endif
     }
 }
 
-template <bool GRAY, bool ALIGNED, int FORCE>
-__global__ __launch_bounds__(64 * WPB, JPEZY_F32_WAVES) void fdct_quant_f32_kernel(EncParams p)
+// One block column out of a row-major LDS tile, paired as fdct8p wants it: A[k] = (tile[k], tile[7-k]) (rows PITCH dwords
+// apart).  ds_read2_b32 takes two independent offsets, so every pair arrives in its register pair; left to itself hipcc
+// merges the eight loads by ADJACENT rows and re-pairs them with eight v_mov.  The wait is part of the statement (the
+// compiler does not count LDS loads issued by inline asm); "memory": not to be moved across the tile's barriers.
+template <int PITCH>
+__device__ __forceinline__ void lds_column(const float* src, f2* A)
 {
-    __shared__ __attribute__((aligned(16))) uint32_t lds_all[WPB][WAVE_LDS_DWORDS];
+    static_assert(7 * PITCH <= 255, "ds_read2_b32 offsets are 8-bit dword counts");
+    const unsigned addr = (unsigned)(uintptr_t)src;
+    asm volatile("ds_read2_b32 %0, %4 offset1:%8\n\t"
+                 "ds_read2_b32 %1, %4 offset0:%5 offset1:%9\n\t"
+                 "ds_read2_b32 %2, %4 offset0:%6 offset1:%10\n\t"
+                 "ds_read2_b32 %3, %4 offset0:%7 offset1:%11\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(A[0]), "=&v"(A[1]), "=&v"(A[2]), "=&v"(A[3])
+                 : "v"(addr), "n"(1 * PITCH), "n"(2 * PITCH), "n"(3 * PITCH), "n"(7 * PITCH), "n"(6 * PITCH), "n"(5 * PITCH), "n"(4 * PITCH)
+                 : "memory");
+}
+
+// natural-order view of a row of samples held as fdct8p wants them: x-th sample of A[k] = (s[k], s[7-k])
+__device__ __forceinline__ float pick(const f2* A, int x) { return x < 4 ? A[x].x : A[7 - x].y; }
+
+// development builds (-DJPEZY_TRACE=3, tools/wave_phases.py): the shader clock at the phase boundaries of every wave
+#if defined(JPEZY_TRACE) && JPEZY_TRACE >= 3
+#define PHASE_STAMP(k)                                                                                        \
+    do {                                                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ph[k]) : : "memory");                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+    } while (0)
+#else
+#define PHASE_STAMP(k) do { } while (0)
+#endif
+
+template <bool GRAY, bool ALIGNED, int FORCE>
+__global__ __launch_bounds__(64 * EWPB, JPEZY_F32_WAVES) void fdct_quant_f32_kernel(EncParams p)
+{
+#if defined(JPEZY_TRACE) && JPEZY_TRACE >= 3
+    unsigned long long ph[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+#endif
+    PHASE_STAMP(0);
+    __shared__ __attribute__((aligned(16))) uint32_t lds_all[EWPB][WAVE_LDS_DWORDS];
     constexpr int BPM = GRAY ? 4 : 6;
+    constexpr bool COOP = ALIGNED && JPEZY_COOP_LOAD;
+    static_assert(!COOP || 3 * 4096 <= EWPB * WAVE_LDS_DWORDS * 4, "the pixel staging area lies over the waves' slices");
 
     // WPB waves per workgroup; the wave index is made an SGPR so that everything derived from it (quad position, plane
     // and coefficient base addresses, the LDS slice) is computed once on the scalar unit
@@ -371,19 +481,20 @@ __global__ __launch_bounds__(64 * WPB, JPEZY_F32_WAVES) void fdct_quant_f32_kern
     // SIMD, 4 quads each, the next quad's pixels prefetched during the current one (109 VGPRs) -- 34.7 us: waves started
     // together stay in the same phase of the quad (all in the LDS transposes, then all in the butterflies), whereas waves
     // of one-quad launches arrive staggered and overlap each other's latency-bound phases.
-    const unsigned qidx = blockIdx.x * (unsigned)WPB + (unsigned)wave;          // quad index inside the frame
-    if (qidx >= (unsigned)(p.mcu_rows * p.quads_per_row)) return;     // wave-uniform
+    // grid x = groups of EWPB quads: groups_per_row = ceil(quads_per_row / EWPB) per MCU row (a group never straddles rows)
+    const int mcu_y = (int)fast_div(blockIdx.x, p.gpr_magic, p.gpr_shift);
+    const int gx = (int)blockIdx.x - mcu_y * p.groups_per_row;
+    const int quad_x = gx * EWPB + wave;
+    const bool has_quad = quad_x < p.quads_per_row;                    // wave-uniform
+    if (!COOP && !has_quad) return;
+    const unsigned qidx = (unsigned)(mcu_y * p.quads_per_row + quad_x);   // quad index inside the frame
     const int frame = (int)blockIdx.y;
-    const int mcu_y = (int)fast_div(qidx, p.qpr_magic, p.qpr_shift);
-    const int quad_x = (int)qidx - mcu_y * p.quads_per_row;
-
 #ifdef JPEZY_TRACE
     const unsigned long long tr_t0 = __builtin_amdgcn_s_memrealtime();
 #endif
     uint32_t* lds = lds_all[wave];
     float* ldsf = reinterpret_cast<float*>(lds);
-    unsigned* queue = lds + TILE_BYTES / 4;                            // [0] = count, then 16-bit entries
-    if (lane == 0) queue[0] = 0;
+    unsigned* queue = lds + TILE_BYTES / 4;                            // [0] = count, then 16-bit entries (cleared below, once the slice is private)
     const int row = lane >> 2, m = lane & 3;
     const int mcu_x_raw = quad_x * 4 + m;
     const bool live = mcu_x_raw < p.mcu_cols;
@@ -402,7 +513,38 @@ __global__ __launch_bounds__(64 * WPB, JPEZY_F32_WAVES) void fdct_quant_f32_kern
 
     // ---- 1. this lane's 16-pixel row segment of the three planes ----
     uint32_t R[4], G[4], B[4];
-    {
+    if (COOP) {
+        // The workgroup's 256 x 16 pixels of each plane go to LDS as [plane][row][16 pieces of 16 bytes]: wave w fetches rows
+        // 4w .. 4w+3, 16 lanes per row, with ONE LDS-DMA instruction per plane (the destination of an LDS-DMA is the wave's
+        // base + 16 x lane, so the image is lane-linear: 4 rows of 256 bytes).  Piece c of row r lies at position
+        // c ^ 4(r & 3) -- the swizzle is applied to the SOURCE address -- so that the 16-byte reads below, whose 16-lane
+        // groups span the rows {0,3,5,6} / {1,2,4,7} of one quad, hit 16 different bank groups.  The area lies over the
+        // waves' slices: a second barrier before anybody writes a slice.
+        char* stg = reinterpret_cast<char*>(&lds_all[0][0]);
+        {
+            const int lr = lane >> 4, cp = lane & 15;
+            const int y = min(mcu_y * 16 + wave * 4 + lr, H - 1);                     // edge replication, ref :101
+            const int piece = min(gx * 16 + (cp ^ (4 * lr)), p.mcu_cols - 1);         // W % 16 == 0 here: a piece is an MCU column
+            const unsigned off = (unsigned)y * (unsigned)W + (unsigned)piece * 16u;   // W, H <= 65535 (launcher): fits 32 bits
+            typedef __attribute__((address_space(1))) const void* gptr;
+            typedef __attribute__((address_space(3))) void* lptr;
+            __builtin_amdgcn_global_load_lds((gptr)(pr + off), (lptr)(stg + wave * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr)(pg + off), (lptr)(stg + 4096 + wave * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr)(pb + off), (lptr)(stg + 8192 + wave * 1024), 16, 0, 0);
+        }
+        __syncthreads();                                   // waits for this wave's DMA (vmcnt) and for the other three
+        {
+            const char* src = stg + row * 256 + (((wave * 4 + m) ^ (4 * (row & 3))) * 16);
+            const uint4 vr = *reinterpret_cast<const uint4*>(src);
+            const uint4 vg = *reinterpret_cast<const uint4*>(src + 4096);
+            const uint4 vb = *reinterpret_cast<const uint4*>(src + 8192);
+            R[0] = vr.x; R[1] = vr.y; R[2] = vr.z; R[3] = vr.w;
+            G[0] = vg.x; G[1] = vg.y; G[2] = vg.z; G[3] = vg.w;
+            B[0] = vb.x; B[1] = vb.y; B[2] = vb.z; B[3] = vb.w;
+        }
+        __syncthreads();                                   // staging area consumed: the slices are private from here on
+        if (!has_quad) return;
+    } else {
         const int y = min(mcu_y * 16 + row, H - 1);                   // edge replication, ref :101
         const unsigned rowoff = (unsigned)y * (unsigned)W;            // W, H <= 65535 (launcher): fits 32 bits
         if (ALIGNED) {
@@ -428,30 +570,38 @@ __global__ __launch_bounds__(64 * WPB, JPEZY_F32_WAVES) void fdct_quant_f32_kern
             }
         }
     }
+    if (lane == 0) queue[0] = 0;
 
 #ifdef JPEZY_TRACE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const unsigned long long tr_t1 = __builtin_amdgcn_s_memrealtime();
 #endif
+    PHASE_STAMP(1);
+    PkCos kc = pk_cos();
+#if JPEZY_PIN_CONSTANTS
+    // ten SGPRs for the whole kernel: left alone, hipcc rebuilds every constant pair with s_mov_b32 in front of the packed
+    // instruction that uses it (~100 scalar instructions per wave, which share the SIMD's issue with the vector ones)
+    asm volatile("" : "+s"(kc.k13), "+s"(kc.k37), "+s"(kc.k51), "+s"(kc.k75), "+s"(kc.k26));
+#endif
     // ---- 2. luma + row pass of the left and right block, into the transpose tile.  The integer samples stay in
-    //         registers as floats (ys: luma 16, cs: chroma 8) for the chroma row pass and the rare levels 2 and 3. ----
-    float ys[16], cs[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    //         registers as floats, paired as the transform wants them -- YL/YR[k] = (Y[k], Y[7-k]) of the left / right
+    //         block row, CS[k] likewise for the chroma row -- for the chroma row pass and the rare levels 2 and 3. ----
+    f2 YL[4], YR[4], CS[4] = { { 0, 0 }, { 0, 0 }, { 0, 0 }, { 0, 0 } };
     {
-        float4* dst = reinterpret_cast<float4*>(ldsf + m * Y_MCU + row * Y_PITCH);
-        float X[8];
-        luma8(R, G, B, ys);
-        fdct8f(ys, X);
-        dst[0] = make_float4(X[0], X[1], X[2], X[3]);
-        dst[1] = make_float4(X[4], X[5], X[6], X[7]);
-        luma8(R + 2, G + 2, B + 2, ys + 8);
-        fdct8f(ys + 8, X);
-        dst[2] = make_float4(X[0], X[1], X[2], X[3]);
-        dst[3] = make_float4(X[4], X[5], X[6], X[7]);
+        f2* dst = reinterpret_cast<f2*>(ldsf + m * Y_MCU + row * Y_PITCH);
+        f2 X[4];
+        luma8(R, G, B, YL);
+        fdct8p(YL, X, kc);
+        dst[0] = X[0]; dst[1] = X[1]; dst[2] = X[2]; dst[3] = X[3];
+        luma8(R + 2, G + 2, B + 2, YR);
+        fdct8p(YR, X, kc);
+        dst[4] = X[0]; dst[5] = X[1]; dst[6] = X[2]; dst[7] = X[3];
     }
-    __builtin_amdgcn_sched_barrier(0);   // keep the phases apart: the scheduler otherwise overlaps them and needs >80 VGPRs
+    __builtin_amdgcn_sched_barrier(0);   // keep the phases apart: the scheduler otherwise overlaps them and needs more VGPRs
+    PHASE_STAMP(2);
     // ---- 2b. chroma samples (top-left pixel of every 2x2, ref :134-142): the odd-row lane takes its even neighbour's
     //         pixels (DPP row_shr:4) and computes Cr, the even-row lane Cb.  Only the samples survive, so the raw
-    //         pixel registers die here. ----
+    //         pixel registers die here.  Sample s is pixel 2s: byte 2(s & 1) of word s >> 1. ----
     if (!GRAY) {
         const bool odd = (row & 1) != 0;
         uint32_t R2[4], G2[4], B2[4];
@@ -463,44 +613,41 @@ __global__ __launch_bounds__(64 * WPB, JPEZY_F32_WAVES) void fdct_quant_f32_kern
         }
         // (Cb, Cr) = (-.1687 R - .3313 G + .5 B), (.5 R - .4187 G - .0813 B)   (ref :249-256)
         const float k1 = odd ? 0.5f : -0.1687f, k2 = odd ? -0.4187f : -0.3313f, k3 = odd ? -0.0813f : 0.5f;
-        float cv[8], e[8];
-        chroma_px2<0, 2>(R2[0], G2[0], B2[0], R2[0], G2[0], B2[0], k1, k2, k3, cv[0], cv[1], e[0], e[1]);
-        chroma_px2<0, 2>(R2[1], G2[1], B2[1], R2[1], G2[1], B2[1], k1, k2, k3, cv[2], cv[3], e[2], e[3]);
+        f2 e[4];
+        chroma_px2<0, 2>(R2[0], G2[0], B2[0], R2[3], G2[3], B2[3], k1, k2, k3, CS[0], e[0]);    // samples 0, 7
+        chroma_px2<2, 0>(R2[0], G2[0], B2[0], R2[3], G2[3], B2[3], k1, k2, k3, CS[1], e[1]);    // samples 1, 6
         __builtin_amdgcn_sched_barrier(0);
-        chroma_px2<0, 2>(R2[2], G2[2], B2[2], R2[2], G2[2], B2[2], k1, k2, k3, cv[4], cv[5], e[4], e[5]);
-        chroma_px2<0, 2>(R2[3], G2[3], B2[3], R2[3], G2[3], B2[3], k1, k2, k3, cv[6], cv[7], e[6], e[7]);
-        constexpr float TH = 0.5f - CHROMA_EPS;
+        chroma_px2<0, 2>(R2[1], G2[1], B2[1], R2[2], G2[2], B2[2], k1, k2, k3, CS[2], e[2]);    // samples 2, 5
+        chroma_px2<2, 0>(R2[1], G2[1], B2[1], R2[2], G2[2], B2[2], k1, k2, k3, CS[3], e[3]);    // samples 3, 4
 #ifdef JPEZY_ABL_NOCFLAG
         if (false) {
 #else
-        if (wave_any(absmax8(e) > TH)) {
+        if (wave_any(min8(e) < CHROMA_TH)) {
 #endif
             bool f;
-            f = __builtin_fabsf(e[0]) > TH; if (wave_any(f)) { if (f) cv[0] = chroma_px_ref<0>(R2[0], G2[0], B2[0], odd); }
-            f = __builtin_fabsf(e[1]) > TH; if (wave_any(f)) { if (f) cv[1] = chroma_px_ref<2>(R2[0], G2[0], B2[0], odd); }
-            f = __builtin_fabsf(e[2]) > TH; if (wave_any(f)) { if (f) cv[2] = chroma_px_ref<0>(R2[1], G2[1], B2[1], odd); }
-            f = __builtin_fabsf(e[3]) > TH; if (wave_any(f)) { if (f) cv[3] = chroma_px_ref<2>(R2[1], G2[1], B2[1], odd); }
-            f = __builtin_fabsf(e[4]) > TH; if (wave_any(f)) { if (f) cv[4] = chroma_px_ref<0>(R2[2], G2[2], B2[2], odd); }
-            f = __builtin_fabsf(e[5]) > TH; if (wave_any(f)) { if (f) cv[5] = chroma_px_ref<2>(R2[2], G2[2], B2[2], odd); }
-            f = __builtin_fabsf(e[6]) > TH; if (wave_any(f)) { if (f) cv[6] = chroma_px_ref<0>(R2[3], G2[3], B2[3], odd); }
-            f = __builtin_fabsf(e[7]) > TH; if (wave_any(f)) { if (f) cv[7] = chroma_px_ref<2>(R2[3], G2[3], B2[3], odd); }
+            f = e[0].x < CHROMA_TH; if (wave_any(f)) { if (f) CS[0].x = chroma_px_ref<0>(R2[0], G2[0], B2[0], odd); }
+            f = e[1].x < CHROMA_TH; if (wave_any(f)) { if (f) CS[1].x = chroma_px_ref<2>(R2[0], G2[0], B2[0], odd); }
+            f = e[2].x < CHROMA_TH; if (wave_any(f)) { if (f) CS[2].x = chroma_px_ref<0>(R2[1], G2[1], B2[1], odd); }
+            f = e[3].x < CHROMA_TH; if (wave_any(f)) { if (f) CS[3].x = chroma_px_ref<2>(R2[1], G2[1], B2[1], odd); }
+            f = e[3].y < CHROMA_TH; if (wave_any(f)) { if (f) CS[3].y = chroma_px_ref<0>(R2[2], G2[2], B2[2], odd); }
+            f = e[2].y < CHROMA_TH; if (wave_any(f)) { if (f) CS[2].y = chroma_px_ref<2>(R2[2], G2[2], B2[2], odd); }
+            f = e[1].y < CHROMA_TH; if (wave_any(f)) { if (f) CS[1].y = chroma_px_ref<0>(R2[3], G2[3], B2[3], odd); }
+            f = e[0].y < CHROMA_TH; if (wave_any(f)) { if (f) CS[0].y = chroma_px_ref<2>(R2[3], G2[3], B2[3], odd); }
         }
-#pragma unroll
-        for (int k = 0; k < 8; ++k) cs[k] = cv[k];
     }
     __builtin_amdgcn_sched_barrier(0);
+    PHASE_STAMP(3);
     wave_sync();
 
-    // ---- 3+4. luma column pass, quantise + zig-zag into the staging area; top block first, then the bottom block
-    //           (kept apart so that only one block column of coefficients is live at a time) ----
-    const int cq = row, j = cq & 7;
+    // ---- 3+4. luma column pass, quantise + zig-zag into the staging area; top block first, then the bottom block.
+    //           The row pass stored its outputs in pair order, so the lane at position c of a block row handles the
+    //           natural column j = pair_row(c). ----
+    const int cq = row, j = (int)((0x75316240u >> (4 * (cq & 7))) & 7u);
     const unsigned ju = (unsigned)j;   // unsigned table indices: scalar base + 32-bit offset addressing
-    float col[16];
-    {
-        const float* src = ldsf + m * Y_MCU + cq;
-#pragma unroll
-        for (int rr = 0; rr < 16; ++rr) col[rr] = src[rr * Y_PITCH];
-    }
+    f2 TP[4], BT[4];
+    lds_column<Y_PITCH>(ldsf + m * Y_MCU + cq, TP);
+    lds_column<Y_PITCH>(ldsf + m * Y_MCU + cq + 8 * Y_PITCH, BT);
+    PHASE_STAMP(4);
     wave_sync();   // tile consumed; the slice is reused (chroma tile | staging)
     char* stage = reinterpret_cast<char*>(lds) + CT_BYTES;
     const int bx = cq >> 3;
@@ -509,70 +656,70 @@ __global__ __launch_bounds__(64 * WPB, JPEZY_F32_WAVES) void fdct_quant_f32_kern
     const uint32_t zz_lo = lcol->zz_lo, zz_hi = lcol->zz_hi;
     const signed char* dcq_l = p.dcq_luma;
     const signed char* dcq_c = p.dcq_chroma;
-    {
-        float ks[8];
+#ifdef JPEZY_ZZ_HOIST
+    // the eight staging addresses of this lane's block column, formed once (the three blocks are immediates apart); the
+    // empty asm keeps hipcc from re-deriving them at every store
+    unsigned zaddr[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) ks[i] = lcol->ks[i];
-        const float dl = lcol->delta1;
-        const int dc_top = dc_lookup(col, dcq_l), dc_bot = dc_lookup(col + 8, dcq_l);
+    for (int k = 0; k < 8; ++k) {
+        zaddr[k] = (unsigned)(uintptr_t)sbase + (((k < 4 ? zz_lo : zz_hi) >> (8 * (k & 3))) & 0xFFu);
+        asm("" : "+v"(zaddr[k]));
+    }
+#define ZZ_ARG , zaddr
+#else
+#define ZZ_ARG
+#endif
+    {
+        f2 ks[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) ks[k] = f2{ lcol->ks[2 * k], lcol->ks[2 * k + 1] };
+        const f2 dd = { lcol->delta1[0], lcol->delta1[1] };
+        const float th = lcol->th;
         {
-            float F[8];
-            fdct8f(col, F);
-            quant_block_column(F, ks, dl, j, dc_top, live, sbase, zz_lo, zz_hi, 0, m * BPM + bx, queue, FORCE != 0 DUMP_ARG);
+            f2 F[4];
+            fdct8p(TP, F, kc);
+            const int dc_top = dc_lookup(F[0].x, dcq_l);
+            quant_block_column(F, ks, dd, th, j, dc_top, live, sbase, zz_lo, zz_hi, 0, m * BPM + bx, queue, FORCE != 0 ZZ_ARG DUMP_ARG);
         }
         __builtin_amdgcn_sched_barrier(0);
         {
-            float F[8];
-            fdct8f(col + 8, F);
-            quant_block_column(F, ks, dl, j, dc_bot, live, sbase, zz_lo, zz_hi, 2 * STG_BLK, m * BPM + 2 + bx, queue, FORCE != 0 DUMP_ARG);
+            f2 F[4];
+            fdct8p(BT, F, kc);
+            const int dc_bot = dc_lookup(F[0].x, dcq_l);
+            quant_block_column(F, ks, dd, th, j, dc_bot, live, sbase, zz_lo, zz_hi, 2 * STG_BLK, m * BPM + 2 + bx, queue, FORCE != 0 ZZ_ARG DUMP_ARG);
         }
     }
 
     __builtin_amdgcn_sched_barrier(0);
+    PHASE_STAMP(5);
     // ---- 5. chroma row pass, transpose, column pass ----
     if (!GRAY) {
         const bool odd = (row & 1) != 0;
-        float cX[8];
-        fdct8f(cs, cX);
-        float4* dst = reinterpret_cast<float4*>(ldsf + m * C_MCU + (odd ? C_COMP : 0) + (row >> 1) * C_PITCH);
-        dst[0] = make_float4(cX[0], cX[1], cX[2], cX[3]);
-        dst[1] = make_float4(cX[4], cX[5], cX[6], cX[7]);
+        f2 cX[4];
+        fdct8p(CS, cX, kc);
+        f2* dst = reinterpret_cast<f2*>(ldsf + m * C_MCU + (odd ? C_COMP : 0) + (row >> 1) * C_PITCH);
+        dst[0] = cX[0]; dst[1] = cX[1]; dst[2] = cX[2]; dst[3] = cX[3];
         wave_sync();
 
-        float Fc[8];
+        f2 Fc[4];
         int dc_c;
         {
-            float col[8];
-            const float* src = ldsf + m * C_MCU + (cq >> 3) * C_COMP + j;
-#pragma unroll
-            for (int rr = 0; rr < 8; ++rr) col[rr] = src[rr * C_PITCH];
-            dc_c = dc_lookup(col, dcq_c);
-            fdct8f(col, Fc);
+            f2 col[4];
+            lds_column<C_PITCH>(ldsf + m * C_MCU + (cq >> 3) * C_COMP + (cq & 7), col);
+            fdct8p(col, Fc, kc);
+            dc_c = dc_lookup(Fc[0].x, dcq_c);
         }
-        float ks[8];
+        f2 ks[4];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) ks[i] = lcol[8].ks[i];
-        quant_block_column(Fc, ks, lcol[8].delta1, j, dc_c, live, sbase, zz_lo, zz_hi, 4 * STG_BLK, m * BPM + 4 + bx, queue, FORCE != 0 DUMP_ARG);
+        for (int k = 0; k < 4; ++k) ks[k] = f2{ lcol[8].ks[2 * k], lcol[8].ks[2 * k + 1] };
+        const f2 dd = { lcol[8].delta1[0], lcol[8].delta1[1] };
+        quant_block_column(Fc, ks, dd, lcol[8].th, j, dc_c, live, sbase, zz_lo, zz_hi, 4 * STG_BLK, m * BPM + 4 + bx, queue, FORCE != 0 ZZ_ARG DUMP_ARG);
     }
     wave_sync();
+    PHASE_STAMP(6);
 
     // ---- 5b. levels 2 and 3 for the queued coefficients (FORCE 1/2: every coefficient of the quad) ----
     const unsigned nq = queue[0];
-#ifdef JPEZY_DEFER_PROBE
-    // timing probe of "deferred resolves" (tools/experiments, WRONG RESULTS: nothing resolves the entries): the guard-band hits
-    // of the wave are appended to a global list sharded 64 ways (one returning atomic per wave with hits), levels 2/3 are not run
-    if (FORCE == 0) {
-        if (nq) {
-            unsigned long long* shard = p.fallback_count + 64 + (qidx & 63u) * 8u;          // probe: counters live in the fallback array
-            unsigned base = 0;
-            if (lane == 0) base = (unsigned)atomicAdd(shard, (unsigned long long)nq);
-            base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
-            uint2* list = reinterpret_cast<uint2*>(p.defer_list) + (size_t)(qidx & 63u) * 4096u;
-            for (unsigned e = lane; e < nq && e < (unsigned)QUEUE_CAP; e += 64)
-                list[(base + e) & 4095u] = make_uint2(qidx, reinterpret_cast<const unsigned short*>(queue + 1)[e]);
-        }
-    } else
-#endif
     if (FORCE == 3 || (FORCE == 0 && nq > (unsigned)QUEUE_CAP)) {
         // More guard-band hits than the queue holds (adversarial patterns; FORCE 3 exercises it): every lane evaluates
         // the 24 coefficients of its three block columns in the reference's order by itself.  The integer samples go
@@ -584,9 +731,12 @@ __global__ __launch_bounds__(64 * WPB, JPEZY_F32_WAVES) void fdct_quant_f32_kern
         {
             uint32_t w4[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
-                w4[k] = ((uint32_t)(int)ys[4 * k] & 0xFFu) | (((uint32_t)(int)ys[4 * k + 1] & 0xFFu) << 8) |
-                        (((uint32_t)(int)ys[4 * k + 2] & 0xFFu) << 16) | (((uint32_t)(int)ys[4 * k + 3] & 0xFFu) << 24);
+            for (int k = 0; k < 4; ++k) {
+                const f2* A = k < 2 ? YL : YR;
+                const int x0 = 4 * (k & 1);
+                w4[k] = ((uint32_t)(int)pick(A, x0) & 0xFFu) | (((uint32_t)(int)pick(A, x0 + 1) & 0xFFu) << 8) |
+                        (((uint32_t)(int)pick(A, x0 + 2) & 0xFFu) << 16) | (((uint32_t)(int)pick(A, x0 + 3) & 0xFFu) << 24);
+            }
             const int by = row >> 3, y = row & 7;
             uint32_t* d0 = reinterpret_cast<uint32_t*>(smp + ((m * 4 + by * 2) * 64 + y * 8));
             d0[0] = w4[0]; d0[1] = w4[1];
@@ -594,8 +744,8 @@ __global__ __launch_bounds__(64 * WPB, JPEZY_F32_WAVES) void fdct_quant_f32_kern
             if (!GRAY) {
 #pragma unroll
                 for (int k = 0; k < 2; ++k)
-                    w4[k] = ((uint32_t)(int)cs[4 * k] & 0xFFu) | (((uint32_t)(int)cs[4 * k + 1] & 0xFFu) << 8) |
-                            (((uint32_t)(int)cs[4 * k + 2] & 0xFFu) << 16) | (((uint32_t)(int)cs[4 * k + 3] & 0xFFu) << 24);
+                    w4[k] = ((uint32_t)(int)pick(CS, 4 * k) & 0xFFu) | (((uint32_t)(int)pick(CS, 4 * k + 1) & 0xFFu) << 8) |
+                            (((uint32_t)(int)pick(CS, 4 * k + 2) & 0xFFu) << 16) | (((uint32_t)(int)pick(CS, 4 * k + 3) & 0xFFu) << 24);
                 uint32_t* dc = reinterpret_cast<uint32_t*>(smp + 1024 + ((m * 2 + (row & 1)) * 64 + (row >> 1) * 8));
                 dc[0] = w4[0]; dc[1] = w4[1];
             }
@@ -643,16 +793,16 @@ __global__ __launch_bounds__(64 * WPB, JPEZY_F32_WAVES) void fdct_quant_f32_kern
                 if (em >= valid_mcus) continue;
                 const int ei = nat >> 3, ej = nat & 7;
                 const int comp = eb < 4 ? 0 : eb - 3, tbl = comp ? 1 : 0;
-                // the 8 lanes that hold the block's rows: luma block (by,bx): rows by*8+y, samples ys[8bx..]; chroma:
-                // Cb on even-row lanes, Cr on odd-row lanes, samples cs[]
-                const int by = (eb >> 1) & 1, bx = eb & 1;
+                // the 8 lanes that hold the block's rows: luma block (by, ebx): rows by*8+y, samples of the left / right
+                // block row; chroma: Cb on even-row lanes, Cr on odd-row lanes
+                const int by = (eb >> 1) & 1, ebx = eb & 1;
                 const int first = comp ? (comp == 2 ? 4 : 0) + em : by * 32 + em;
                 const int stride = comp ? 8 : 4;
                 const bool part = (m == em) && (comp ? ((row & 1) == (comp == 2)) : ((row >> 3) == by));
                 const int yrow = comp ? (row >> 1) : (row & 7);
                 float w[8];
 #pragma unroll
-                for (int k = 0; k < 8; ++k) w[k] = comp ? cs[k] : (bx ? ys[8 + k] : ys[k]);
+                for (int k = 0; k < 8; ++k) w[k] = comp ? pick(CS, k) : (ebx ? pick(YR, k) : pick(YL, k));
                 const int qv = resolve_coef<FORCE>(w, part, yrow, first, stride, ei, ej, tab->qt[tbl][nat], tab->qinv[tbl][nat]);
                 if (lane == 0) *reinterpret_cast<int16_t*>(stage + blk * STG_BLK + 2 * (int)c_zzinv[nat]) = (int16_t)qv;
                 ++done;
@@ -662,6 +812,7 @@ __global__ __launch_bounds__(64 * WPB, JPEZY_F32_WAVES) void fdct_quant_f32_kern
         }
     }
 
+    PHASE_STAMP(7);
 #ifdef JPEZY_TRACE
     const unsigned long long tr_t2 = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -695,414 +846,17 @@ __global__ __launch_bounds__(64 * WPB, JPEZY_F32_WAVES) void fdct_quant_f32_kern
             p.trace[qidx * 4 + 1] = ((tr_t1 - tr_t0) << 32) | (tr_t2 - tr_t0);
             p.trace[qidx * 4 + 2] = tr_t3 - tr_t0;
             p.trace[qidx * 4 + 3] = ((unsigned long long)xcc << 32) | hw;
+#if JPEZY_TRACE >= 3
+            unsigned long long t_end;
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_end) : : "memory");
+#pragma unroll
+            for (int k = 0; k < 8; ++k) p.trace[4 * 65536 + qidx * 9 + k] = ph[k];
+            p.trace[4 * 65536 + qidx * 9 + 8] = t_end;
+#endif
         }
     }
 #endif
 }
-
-// ======================================================================================================
-// Encode, variant 2: the luma transforms of a quad as one matrix product on the matrix pipe (v_mfma_f32_16x16x32_f16, the
-// constants as two f16 limbs), everything else as in variant 1 (colour conversion with its guard band, chroma butterflies on
-// the VALU, levels 2 and 3 for guard-band hits, exact DC table).  OPT-IN (jpezy_ctx_set_variant(ctx, 2)): the accumulation
-// inside an f16 MFMA is undocumented and is NOT a correctly rounded dot product (tools/ubench/mfma_f16_numerics.hip), so the
-// level-1 guard band of this variant rests on a measured error model (40 x 2^-24 x sum |x G| per coefficient: twice the worst
-// error seen per instruction, four instructions per chain, plus the limb truncation), not on a proof -- DESIGN.md section 4.
-// ======================================================================================================
-constexpr int WPB2 = 2;                           // waves per workgroup (as variant 1: the waves never talk to each other)
-constexpr int XB_PITCH = 144, XM_PITCH = 4 * XB_PITCH + 16;      // sample exchange tile: bytes per block / per MCU (f16 samples)
-constexpr int REGA_BYTES = (4 * XM_PITCH > CT_BYTES) ? 4 * XM_PITCH : CT_BYTES;     // exchange tile, later the chroma tile
-constexpr int TILE2_BYTES = REGA_BYTES + STG_BYTES;
-constexpr int QUEUE2_DWORDS = 64;
-constexpr int QUEUE2_CAP = 2 * (QUEUE2_DWORDS - 1);
-constexpr int WAVE2_LDS_DWORDS = TILE2_BYTES / 4 + QUEUE2_DWORDS;
-__constant__ unsigned char c_zz[64] = JPEZY_ZZ_INIT;
-
-template <bool GRAY, bool ALIGNED, int FORCE>
-__global__ __launch_bounds__(64 * WPB2, JPEZY_F32_WAVES) void fdct_quant_mfma_kernel(EncParams p)
-{
-    __shared__ __attribute__((aligned(16))) uint32_t lds_all[WPB2][WAVE2_LDS_DWORDS];
-    constexpr int BPM = GRAY ? 4 : 6;
-
-    // WPB waves per workgroup; the wave index is made an SGPR so that everything derived from it (quad position, plane
-    // and coefficient base addresses, the LDS slice) is computed once on the scalar unit
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    // The constant operands (16 KB, the same for every wave of the launch) are read from global memory, i.e. out of the L1/L2:
-    // a copy in LDS would have to be shared by ten waves to fit -- measured: workgroups of ten waves behind one barrier run in
-    // lockstep phases and release their slots only together, 40.9 us per 4096^2 frame.
-    const uint4* atab = reinterpret_cast<const uint4*>(p.tab->mfma_a);
-    const unsigned qidx = blockIdx.x * (unsigned)WPB2 + (unsigned)wave;          // quad index inside the frame
-    if (qidx >= (unsigned)(p.mcu_rows * p.quads_per_row)) return;     // wave-uniform
-    const int frame = (int)blockIdx.y;
-    const int mcu_y = (int)fast_div(qidx, p.qpr_magic, p.qpr_shift);
-    const int quad_x = (int)qidx - mcu_y * p.quads_per_row;
-
-#ifdef JPEZY_TRACE
-    const unsigned long long tr_t0 = __builtin_amdgcn_s_memrealtime();
-#endif
-    uint32_t* lds = lds_all[wave];
-    float* ldsf = reinterpret_cast<float*>(lds);
-    unsigned* queue = lds + TILE2_BYTES / 4;                            // [0] = count, then 16-bit entries
-    if (lane == 0) queue[0] = 0;
-    const int row = lane >> 2, m = lane & 3;
-    const int mcu_x_raw = quad_x * 4 + m;
-    const bool live = mcu_x_raw < p.mcu_cols;
-    const int mcu_x = live ? mcu_x_raw : p.mcu_cols - 1;
-    const int W = p.W, H = p.H;
-    const uint8_t* pr = p.r + (size_t)frame * p.plane_stride;
-    const uint8_t* pg = p.g + (size_t)frame * p.plane_stride;
-    const uint8_t* pb = p.b + (size_t)frame * p.plane_stride;
-    const DeviceTables* tab = p.tab;
-#ifdef JPEZY_DUMP_T
-    float* dump_quad = p.dump_t ? p.dump_t + (size_t)frame * p.coeffs_per_frame + ((size_t)mcu_y * p.mcu_cols + (size_t)quad_x * 4) * (BPM * 64) : nullptr;
-#define DUMP_ARG , dump_quad
-#else
-#define DUMP_ARG
-#endif
-
-    // ---- 1. this lane's 16-pixel row segment of the three planes ----
-    uint32_t R[4], G[4], B[4];
-    {
-        const int y = min(mcu_y * 16 + row, H - 1);                   // edge replication, ref :101
-        const unsigned rowoff = (unsigned)y * (unsigned)W;            // W, H <= 65535 (launcher): fits 32 bits
-        if (ALIGNED) {
-            const unsigned off = rowoff + (unsigned)mcu_x * 16u;
-            const uint4 vr = *reinterpret_cast<const uint4*>(pr + off);
-            const uint4 vg = *reinterpret_cast<const uint4*>(pg + off);
-            const uint4 vb = *reinterpret_cast<const uint4*>(pb + off);
-            R[0] = vr.x; R[1] = vr.y; R[2] = vr.z; R[3] = vr.w;
-            G[0] = vg.x; G[1] = vg.y; G[2] = vg.z; G[3] = vg.w;
-            B[0] = vb.x; B[1] = vb.y; B[2] = vb.z; B[3] = vb.w;
-        } else {
-#pragma unroll
-            for (int w4 = 0; w4 < 4; ++w4) {
-                uint32_t ar = 0, ag = 0, ab = 0;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int x = min(mcu_x * 16 + w4 * 4 + k, W - 1);   // ref :104
-                    ar |= (uint32_t)pr[rowoff + x] << (8 * k);
-                    ag |= (uint32_t)pg[rowoff + x] << (8 * k);
-                    ab |= (uint32_t)pb[rowoff + x] << (8 * k);
-                }
-                R[w4] = ar; G[w4] = ag; B[w4] = ab;
-            }
-        }
-    }
-
-#ifdef JPEZY_TRACE
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const unsigned long long tr_t1 = __builtin_amdgcn_s_memrealtime();
-#endif
-    // ---- 2'. luma samples (integers held as floats in ys[], also for the rare levels 2 and 3); packed to f16 (exact:
-    //          |Y| <= 128), scaled by 2^-12 (the constant operands carry 2^12 so that both of their f16 limbs are normal
-    //          numbers) and exchanged through LDS into the B-operand layout of v_mfma_f32_16x16x32_f16 ----
-    float ys[16], cs[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
-    {
-        luma8(R, G, B, ys);
-        luma8(R + 2, G + 2, B + 2, ys + 8);
-        typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
-        uint32_t hp[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            h2_t v = __builtin_bit_cast(h2_t, __builtin_amdgcn_cvt_pkrtz(ys[2 * q], ys[2 * q + 1]));
-            v = v * h2_t{ (_Float16)0x1p-12f, (_Float16)0x1p-12f };
-            hp[q] = __builtin_bit_cast(uint32_t, v);
-        }
-        char* xt = reinterpret_cast<char*>(lds) + m * XM_PITCH + ((row >> 3) * 2) * XB_PITCH + (row & 7) * 16;
-        *reinterpret_cast<uint4*>(xt) = make_uint4(hp[0], hp[1], hp[2], hp[3]);                 // row of the left block
-        *reinterpret_cast<uint4*>(xt + XB_PITCH) = make_uint4(hp[4], hp[5], hp[6], hp[7]);      // row of the right block
-    }
-    __builtin_amdgcn_sched_barrier(0);   // keep the phases apart: the scheduler otherwise overlaps them and needs >80 VGPRs
-    // ---- 2b. chroma samples (top-left pixel of every 2x2, ref :134-142): the odd-row lane takes its even neighbour's
-    //         pixels (DPP row_shr:4) and computes Cr, the even-row lane Cb.  Only the samples survive, so the raw
-    //         pixel registers die here. ----
-    if (!GRAY) {
-        const bool odd = (row & 1) != 0;
-        uint32_t R2[4], G2[4], B2[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            R2[k] = (uint32_t)__builtin_amdgcn_update_dpp((int)R[k], (int)R[k], 0x114, 0xF, 0xA, false);
-            G2[k] = (uint32_t)__builtin_amdgcn_update_dpp((int)G[k], (int)G[k], 0x114, 0xF, 0xA, false);
-            B2[k] = (uint32_t)__builtin_amdgcn_update_dpp((int)B[k], (int)B[k], 0x114, 0xF, 0xA, false);
-        }
-        // (Cb, Cr) = (-.1687 R - .3313 G + .5 B), (.5 R - .4187 G - .0813 B)   (ref :249-256)
-        const float k1 = odd ? 0.5f : -0.1687f, k2 = odd ? -0.4187f : -0.3313f, k3 = odd ? -0.0813f : 0.5f;
-        float cv[8], e[8];
-        chroma_px2<0, 2>(R2[0], G2[0], B2[0], R2[0], G2[0], B2[0], k1, k2, k3, cv[0], cv[1], e[0], e[1]);
-        chroma_px2<0, 2>(R2[1], G2[1], B2[1], R2[1], G2[1], B2[1], k1, k2, k3, cv[2], cv[3], e[2], e[3]);
-        __builtin_amdgcn_sched_barrier(0);
-        chroma_px2<0, 2>(R2[2], G2[2], B2[2], R2[2], G2[2], B2[2], k1, k2, k3, cv[4], cv[5], e[4], e[5]);
-        chroma_px2<0, 2>(R2[3], G2[3], B2[3], R2[3], G2[3], B2[3], k1, k2, k3, cv[6], cv[7], e[6], e[7]);
-        constexpr float TH = 0.5f - CHROMA_EPS;
-#ifdef JPEZY_ABL_NOCFLAG
-        if (false) {
-#else
-        if (wave_any(absmax8(e) > TH)) {
-#endif
-            bool f;
-            f = __builtin_fabsf(e[0]) > TH; if (wave_any(f)) { if (f) cv[0] = chroma_px_ref<0>(R2[0], G2[0], B2[0], odd); }
-            f = __builtin_fabsf(e[1]) > TH; if (wave_any(f)) { if (f) cv[1] = chroma_px_ref<2>(R2[0], G2[0], B2[0], odd); }
-            f = __builtin_fabsf(e[2]) > TH; if (wave_any(f)) { if (f) cv[2] = chroma_px_ref<0>(R2[1], G2[1], B2[1], odd); }
-            f = __builtin_fabsf(e[3]) > TH; if (wave_any(f)) { if (f) cv[3] = chroma_px_ref<2>(R2[1], G2[1], B2[1], odd); }
-            f = __builtin_fabsf(e[4]) > TH; if (wave_any(f)) { if (f) cv[4] = chroma_px_ref<0>(R2[2], G2[2], B2[2], odd); }
-            f = __builtin_fabsf(e[5]) > TH; if (wave_any(f)) { if (f) cv[5] = chroma_px_ref<2>(R2[2], G2[2], B2[2], odd); }
-            f = __builtin_fabsf(e[6]) > TH; if (wave_any(f)) { if (f) cv[6] = chroma_px_ref<0>(R2[3], G2[3], B2[3], odd); }
-            f = __builtin_fabsf(e[7]) > TH; if (wave_any(f)) { if (f) cv[7] = chroma_px_ref<2>(R2[3], G2[3], B2[3], odd); }
-        }
-#pragma unroll
-        for (int k = 0; k < 8; ++k) cs[k] = cv[k];
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    wave_sync();
-
-    // ---- 3'+4'. the sixteen luma blocks of the quad as ONE matrix product on the matrix pipe:
-    //   t[p][n] = sum_k G[p][k] * x[k][n],  p = zig-zag position, k = 8 y + x, n = 4 m + 2 by + bx the block,
-    //   G[p][k] = cos_i(y) cos_j(x) cu cv / (4 Q) (DeviceTables::mfma_a: two f16 limbs, rows in zig-zag order, quantiser folded
-    //   in; row 0 is all ones so that the DC comes out as the exact sample sum for the table lookup).
-    // 4 row tiles x 2 K steps x 2 limbs = 16 v_mfma_f32_16x16x32_f16; lane (g = lane >> 4, n = lane & 15) receives
-    // t[16 T + 4 g + r][n], r = 0..3: four consecutive zig-zag positions per tile -- one 8-byte store into the staging area.
-    const int cq = row, j = cq & 7;
-    const unsigned ju = (unsigned)j;
-    const int n_blk = lane & 15, g4 = lane >> 4;
-    typedef _Float16 h8_t __attribute__((ext_vector_type(8)));
-    typedef float f4_t __attribute__((ext_vector_type(4)));
-    h8_t bfrag[2];
-    {
-        const char* xr = reinterpret_cast<const char*>(lds) + (n_blk >> 2) * XM_PITCH + (n_blk & 3) * XB_PITCH + g4 * 16;
-        bfrag[0] = __builtin_bit_cast(h8_t, *reinterpret_cast<const uint4*>(xr));          // block row g (K step 0)
-        bfrag[1] = __builtin_bit_cast(h8_t, *reinterpret_cast<const uint4*>(xr + 64));     // block row g + 4 (K step 1)
-    }
-    wave_sync();   // exchange tile consumed; the slice is reused (chroma tile | staging)
-    char* stage = reinterpret_cast<char*>(lds) + REGA_BYTES;
-    const int bx = cq >> 3;
-    char* sbase = stage + (m * BPM + bx) * STG_BLK;
-    const F32Column* lcol = &tab->f32col[0][ju];
-    const uint32_t zz_lo = lcol->zz_lo, zz_hi = lcol->zz_hi;
-    const signed char* dcq_l = p.dcq_luma;
-    const signed char* dcq_c = p.dcq_chroma;
-    {
-        f4_t acc[4];
-#pragma unroll
-        for (int T = 0; T < 4; ++T) acc[T] = f4_t{ 0.f, 0.f, 0.f, 0.f };
-#pragma unroll
-        for (int hs = 0; hs < 4; ++hs) {            // limb (low first: the small terms are accumulated first), K step
-#pragma unroll
-            for (int T = 0; T < 4; ++T) {
-                const h8_t afrag = __builtin_bit_cast(h8_t, atab[(hs * 4 + T) * 64 + lane]);
-                acc[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(afrag, bfrag[hs & 1], acc[T], 0, 0, 0);
-            }
-        }
-        const int lblk = (n_blk >> 2) * BPM + (n_blk & 3);                       // block index inside the quad's staging area
-        const bool live_n = quad_x * 4 + (n_blk >> 2) < p.mcu_cols;
-        // the block's quantised DC from the exact table: the sample sum (row 0 of G is ones: exact) is this lane's acc[0][0]
-        int dcv = 0;
-        if (g4 == 0) {
-            const unsigned si = (unsigned)(__builtin_fminf(__builtin_fmaxf(acc[0][0], -8192.f), 8192.f) + 8192.f);
-            dcv = dcq_l[si];
-        }
-        bool cand = false;
-        int q[16];
-#pragma unroll
-        for (int T = 0; T < 4; ++T) {
-            float d[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float t = acc[T][r];
-                q[4 * T + r] = (int)t;
-                d[r] = __builtin_fabsf(t - __builtin_rintf(t));
-            }
-            if (T == 0 && g4 == 0) d[0] = 1.f;                                  // the DC never uses the guard band
-            const float dmin = __builtin_fminf(__builtin_fminf(d[0], d[1]), __builtin_fminf(d[2], d[3]));
-            cand = cand || dmin < tab->mfma_delta[T][g4];
-        }
-        if (g4 == 0) q[0] = dcv;
-#ifdef JPEZY_DUMP_T
-        if (live_n && dump_quad)
-#pragma unroll
-            for (int T = 0; T < 4; ++T)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) dump_quad[lblk * 64 + (int)c_zz[16 * T + 4 * g4 + r]] = acc[T][r];
-#endif
-        if (FORCE == 0 && wave_any(cand)) {
-            if (cand && live_n) {
-#pragma unroll
-                for (int T = 0; T < 4; ++T)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float t = acc[T][r];
-                        const int pz = 16 * T + 4 * g4 + r;
-                        if (__builtin_fabsf(t - __builtin_rintf(t)) < tab->mfma_delta[T][g4] && __builtin_fabsf(t) > 0.5f && pz != 0) {
-                            const unsigned slot = atomicAdd(&queue[0], 1u);
-                            if (slot < (unsigned)QUEUE2_CAP)
-                                reinterpret_cast<unsigned short*>(queue + 1)[slot] = (unsigned short)((lblk << 6) | (int)c_zz[pz]);
-                        }
-                    }
-            }
-        }
-#pragma unroll
-        for (int T = 0; T < 4; ++T) {
-            const uint32_t lo = ((uint32_t)q[4 * T] & 0xFFFFu) | ((uint32_t)q[4 * T + 1] << 16);
-            const uint32_t hi = ((uint32_t)q[4 * T + 2] & 0xFFFFu) | ((uint32_t)q[4 * T + 3] << 16);
-            *reinterpret_cast<uint2*>(stage + lblk * STG_BLK + 32 * T + 8 * g4) = make_uint2(lo, hi);
-        }
-    }
-
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- 5. chroma row pass, transpose, column pass ----
-    if (!GRAY) {
-        const bool odd = (row & 1) != 0;
-        float cX[8];
-        fdct8f(cs, cX);
-        float4* dst = reinterpret_cast<float4*>(ldsf + m * C_MCU + (odd ? C_COMP : 0) + (row >> 1) * C_PITCH);
-        dst[0] = make_float4(cX[0], cX[1], cX[2], cX[3]);
-        dst[1] = make_float4(cX[4], cX[5], cX[6], cX[7]);
-        wave_sync();
-
-        float Fc[8];
-        int dc_c;
-        {
-            float col[8];
-            const float* src = ldsf + m * C_MCU + (cq >> 3) * C_COMP + j;
-#pragma unroll
-            for (int rr = 0; rr < 8; ++rr) col[rr] = src[rr * C_PITCH];
-            dc_c = dc_lookup(col, dcq_c);
-            fdct8f(col, Fc);
-        }
-        float ks[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) ks[i] = lcol[8].ks[i];
-        quant_block_column(Fc, ks, lcol[8].delta1, j, dc_c, live, sbase, zz_lo, zz_hi, 4 * STG_BLK, m * BPM + 4 + bx, queue, FORCE != 0 DUMP_ARG, QUEUE2_CAP);
-    }
-    wave_sync();
-
-    // ---- 5b. levels 2 and 3 for the queued coefficients (FORCE 1/2: every coefficient of the quad) ----
-    const unsigned nq = queue[0];
-    if (FORCE == 3 || (FORCE == 0 && nq > (unsigned)QUEUE2_CAP)) {
-        // More guard-band hits than the queue holds (adversarial patterns; FORCE 3 exercises it): every lane evaluates
-        // the 24 coefficients of its three block columns in the reference's order by itself.  The integer samples go
-        // to LDS as bytes (1.5 KB in the dead chroma tile); a lane walks its block row by row, keeps the eight running
-        // sums of its column (i = 0..7) and adds (pic * cos[j][x]) * cos[i][y] for x = 0..7 to each -- for every i
-        // exactly the reference's sequence (ref :146-166).  ~3,500 FP64 operations per lane, 7 us per wave, against
-        // ~1 ms for the cooperative path on all 1536 coefficients.
-        signed char* smp = reinterpret_cast<signed char*>(lds);
-        {
-            uint32_t w4[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-                w4[k] = ((uint32_t)(int)ys[4 * k] & 0xFFu) | (((uint32_t)(int)ys[4 * k + 1] & 0xFFu) << 8) |
-                        (((uint32_t)(int)ys[4 * k + 2] & 0xFFu) << 16) | (((uint32_t)(int)ys[4 * k + 3] & 0xFFu) << 24);
-            const int by = row >> 3, y = row & 7;
-            uint32_t* d0 = reinterpret_cast<uint32_t*>(smp + ((m * 4 + by * 2) * 64 + y * 8));
-            d0[0] = w4[0]; d0[1] = w4[1];
-            d0[16] = w4[2]; d0[17] = w4[3];                      // the right block, 64 bytes further
-            if (!GRAY) {
-#pragma unroll
-                for (int k = 0; k < 2; ++k)
-                    w4[k] = ((uint32_t)(int)cs[4 * k] & 0xFFu) | (((uint32_t)(int)cs[4 * k + 1] & 0xFFu) << 8) |
-                            (((uint32_t)(int)cs[4 * k + 2] & 0xFFu) << 16) | (((uint32_t)(int)cs[4 * k + 3] & 0xFFu) << 24);
-                uint32_t* dc = reinterpret_cast<uint32_t*>(smp + 1024 + ((m * 2 + (row & 1)) * 64 + (row >> 1) * 8));
-                dc[0] = w4[0]; dc[1] = w4[1];
-            }
-        }
-        wave_sync();
-        const double cu = j ? 1.0 : JPEZY_S;
-#pragma unroll 1
-        for (int bc = 0; bc < (GRAY ? 2 : 3); ++bc) {
-            // block column bc of this lane: 0 top luma block, 1 bottom luma block, 2 chroma block (Cb / Cr by cq >> 3)
-            const int blk = m * BPM + (bc < 2 ? bc * 2 + bx : 4 + bx);
-            const signed char* src = bc < 2 ? smp + (m * 4 + bc * 2 + bx) * 64 : smp + 1024 + (m * 2 + bx) * 64;
-            const int tbl = bc < 2 ? 0 : 1;
-            double S[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
-#pragma unroll 1
-            for (int y = 0; y < 8; ++y) {
-                // x is not unrolled: this path must not raise the kernel's register count (it is never the hot one)
-#pragma unroll 1
-                for (int x = 0; x < 8; ++x) {
-                    const double px = (double)(int)src[y * 8 + x] * c_cos[j * 8 + x];
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) S[i] += px * c_cos[i * 8 + y];
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const double cv = i ? 1.0 : JPEZY_S;
-                const int dct = (int)(S[i] * cu * cv / 4);
-                const int qv = dct / tab->qt[tbl][i * 8 + j];
-                *reinterpret_cast<int16_t*>(stage + blk * STG_BLK + 2 * (int)c_zzinv[i * 8 + j]) = (int16_t)qv;
-            }
-        }
-        if (lane == 0) atomicAdd(p.fallback_count + (qidx & (COUNTER_SHARDS - 1)), (unsigned long long)(4 * BPM * 64));
-        wave_sync();
-    } else {
-        const bool all = FORCE != 0;
-        const unsigned total = all ? (unsigned)(4 * BPM * 64) : nq;
-        if (total) {
-            const int valid_mcus = min(4, p.mcu_cols - quad_x * 4);
-            unsigned done = 0;
-#pragma unroll 1
-            for (unsigned e = 0; e < total; ++e) {
-                const unsigned code = all ? e : reinterpret_cast<const unsigned short*>(queue + 1)[e];
-                const int blk = __builtin_amdgcn_readfirstlane((int)(code >> 6)), nat = __builtin_amdgcn_readfirstlane((int)(code & 63));
-                const int em = blk / BPM, eb = blk - em * BPM;
-                if (em >= valid_mcus) continue;
-                const int ei = nat >> 3, ej = nat & 7;
-                const int comp = eb < 4 ? 0 : eb - 3, tbl = comp ? 1 : 0;
-                // the 8 lanes that hold the block's rows: luma block (by,bx): rows by*8+y, samples ys[8bx..]; chroma:
-                // Cb on even-row lanes, Cr on odd-row lanes, samples cs[]
-                const int by = (eb >> 1) & 1, bx = eb & 1;
-                const int first = comp ? (comp == 2 ? 4 : 0) + em : by * 32 + em;
-                const int stride = comp ? 8 : 4;
-                const bool part = (m == em) && (comp ? ((row & 1) == (comp == 2)) : ((row >> 3) == by));
-                const int yrow = comp ? (row >> 1) : (row & 7);
-                float w[8];
-#pragma unroll
-                for (int k = 0; k < 8; ++k) w[k] = comp ? cs[k] : (bx ? ys[8 + k] : ys[k]);
-                const int qv = resolve_coef<FORCE>(w, part, yrow, first, stride, ei, ej, tab->qt[tbl][nat], tab->qinv[tbl][nat]);
-                if (lane == 0) *reinterpret_cast<int16_t*>(stage + blk * STG_BLK + 2 * (int)c_zzinv[nat]) = (int16_t)qv;
-                ++done;
-            }
-            if (lane == 0 && done) atomicAdd(p.fallback_count + (qidx & (COUNTER_SHARDS - 1)), (unsigned long long)done);
-            wave_sync();
-        }
-    }
-
-#ifdef JPEZY_TRACE
-    const unsigned long long tr_t2 = __builtin_amdgcn_s_memrealtime();
-#endif
-    // ---- 6. coalesced store of the quad's coefficients ----
-    {
-        const int valid_chunks = min(4, p.mcu_cols - quad_x * 4) * BPM * 8;         // 16-byte chunks
-        int16_t* gbase = p.coeffs + (size_t)frame * p.coeffs_per_frame +
-                         ((size_t)mcu_y * p.mcu_cols + (size_t)quad_x * 4) * (BPM * 64);
-        uint4* g4 = reinterpret_cast<uint4*>(gbase);
-#pragma unroll
-        for (int k = 0; k < BPM * 128 * 4 / 1024; ++k) {
-            const int c = k * 64 + lane;
-            if (c < valid_chunks) {
-                // streamed out, never re-read by this kernel: a non-temporal store leaves less dirty data in the L2s
-                // for the end-of-kernel write-back (measured: 2 us per 4096^2 frame)
-                const uint4 v = *reinterpret_cast<const uint4*>(stage + (c >> 3) * STG_BLK + (c & 7) * 16);
-                typedef unsigned v4u __attribute__((ext_vector_type(4)));
-                __builtin_nontemporal_store(v4u{v.x, v.y, v.z, v.w}, reinterpret_cast<v4u*>(g4 + c));
-            }
-        }
-    }
-#ifdef JPEZY_TRACE
-    if (frame == 0 && qidx < 65536u) {
-#if JPEZY_TRACE > 1
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-        const unsigned long long tr_t3 = __builtin_amdgcn_s_memrealtime();
-        const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
-        if (lane == 0) {
-            p.trace[qidx * 4 + 0] = tr_t0;
-            p.trace[qidx * 4 + 1] = ((tr_t1 - tr_t0) << 32) | (tr_t2 - tr_t0);
-            p.trace[qidx * 4 + 2] = tr_t3 - tr_t0;
-            p.trace[qidx * 4 + 3] = ((unsigned long long)xcc << 32) | hw;
-        }
-    }
-#endif
-}
-
 
 }  // namespace f32
 
@@ -1110,47 +864,24 @@ template <bool GRAY, bool ALIGNED>
 static void enc_f32_launch2(const EncParams& p, int force, dim3 grid, hipStream_t s)
 {
     if (force == 1)
-        hipLaunchKernelGGL((f32::fdct_quant_f32_kernel<GRAY, ALIGNED, 1>), grid, dim3(64 * WPB), 0, s, p);
+        hipLaunchKernelGGL((f32::fdct_quant_f32_kernel<GRAY, ALIGNED, 1>), grid, dim3(64 * f32::EWPB), 0, s, p);
     else if (force == 2)
-        hipLaunchKernelGGL((f32::fdct_quant_f32_kernel<GRAY, ALIGNED, 2>), grid, dim3(64 * WPB), 0, s, p);
+        hipLaunchKernelGGL((f32::fdct_quant_f32_kernel<GRAY, ALIGNED, 2>), grid, dim3(64 * f32::EWPB), 0, s, p);
     else if (force == 3)
-        hipLaunchKernelGGL((f32::fdct_quant_f32_kernel<GRAY, ALIGNED, 3>), grid, dim3(64 * WPB), 0, s, p);
+        hipLaunchKernelGGL((f32::fdct_quant_f32_kernel<GRAY, ALIGNED, 3>), grid, dim3(64 * f32::EWPB), 0, s, p);
     else
-        hipLaunchKernelGGL((f32::fdct_quant_f32_kernel<GRAY, ALIGNED, 0>), grid, dim3(64 * WPB), 0, s, p);
+        hipLaunchKernelGGL((f32::fdct_quant_f32_kernel<GRAY, ALIGNED, 0>), grid, dim3(64 * f32::EWPB), 0, s, p);
 }
 
-template <bool GRAY, bool ALIGNED>
-static void enc_mfma_launch2(const EncParams& p, int force, dim3 grid, hipStream_t s)
+hipError_t launch_fdct_quant_f32(const EncParams& p0, bool gray, int force, hipStream_t stream)
 {
-    if (force == 1)
-        hipLaunchKernelGGL((f32::fdct_quant_mfma_kernel<GRAY, ALIGNED, 1>), grid, dim3(64 * f32::WPB2), 0, s, p);
-    else if (force == 2)
-        hipLaunchKernelGGL((f32::fdct_quant_mfma_kernel<GRAY, ALIGNED, 2>), grid, dim3(64 * f32::WPB2), 0, s, p);
-    else if (force == 3)
-        hipLaunchKernelGGL((f32::fdct_quant_mfma_kernel<GRAY, ALIGNED, 3>), grid, dim3(64 * f32::WPB2), 0, s, p);
-    else
-        hipLaunchKernelGGL((f32::fdct_quant_mfma_kernel<GRAY, ALIGNED, 0>), grid, dim3(64 * f32::WPB2), 0, s, p);
-}
-
-hipError_t launch_fdct_quant_mfma(const EncParams& p, bool gray, int force, hipStream_t stream)
-{
-    const long quads = (long)p.mcu_rows * p.quads_per_row;
-    if (quads <= 0 || p.n_frames <= 0) return hipSuccess;
-    if (p.n_frames > 65535) return hipErrorInvalidValue;
-    const dim3 grid((unsigned)((quads + f32::WPB2 - 1) / f32::WPB2), (unsigned)p.n_frames);
-    const bool al = (p.W % 16 == 0) && (p.plane_stride % 16 == 0) &&
-                    (((uintptr_t)p.r | (uintptr_t)p.g | (uintptr_t)p.b) % 16 == 0);
-    if (gray) { if (al) enc_mfma_launch2<true, true>(p, force, grid, stream); else enc_mfma_launch2<true, false>(p, force, grid, stream); }
-    else      { if (al) enc_mfma_launch2<false, true>(p, force, grid, stream); else enc_mfma_launch2<false, false>(p, force, grid, stream); }
-    return hipGetLastError();
-}
-
-hipError_t launch_fdct_quant_f32(const EncParams& p, bool gray, int force, hipStream_t stream)
-{
-    const long quads = (long)p.mcu_rows * p.quads_per_row;
-    if (quads <= 0 || p.n_frames <= 0) return hipSuccess;
+    EncParams p = p0;
+    p.groups_per_row = (p.quads_per_row + f32::EWPB - 1) / f32::EWPB;
+    const long groups = (long)p.mcu_rows * p.groups_per_row;
+    if (groups <= 0 || p.n_frames <= 0) return hipSuccess;
     if (p.n_frames > 65535) return hipErrorInvalidValue;               // grid.y limit; callers chunk larger batches
-    const dim3 grid((unsigned)((quads + WPB - 1) / WPB), (unsigned)p.n_frames);
+    fast_div_setup((unsigned)p.groups_per_row, &p.gpr_magic, &p.gpr_shift);
+    const dim3 grid((unsigned)groups, (unsigned)p.n_frames);
     const bool al = (p.W % 16 == 0) && (p.plane_stride % 16 == 0) &&
                     (((uintptr_t)p.r | (uintptr_t)p.g | (uintptr_t)p.b) % 16 == 0);
     if (gray) { if (al) enc_f32_launch2<true, true>(p, force, grid, stream); else enc_f32_launch2<true, false>(p, force, grid, stream); }

@@ -1,10 +1,11 @@
 """The FP32 first level of encode kernel variant 1 accepts a quantised coefficient t = F*cu*cv/(4Q) only when it is
 further than delta1 from every non-zero integer, delta1 = 1.25 x the worst-case FP32 error of t over the lane's block
 column (DeviceTables::delta1, built in jpezy_capi.hip).  This test re-derives that table, emulates the kernel's exact FP32
-instruction sequence (same butterflies, same FMA placement) in numpy and measures the error against a float64
-evaluation on adversarial blocks (extreme amplitudes, every basis-function sign pattern, checkerboards) and random
-blocks -- the measured maximum must stay far inside the guard band.  The colour-conversion guard band is checked
-exhaustively over all 2^24 RGB triples."""
+instruction sequence (same butterflies, same FMA placement -- the kernel issues them two at a time as v_pk_*_f32, which
+changes no operand and no rounding) in numpy and measures the error against a float64 evaluation on adversarial blocks
+(extreme amplitudes, every basis-function sign pattern, checkerboards) and random blocks -- the measured maximum must stay
+far inside the guard band; the kernel's one-sided form of the test (fract(fma(F, ks, delta1)) < 2 delta1) is checked
+against the two-sided definition.  The colour-conversion guard band is checked exhaustively over all 2^24 RGB triples."""
 import numpy as np
 
 f32 = np.float32
@@ -23,7 +24,9 @@ K1, K2, K3, K4, K5, K6, K7 = (cosk(k) for k in range(1, 8))
 
 
 def fdct8f(x):
-    """x: [..., 8] float32 -> [..., 8]; mirrors f32::fdct8f of jpezy_kernels_f32.hip instruction by instruction"""
+    """x: [..., 8] float32 -> [..., 8]; mirrors f32::fdct8p of jpezy_kernels_f32.hip operation by operation (the kernel
+    computes the pairs (s_k, d_k), (e0, e2), (e1, e3), (X0, X4), (X2, X6), (X1, X3), (X5, X7) with one packed instruction per
+    line below and pair: same operands, same order of the fused multiply-adds)"""
     x = x.astype(f32)
     s0, s1, s2, s3 = x[..., 0] + x[..., 7], x[..., 1] + x[..., 6], x[..., 2] + x[..., 5], x[..., 3] + x[..., 4]
     d0, d1, d2, d3 = x[..., 0] - x[..., 7], x[..., 1] - x[..., 6], x[..., 2] - x[..., 5], x[..., 3] - x[..., 4]
@@ -93,39 +96,56 @@ def test_level1_error_is_far_inside_the_guard_band(oracle):
         err[0, 0] = 0
         assert np.all(err <= bound_t), (err / np.maximum(bound_t, 1e-30)).max()
         assert np.all(err.max(axis=0) < delta1 / 8), (err.max(axis=0) / delta1).max()   # measured: >10x inside the band
+        # the kernel's one-sided test: t' = fma(F, ks, delta1), flagged <=> fract(t') < 2 delta1, q = trunc(t').  Every
+        # coefficient it does NOT flag must truncate to the exact quotient's integer part, and the flagged set must contain
+        # every coefficient whose exact t is within the proven error bound of a non-zero integer
+        tb = fma(F, ks, np.broadcast_to(delta1, F.shape).astype(f32))
+        fr = (tb - np.floor(tb)).astype(f32)                             # v_fract_f32
+        flagged = fr < (delta1 + delta1)
+        t_exact = exact * scale
+        ok = np.trunc(tb.astype(np.float64)) == np.trunc(t_exact)
+        ok[:, 0, 0] = True                                               # DC: exact table
+        assert np.all(ok | flagged)
+        near = np.abs(t_exact - np.rint(t_exact)) <= bound_t
+        near[:, 0, 0] = False
+        assert np.all(flagged[near])
+        # the band is not wider than it has to be: flagged <=> the unbiased FP32 value is within delta1 (+ one rounding) of an integer
+        d32 = np.abs(t32.astype(np.float64) - np.rint(t32.astype(np.float64)))
+        assert np.all(d32[flagged] <= delta1.astype(np.float64).max() * 1.001 + 2.0 ** -23 * 128)
     # exact integer sums: the DC input of the lookup table
     assert np.array_equal(F[:, 0, 0].astype(np.int64), pic.sum(axis=(1, 2)))
 
 
 def test_colour_level1_guard_band_exhaustive():
-    """f32::luma_px / chroma_px: Y = trunc(t), t an FP32 fma chain; flagged (-> FP64 reference formula) when t is within
-    2^-12 (luma) / 2^-14 (chroma) of an integer.  Over all 2^24 RGB triples: every unflagged pixel truncates to the exact
-    integer quotient, and every pixel whose exact value is an integer (where the reference's FP64 rounding decides) is
-    flagged."""
+    """f32::luma_px2 / chroma_px2: Y = trunc(t'), t' an FP32 fma chain that starts from a small bias eps; flagged (-> FP64
+    reference formula) when fract(t') < threshold (2^-12 / 2^-11 luma, 3*2^-16 / 3*2^-15 chroma).  Over all 2^24 RGB triples:
+    every unflagged pixel truncates to the exact integer quotient, and exactly the pixels whose exact value is an integer
+    (where the reference's FP64 rounding decides) are flagged."""
     G, B = np.meshgrid(np.arange(256, dtype=np.int64), np.arange(256, dtype=np.int64), indexing="ij")
     Gf, Bf = G.astype(f32), B.astype(f32)
     worst = {"y": 0.0, "cb": 0.0, "cr": 0.0}
     flagged = {"y": 0, "cb": 0, "cr": 0}
+    le, lt, ce, ct = f32(2.0 ** -12), f32(2.0 ** -11), f32(3 * 2.0 ** -16), f32(3 * 2.0 ** -15)
     for R in range(256):
         Rf = np.full_like(Gf, R)
         cases = {
-            "y": (fma(Bf, f32(0.114), fma(Gf, f32(0.587), fma(Rf, f32(0.299), np.full_like(Gf, -128.0)))),
-                  299 * R + 587 * G + 114 * B - 128000, 1000, 2.0 ** -12, 2.4e-5),
-            "cb": (fma(Bf, f32(0.5), fma(Gf, f32(-0.3313), (Rf * f32(-0.1687)).astype(f32))),
-                   -1687 * R - 3313 * G + 5000 * B, 10000, 2.0 ** -14, 1.7e-5),
-            "cr": (fma(Bf, f32(-0.0813), fma(Gf, f32(-0.4187), (Rf * f32(0.5)).astype(f32))),
-                   5000 * R - 4187 * G - 813 * B, 10000, 2.0 ** -14, 1.7e-5),
+            "y": (fma(Bf, f32(0.114), fma(Gf, f32(0.587), fma(Rf, f32(0.299), np.full_like(Gf, f32(-128.0) + le)))),
+                  299 * R + 587 * G + 114 * B - 128000, 1000, le, lt, 2.4e-5),
+            "cb": (fma(Bf, f32(0.5), fma(Gf, f32(-0.3313), fma(Rf, f32(-0.1687), np.full_like(Gf, ce)))),
+                   -1687 * R - 3313 * G + 5000 * B, 10000, ce, ct, 1.7e-5),
+            "cr": (fma(Bf, f32(-0.0813), fma(Gf, f32(-0.4187), fma(Rf, f32(0.5), np.full_like(Gf, ce)))),
+                   5000 * R - 4187 * G - 813 * B, 10000, ce, ct, 1.7e-5),
         }
-        for name, (t, num, den, eps, bound) in cases.items():
+        for name, (t, num, den, eps, th, bound) in cases.items():
+            assert t.dtype == f32
             tr = np.trunc(t)
-            d = np.abs(t - tr)                                         # exact in FP32
-            e = (d - f32(0.5)).astype(f32)
-            flag = np.abs(e) > f32(0.5) - f32(eps)
+            fr = (t - np.floor(t)).astype(f32)                         # v_fract_f32: exact in FP32
+            flag = fr < th
             exact_q = np.trunc(num / den)                              # float64 quotient: exact enough for integers < 2^24
             integral = (num % den) == 0
             assert np.all(flag[integral]), name                        # the reference's rounding decides: must be flagged
             assert np.array_equal(tr[~flag], exact_q[~flag]), name     # everything else is already right
-            worst[name] = max(worst[name], float(np.abs(t.astype(np.float64) - num / den).max()))
+            worst[name] = max(worst[name], float(np.abs(t.astype(np.float64) - float(eps) - num / den).max()))
             flagged[name] += int(flag.sum())
             assert worst[name] <= bound, (name, worst[name])
             assert int(flag.sum()) == int(integral.sum()), name        # the band catches nothing else

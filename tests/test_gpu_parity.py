@@ -23,11 +23,10 @@ def J():
     return jpezy_amd
 
 
-@pytest.fixture(scope="module", params=[0, 1, 2], ids=["enc-f64", "enc-f32", "enc-mfma"])
+@pytest.fixture(scope="module", params=[0, 1], ids=["enc-f64", "enc-f32"])
 def ctx(J, request):
-    """every test runs with all encode kernel variants (0: FP64 butterflies, 1: FP32 first level + FP64 second
-    level + reference-order third level, 2: variant 1 with the luma transforms on the matrix pipe); the decode kernel is
-    the same in all of them."""
+    """every test runs with both encode kernel variants (0: FP64 butterflies, 1: packed-FP32 first level + FP64 second
+    level + reference-order third level -- two independently written kernels); the decode kernel is the same in both."""
     c = J.Context(0)
     c.set_variant(request.param)
     c.variant = request.param

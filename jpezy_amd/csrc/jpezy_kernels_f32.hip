@@ -251,14 +251,14 @@ __device__ __forceinline__ void luma8(const uint32_t* wr, const uint32_t* wg, co
     if (wave_any(min8(e) < LUMA_TH)) {   // one pixel in 1000: the reference's FP64 rounding decides
 #endif
         bool f;
-        f = e[0].x < LUMA_TH; if (wave_any(f)) { if (f) A[0].x = luma_px_ref<0>(wr[0], wg[0], wb[0]); }
-        f = e[1].x < LUMA_TH; if (wave_any(f)) { if (f) A[1].x = luma_px_ref<1>(wr[0], wg[0], wb[0]); }
-        f = e[2].x < LUMA_TH; if (wave_any(f)) { if (f) A[2].x = luma_px_ref<2>(wr[0], wg[0], wb[0]); }
-        f = e[3].x < LUMA_TH; if (wave_any(f)) { if (f) A[3].x = luma_px_ref<3>(wr[0], wg[0], wb[0]); }
-        f = e[3].y < LUMA_TH; if (wave_any(f)) { if (f) A[3].y = luma_px_ref<0>(wr[1], wg[1], wb[1]); }
-        f = e[2].y < LUMA_TH; if (wave_any(f)) { if (f) A[2].y = luma_px_ref<1>(wr[1], wg[1], wb[1]); }
-        f = e[1].y < LUMA_TH; if (wave_any(f)) { if (f) A[1].y = luma_px_ref<2>(wr[1], wg[1], wb[1]); }
-        f = e[0].y < LUMA_TH; if (wave_any(f)) { if (f) A[0].y = luma_px_ref<3>(wr[1], wg[1], wb[1]); }
+        f = e[0].x < LUMA_TH; if (f) A[0].x = luma_px_ref<0>(wr[0], wg[0], wb[0]);
+        f = e[1].x < LUMA_TH; if (f) A[1].x = luma_px_ref<1>(wr[0], wg[0], wb[0]);
+        f = e[2].x < LUMA_TH; if (f) A[2].x = luma_px_ref<2>(wr[0], wg[0], wb[0]);
+        f = e[3].x < LUMA_TH; if (f) A[3].x = luma_px_ref<3>(wr[0], wg[0], wb[0]);
+        f = e[3].y < LUMA_TH; if (f) A[3].y = luma_px_ref<0>(wr[1], wg[1], wb[1]);
+        f = e[2].y < LUMA_TH; if (f) A[2].y = luma_px_ref<1>(wr[1], wg[1], wb[1]);
+        f = e[1].y < LUMA_TH; if (f) A[1].y = luma_px_ref<2>(wr[1], wg[1], wb[1]);
+        f = e[0].y < LUMA_TH; if (f) A[0].y = luma_px_ref<3>(wr[1], wg[1], wb[1]);
     }
 }
 
@@ -625,14 +625,14 @@ __global__ __launch_bounds__(64 * EWPB, JPEZY_F32_WAVES) void fdct_quant_f32_ker
         if (wave_any(min8(e) < CHROMA_TH)) {
 #endif
             bool f;
-            f = e[0].x < CHROMA_TH; if (wave_any(f)) { if (f) CS[0].x = chroma_px_ref<0>(R2[0], G2[0], B2[0], odd); }
-            f = e[1].x < CHROMA_TH; if (wave_any(f)) { if (f) CS[1].x = chroma_px_ref<2>(R2[0], G2[0], B2[0], odd); }
-            f = e[2].x < CHROMA_TH; if (wave_any(f)) { if (f) CS[2].x = chroma_px_ref<0>(R2[1], G2[1], B2[1], odd); }
-            f = e[3].x < CHROMA_TH; if (wave_any(f)) { if (f) CS[3].x = chroma_px_ref<2>(R2[1], G2[1], B2[1], odd); }
-            f = e[3].y < CHROMA_TH; if (wave_any(f)) { if (f) CS[3].y = chroma_px_ref<0>(R2[2], G2[2], B2[2], odd); }
-            f = e[2].y < CHROMA_TH; if (wave_any(f)) { if (f) CS[2].y = chroma_px_ref<2>(R2[2], G2[2], B2[2], odd); }
-            f = e[1].y < CHROMA_TH; if (wave_any(f)) { if (f) CS[1].y = chroma_px_ref<0>(R2[3], G2[3], B2[3], odd); }
-            f = e[0].y < CHROMA_TH; if (wave_any(f)) { if (f) CS[0].y = chroma_px_ref<2>(R2[3], G2[3], B2[3], odd); }
+            f = e[0].x < CHROMA_TH; if (f) CS[0].x = chroma_px_ref<0>(R2[0], G2[0], B2[0], odd);
+            f = e[1].x < CHROMA_TH; if (f) CS[1].x = chroma_px_ref<2>(R2[0], G2[0], B2[0], odd);
+            f = e[2].x < CHROMA_TH; if (f) CS[2].x = chroma_px_ref<0>(R2[1], G2[1], B2[1], odd);
+            f = e[3].x < CHROMA_TH; if (f) CS[3].x = chroma_px_ref<2>(R2[1], G2[1], B2[1], odd);
+            f = e[3].y < CHROMA_TH; if (f) CS[3].y = chroma_px_ref<0>(R2[2], G2[2], B2[2], odd);
+            f = e[2].y < CHROMA_TH; if (f) CS[2].y = chroma_px_ref<2>(R2[2], G2[2], B2[2], odd);
+            f = e[1].y < CHROMA_TH; if (f) CS[1].y = chroma_px_ref<0>(R2[3], G2[3], B2[3], odd);
+            f = e[0].y < CHROMA_TH; if (f) CS[0].y = chroma_px_ref<2>(R2[3], G2[3], B2[3], odd);
         }
     }
     __builtin_amdgcn_sched_barrier(0);

@@ -1,0 +1,249 @@
+"""The integer half of the path, pinned to the reference itself.
+
+tests/golden/ref_tables.json holds what tools/extract_ref_tables.py read out of the reference's source text (data only): `ZZ`,
+Tables K.1 / K.2, the MARKER values (src/jpezy.hpp:36-45, 131-152, 47-127), Tables K.3-K.6 as (size, code) arrays in the
+reference's own `run * 10 + s + (run == 15)` layout with the EOB / ZRL indices and the four DHT segments
+(src/encoder/huffman_table.hpp:26-282), and the bytes `jpezy_writer::write_header` / `write_eoi` emit
+(src/encoder/jpezy_writer.hpp:20-105) for the property sets of the CLI (src/encoder/encode_io.hpp:144-160, 177-188).
+
+Held to it here: the oracle's tables and header, the host codec's header and Huffman coder / decoder (through a stream that
+uses every symbol of all four tables, coded by a Python restatement of `encode_huffman` -- src/encoder/jpezy_encoder.hpp:174-225
+-- driven by the FIXTURE's tables), and on the GPU the device entropy coder and its header cache.  What stays unpinned is what
+the reference takes from SrookCppLibraries: the cosine table, 1/sqrt 2, and the bit writer's stuffing / pad bits (the Python
+coder below stuffs 0x00 after 0xFF and pads with zeros like the oracle: DESIGN.md section 6)."""
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import jpezy_amd as J
+
+FIX = json.loads((Path(__file__).parent / "golden" / "ref_tables.json").read_text())
+H = FIX["huffman"]
+
+
+def canonical_codes(dht):
+    """(size, code) per symbol from a DHT segment FF C4 Lh Tc|Th BITS[16] HUFFVAL[] (ISO/IEC 10918-1 Annex C)"""
+    assert dht[0] == 0xFF and dht[1] == FIX["markers"]["DHT"] and (dht[2] << 8 | dht[3]) == len(dht) - 2
+    bits, vals = dht[5:21], dht[21:]
+    assert sum(bits) == len(vals)
+    out, code, k = {}, 0, 0
+    for length in range(1, 17):
+        for _ in range(bits[length - 1]):
+            out[vals[k]] = (length, code)
+            code += 1
+            k += 1
+        code <<= 1
+    return out
+
+
+def ref_index(run, size):
+    """the reference's table index of the AC symbol (run, size): encoder/jpezy_encoder.hpp:212-216"""
+    return run * 10 + size + (1 if run == 15 else 0)
+
+
+def test_fixture_is_self_consistent():
+    """the reference's explicit (size, code) tables are the canonical codes of its own DHT segments, in its index layout"""
+    for dc, dht in (("YDc", "YDcDht"), ("CDc", "CDcDht")):
+        canon = canonical_codes(FIX["dht"][dht])
+        assert sorted(canon) == list(range(12))
+        for cat in range(12):
+            assert (H[dc + "SizeT"][cat], H[dc + "CodeT"][cat]) == canon[cat], (dc, cat)
+    for ac, dht, eob, zrl in (("YAc", "YAcDht", "YEOBidx", "YZRLidx"), ("CAc", "CAcDht", "CEOBidx", "CZRLidx")):
+        canon = canonical_codes(FIX["dht"][dht])
+        assert len(canon) == 162
+        assert (H[ac + "SizeT"][H[eob]], H[ac + "CodeT"][H[eob]]) == canon[0x00]
+        assert (H[ac + "SizeT"][H[zrl]], H[ac + "CodeT"][H[zrl]]) == canon[0xF0]
+        for run in range(16):
+            for size in range(1, 11):
+                i = ref_index(run, size)
+                assert (H[ac + "SizeT"][i], H[ac + "CodeT"][i]) == canon[run << 4 | size], (ac, run, size)
+    assert H["DcDhtLength"] == len(FIX["dht"]["YDcDht"]) and H["AcDhtLength"] == len(FIX["dht"]["YAcDht"])
+    assert FIX["markers"]["SOI"] == 0xD8 and FIX["markers"]["EOI"] == 0xD9 and FIX["markers"]["SOF0"] == 0xC0
+
+
+def test_oracle_and_product_tables_are_the_references(oracle):
+    c = oracle.constants()
+    assert list(c["zz"]) == FIX["zz"] and list(c["qt_luma"]) == FIX["qt_luma"] and list(c["qt_chroma"]) == FIX["qt_chroma"]
+    # the product: the tables its writer puts into a file, read back by its parser (natural order) -- and the properties
+    from jpezy_amd import api
+    info = api.annex_k_tables()
+    assert list(info.qt[0]) == FIX["qt_luma"] and list(info.qt[1]) == FIX["qt_chroma"]
+    cp = FIX["cli_property"]
+    assert (info.units, info.hdensity, info.vdensity, info.major_rev, info.minor_rev) == (cp["units"], cp["hdensity"], cp["vdensity"], 1, 2)
+    assert info.comment.decode() == FIX["cli_comments"]["color"]
+
+
+@pytest.mark.parametrize("k", range(len(FIX["headers"])))
+def test_header_and_eoi_bytes_are_the_references(oracle, k):
+    hd = FIX["headers"][k]
+    W, Hh, comment = hd["W"], hd["H"], hd["comment"].encode()
+    mc, mr = J.mcu_grid(W, Hh)
+    z = np.zeros((mr, mc, 6, 64), np.int16)
+    want, eoi = bytes(hd["header"]), bytes(hd["eoi"])
+    for writer in (oracle.write_jpeg, J.write_jpeg):
+        got = writer(z, W, Hh, False, comment=comment)
+        assert got[:len(want)] == want and got[-2:] == eoi, writer
+        got = writer(z[:, :, :4].copy(), W, Hh, True, comment=comment)      # --gray writes the same header (three components)
+        assert got[:len(want)] == want and got[-2:] == eoi
+
+
+class BitWriter:
+    def __init__(self):
+        self.out, self.acc, self.n = bytearray(), 0, 0
+
+    def put(self, value, nbits):
+        for k in range(nbits - 1, -1, -1):
+            self.acc = (self.acc << 1) | ((value >> k) & 1)
+            self.n += 1
+            if self.n == 8:
+                self.out.append(self.acc)
+                if self.acc == 0xFF:
+                    self.out.append(0x00)
+                self.acc, self.n = 0, 0
+
+    def finish(self):
+        if self.n:
+            self.put(0, 8 - self.n)
+        return bytes(self.out)
+
+
+def ref_encode_huffman(coeffs, gray):
+    """`encoder::encode_huffman` (src/encoder/jpezy_encoder.hpp:174-225) with the fixture's tables: coeffs [mcu][blocks][64] in
+    zig-zag order (what the reference reads as dct_data[ZZ[n]]), block order Y0 Y1 Y2 Y3 Cb Cr (:227-242); in GRAY mode the
+    chroma blocks are all-zero blocks (:61-64)"""
+    bw = BitWriter()
+    pre_dc = [0, 0, 0]
+    zero = np.zeros(64, np.int64)
+    for mcu in coeffs:
+        blocks = [(mcu[b], 0) for b in range(4)] + ([(zero, 1), (zero, 2)] if gray else [(mcu[4], 1), (mcu[5], 2)])
+        for blk, cs in blocks:
+            dc_s, dc_c = (H["YDcSizeT"], H["YDcCodeT"]) if cs == 0 else (H["CDcSizeT"], H["CDcCodeT"])
+            ac_s, ac_c = (H["YAcSizeT"], H["YAcCodeT"]) if cs == 0 else (H["CAcSizeT"], H["CAcCodeT"])
+            eob, zrl = (H["YEOBidx"], H["YZRLidx"]) if cs == 0 else (H["CEOBidx"], H["CZRLidx"])
+            diff = int(blk[0]) - pre_dc[cs]
+            pre_dc[cs] = int(blk[0])
+            a, di = abs(diff), 0
+            while a > 0:
+                a >>= 1
+                di += 1
+            bw.put(dc_c[di], dc_s[di])
+            if di:
+                bw.put((diff - 1 if diff < 0 else diff) & ((1 << di) - 1), di)
+            run = 0
+            for n in range(1, 64):
+                v = int(blk[n])
+                if v != 0:
+                    while run > 15:
+                        bw.put(ac_c[zrl], ac_s[zrl])
+                        run -= 16
+                    a, s = abs(v), 0
+                    while a > 0:
+                        a >>= 1
+                        s += 1
+                    i = ref_index(run, s)
+                    bw.put(ac_c[i], ac_s[i])
+                    bw.put((v - 1 if v < 0 else v) & ((1 << s) - 1), s)
+                    run = 0
+                else:
+                    if n == 63:
+                        bw.put(ac_c[eob], ac_s[eob])
+                    else:
+                        run += 1
+    return bw.finish()
+
+
+def every_symbol_coeffs():
+    """MCUs whose blocks use every DC category 0..11 (as differences, both signs) and every AC symbol (run 0..15) x (size 1..10),
+    ZRL chains and EOB, in luma and chroma blocks"""
+    rng = np.random.default_rng(7)
+    pairs = [(r, s) for r in range(16) for s in range(1, 11)]
+    blocks = []
+    for k, (r, s) in enumerate(pairs):
+        b = np.zeros(64, np.int64)
+        b[r + 1] = int(rng.integers(1 << (s - 1), 1 << s)) * (1 if k & 1 else -1)
+        if r + 1 + 17 < 63 and k % 3 == 0:
+            b[r + 1 + 17] = 1                       # a run of 16: ZRL + (0, 1)
+        if k % 5 == 0:
+            b[63] = -1                              # no EOB in this block
+        blocks.append(b)
+    for gap in (32, 48, 62):                        # long runs: two and three ZRL in a row
+        b = np.zeros(64, np.int64)
+        b[gap] = 3
+        blocks.append(b)
+    while len(blocks) % 6:
+        blocks.append(np.zeros(64, np.int64))
+    co = np.array(blocks).reshape(-1, 6, 64)
+    # DC terms: differences of every category, both signs, in every component (the running value stays inside +-1023... the
+    # categories 11 need |diff| >= 1024: swing between -1023 and +1023)
+    for comp_blocks in ([0, 1, 2, 3], [4], [5]):
+        seq, cur = [], 0
+        targets = [0, 1, -1, 2, -3, 5, -7, 12, -20, 40, -60, 100, -150, 300, -400, 700, -900, 1023, -1023, 1023, 0]
+        for t in targets:
+            seq.append(t)
+        k = 0
+        for m in range(co.shape[0]):
+            for b in comp_blocks:
+                co[m, b, 0] = seq[k % len(seq)]
+                k += 1
+    return co
+
+
+def test_huffman_coder_and_decoder_follow_the_reference_tables(oracle):
+    co = every_symbol_coeffs()
+    n = co.shape[0]
+    # lay the MCUs out as one row: W = 16 n
+    W, Hh = 16 * n, 16
+    grid = co.reshape(1, n, 6, 64).astype(np.int16)
+    want = ref_encode_huffman(co, gray=False)
+    used = set()
+    for m in co:
+        for b in m:
+            d = np.flatnonzero(b[1:])
+            used.update(int(abs(v)).bit_length() for v in b[1:][d])
+    assert used == set(range(1, 11))
+    for writer in (oracle.write_jpeg, J.write_jpeg):
+        jpg = writer(grid, W, Hh, False)
+        assert jpg[644:-2] == want, writer
+    info, back = J.read_jpeg(J.write_jpeg(grid, W, Hh, False))
+    assert np.array_equal(back.reshape(grid.shape), grid)
+    oinfo, oback = oracle.read_jpeg(oracle.write_jpeg(grid, W, Hh, False))
+    assert np.array_equal(oback.reshape(grid.shape), grid)
+    # gray: the reference codes all-zero chroma blocks
+    g = np.ascontiguousarray(grid[:, :, :4])
+    wantg = ref_encode_huffman(co[:, :4], gray=True)
+    for writer in (oracle.write_jpeg, J.write_jpeg):
+        assert writer(g, W, Hh, True)[644:-2] == wantg, writer
+
+
+@pytest.mark.gpu
+def test_device_entropy_coder_follows_the_reference_tables():
+    import torch
+    co = every_symbol_coeffs()
+    reps = 40                                         # several tiles of 256 blocks
+    co = np.concatenate([co] * reps)
+    n = co.shape[0]
+    W, Hh = 16 * n, 16
+    grid = co.reshape(1, n, 6, 64).astype(np.int16)
+    want = ref_encode_huffman(co, gray=False)
+    ctx = J.Context(0)
+    d = torch.from_numpy(grid.reshape(-1).copy()).cuda()
+    jpg = ctx.write_jpeg_gpu(d, W, Hh, gray=False, comment=FIX["cli_comments"]["color"].encode())
+    if isinstance(jpg, (list, tuple)):
+        jpg = jpg[0]
+    jpg = bytes(jpg)
+    hd = next(h for h in FIX["headers"] if h["comment"] == FIX["cli_comments"]["color"])
+    head = bytearray(hd["header"])
+    # SOF0's size fields (frame header: FF C0 Lf P Y Y X X): the fixture's header is for another size
+    k = bytes(head).index(bytes([0xFF, FIX["markers"]["SOF0"]]))
+    head[k + 5:k + 9] = Hh.to_bytes(2, "big") + W.to_bytes(2, "big")
+    assert jpg[:644] == bytes(head)
+    assert jpg[644:-2] == want and jpg[-2:] == bytes(hd["eoi"])
+    g = np.ascontiguousarray(grid[:, :, :4])
+    dg = torch.from_numpy(g.reshape(-1).copy()).cuda()
+    jg = ctx.write_jpeg_gpu(dg, W, Hh, gray=True)
+    if isinstance(jg, (list, tuple)):
+        jg = jg[0]
+    assert bytes(jg)[644:-2] == ref_encode_huffman(co[:, :4], gray=True)
+    ctx.close()

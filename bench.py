@@ -868,6 +868,16 @@ def run_rank(args):
             out["decode_tolerant"] = dec_tol
         if batch:
             out["batch"] = batch
+            # north_star's 8-GPU target is STRONG scaling of this batch (configs[3]); `value` above is weak scaling of configs[1].
+            # Top-level copies so that a 1 -> 8 curve of the target can be read off the lines without opening the object.
+            out["batch_strong_scaling"] = {
+                "metric": "Mpixels/s, batch of %d 1920x1080 frames end to end in .jpg on rank 0 (strong scaling)" % batch["frames"],
+                "value": batch["end_to_end_jpg"]["Mpixels_per_s"],
+                "value_coefficients_gathered": batch["end_to_end"]["Mpixels_per_s"],
+                "value_kernels_only": batch["kernel_only"]["Mpixels_per_s"],
+                "one_gpu_same_pipeline": batch["one_gpu_same_pipeline_jpg"]["Mpixels_per_s"],
+                "speedup_vs_one_gpu": batch["speedup_end_to_end_jpg"],
+                "n_gpus": world}
         if not args.no_cpu:          # rank 0 only, after every timed region (the other ranks idle at the closing barrier)
             out["cpu_baseline"] = cpu_baseline(W, H, gray, direction)
         print(json.dumps(out), flush=True)

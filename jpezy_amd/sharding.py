@@ -163,6 +163,31 @@ def gather_to_root_pipelined(encode_chunk, n_frames, coeffs_per_frame, chunk_fra
     return out if rank == root else None
 
 
+def band_pixel_rows(mcu_lo, mcu_hi, H):
+    """(first pixel row, number of pixel rows) of the band of MCU rows [mcu_lo, mcu_hi) of a frame H pixels high.  A band of
+    whole MCU rows is a frame of its own for the kernels: only the last band is shorter than 16 rows per MCU row, and it
+    replicates the bottom edge exactly as the whole frame would (ref encoder/jpezy_encoder.hpp:101)."""
+    y0 = 16 * mcu_lo
+    return y0, min(16 * mcu_hi, H) - y0
+
+
+def encode_frame_banded(encode_band, W, H, gray=False, band_rows=8, device="cpu", root=0, group=None, out=None, ring=3):
+    """ONE frame over all ranks (BASELINE configs[1] / [4] at N > 1; SURVEY.md 8e, last sentence): the MCU loop of
+    encoder::encode (ref encoder/jpezy_encoder.hpp:55-67) is separable by MCU rows for everything but pre_DC and the bit
+    cursor, which belong to the Huffman tail -- so the unit that is sharded is the MCU row, rank k transforms the contiguous
+    rows shard_range(mcu_rows, world, k), and the coefficient rows are gathered on `root` band by band, overlapped with the
+    transform of the next band (gather_to_root_pipelined with MCU rows in the place of frames).  The Huffman stage then runs
+    on `root` over the whole frame (host or GPU coder): its DC predictors and bit cursor never cross a rank.
+
+    encode_band(mcu_lo, mcu_hi, dst): enqueue the transform of MCU rows [mcu_lo, mcu_hi) -- pixel rows band_pixel_rows(...) of
+        the planes, as a frame W x that many rows -- into dst, an int16 tensor [mcu_hi - mcu_lo, mcu_cols * (4|6) * 64].
+    Returns the frame's coefficients [mcu_rows, mcu_cols * (4|6) * 64] on root (the layout of a whole-frame call), None elsewhere.
+    """
+    mcu_cols, mcu_rows = (W + 15) // 16, (H + 15) // 16
+    per_row = mcu_cols * (4 if gray else 6) * 64
+    return gather_to_root_pipelined(encode_band, mcu_rows, per_row, band_rows, device, root=root, group=group, out=out, ring=ring)
+
+
 class JpgBatch:
     """What gather_jpg_to_root_pipelined leaves on the consumer: the batch's .jpg files, packed chunk by chunk.
     sizes: int64 CPU tensor [n_frames]; chunks: list of (lo, hi, packed uint8 tensor) in frame order -- frame f of a chunk

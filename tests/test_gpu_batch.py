@@ -159,3 +159,43 @@ def test_bench_gpus_2_on_rccl_when_two_gpus_are_visible():
     assert line["n_gpus"] == 2 and "error" not in bt and "rehearsal" not in bt
     assert bt["gathered_equals_one_gpu_result"] is True and bt["gathered_jpg_equals_one_gpu_result"] is True
     assert bt["end_to_end_jpg"]["bytes_into_rank0"] < bt["gather"]["bytes_into_rank0"] // 5
+
+
+@pytest.mark.parametrize("W,H,gray,band_rows", [(4096, 4096, False, 32), (7680, 4320, True, 17), (1000, 530, False, 5)])
+def test_one_frame_split_by_mcu_row_bands_on_the_gpu(oracle, W, H, gray, band_rows):
+    """configs[1] / [4] as ONE frame cut into MCU-row bands (jpezy_amd.sharding.encode_frame_banded, the N > 1 form of a single
+    frame; here one rank walks all bands): every band is a kernel launch on a slice of the planes, the assembled coefficient
+    buffer equals the whole-frame launch bit for bit -- also for the last, shorter band of 4320 = 270 MCU rows and for a width
+    that takes the unaligned kernel -- and a sample of MCU rows equals the oracle"""
+    import torch
+    import jpezy_amd as J
+    from jpezy_amd import sharding
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev); g.manual_seed(W * 7 + H)
+    planes = [torch.randint(0, 256, (W * H,), dtype=torch.uint8, device=dev, generator=g) for _ in range(3)]
+    ctx = J.Context(0)
+    try:
+        whole = torch.empty(J.coeff_count(W, H, gray), dtype=torch.int16, device=dev)
+        ctx.fdct_quant_dev(planes[0], planes[1], planes[2], W, H, whole, gray=gray)
+        bands = []
+
+        def encode_band(lo, hi, dst):
+            y0, n = sharding.band_pixel_rows(lo, hi, H)
+            bands.append((lo, hi))
+            sl = slice(y0 * W, (y0 + n) * W)
+            ctx.fdct_quant_dev(planes[0][sl], planes[1][sl], planes[2][sl], W, n, dst.reshape(-1), gray=gray)
+
+        got = sharding.encode_frame_banded(encode_band, W, H, gray=gray, band_rows=band_rows, device=dev)
+        torch.cuda.synchronize(dev)
+        mcu_rows = (H + 15) // 16
+        assert bands == sharding.chunk_spans(0, mcu_rows, band_rows)
+        assert torch.equal(got.reshape(-1), whole)
+        # two bands against the oracle, as frames of their own (first and last)
+        hp = [p.cpu().numpy() for p in planes]
+        for lo, hi in (bands[0], bands[-1]):
+            y0, n = sharding.band_pixel_rows(lo, hi, H)
+            sl = slice(y0 * W, (y0 + n) * W)
+            want = oracle.encode_coeffs(hp[0][sl], hp[1][sl], hp[2][sl], W, n, gray=gray)
+            assert np.array_equal(got[lo:hi].cpu().numpy().reshape(-1), np.ascontiguousarray(want).reshape(-1))
+    finally:
+        ctx.close()

@@ -100,7 +100,7 @@ def _worker_pipelined(rank, world, port, n_frames, chunk, W, H, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n_frames,chunk", [(2, 7, 2), (3, 8, 1), (3, 2, 4)])
+@pytest.mark.parametrize("world,n_frames,chunk", [(2, 7, 2), (3, 8, 1), (3, 2, 4), (8, 19, 2)])
 def test_pipelined_gather_to_root_gloo(tmp_path, world, n_frames, chunk):
     """chunked, overlapped gather-to-consumer: uneven shards, ragged last chunks, a rank with no frames,
     staging ring shorter than the number of chunks"""
@@ -166,7 +166,8 @@ def _worker_jpg(rank, world, port, n_frames, chunk, use_meta, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n_frames,chunk,use_meta", [(2, 7, 2, True), (3, 8, 1, False), (3, 2, 4, True), (2, 5, 3, False)])
+@pytest.mark.parametrize("world,n_frames,chunk,use_meta", [(2, 7, 2, True), (3, 8, 1, False), (3, 2, 4, True), (2, 5, 3, False),
+                                                           (8, 21, 2, True), (8, 11, 1, False)])
 def test_pipelined_jpg_gather_to_root_gloo(tmp_path, world, n_frames, chunk, use_meta):
     """every rank codes its frames END TO END (the oracle stands in for FDCT + Huffman stage) and only the .jpg files --
     variable length -- travel to the consumer: uneven shards, ragged last chunks, a rank with no frames, a staging ring
@@ -206,3 +207,52 @@ def test_pipelined_jpg_single_rank_no_process_group():
         return torch.zeros((hi - lo, 4), dtype=torch.uint8), torch.full((hi - lo,), -6, dtype=torch.int64)
     with pytest.raises(RuntimeError):
         sharding.gather_jpg_to_root_pipelined(bad, 2, 2, "cpu")
+
+
+def _worker_banded(rank, world, port, W, H, gray, band_rows, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import oracle as O
+        r, g, b = O.synth_rgb(W, H, frame=3)
+        mcu_cols, mcu_rows = (W + 15) // 16, (H + 15) // 16
+        bands = []
+
+        def encode_band(lo, hi, dst):
+            my_lo, my_hi = sharding.shard_range(mcu_rows, world, rank)
+            assert my_lo <= lo < hi <= my_hi
+            y0, n = sharding.band_pixel_rows(lo, hi, H)
+            bands.append((lo, hi, y0, n))
+            # the band as a frame of its own: W x n pixels cut out of the planes
+            sl = slice(y0 * W, (y0 + n) * W)
+            co = O.encode_coeffs(r[sl], g[sl], b[sl], W, n, gray=gray)
+            dst.copy_(torch.from_numpy(np.ascontiguousarray(co).reshape(hi - lo, -1)))
+
+        full = sharding.encode_frame_banded(encode_band, W, H, gray=gray, band_rows=band_rows, device="cpu")
+        if rank == 0:
+            np.save(Path(out_dir) / "frame.npy", full.numpy())
+        np.save(Path(out_dir) / f"bands_{rank}.npy", np.array(bands, dtype=np.int64).reshape(-1, 4))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,W,H,gray,band_rows", [(2, 48, 100, False, 2), (3, 33, 50, True, 1), (8, 64, 70, False, 1)])
+def test_one_frame_split_by_mcu_row_bands_gloo(tmp_path, world, W, H, gray, band_rows):
+    """a single frame over N ranks (configs[1] / [4] at N > 1): MCU-row bands transformed as frames of their own and gathered
+    on rank 0 equal the one-rank frame bit for bit -- also the last, shorter band (bottom-edge replication), ranks with no
+    band (more ranks than MCU rows: world 8, 5 MCU rows) and gray mode; the .jpg the root then writes is the one-rank file"""
+    port = _free_port()
+    mp.spawn(_worker_banded, args=(world, port, W, H, gray, band_rows, str(tmp_path)), nprocs=world, join=True)
+    from oracle import oracle as O
+    r, g, b = O.synth_rgb(W, H, frame=3)
+    want = O.encode_coeffs(r, g, b, W, H, gray=gray)
+    got = np.load(tmp_path / "frame.npy")
+    assert np.array_equal(got.reshape(-1), np.ascontiguousarray(want).reshape(-1))
+    assert O.write_jpeg(got.reshape(want.shape), W, H, gray) == O.encode_jpeg(r, g, b, W, H, gray)
+    rows = []
+    for k in range(world):
+        for lo, hi, y0, n in np.load(tmp_path / f"bands_{k}.npy"):
+            assert y0 == 16 * lo and n == min(16 * hi, H) - y0 and n > 0
+            rows += list(range(lo, hi))
+    assert sorted(rows) == list(range((H + 15) // 16))

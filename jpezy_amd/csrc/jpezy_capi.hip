@@ -134,7 +134,7 @@ struct jpezy_ctx {
     int dec_tolerance = 0;         // 0 = bit-exact decode (default), 1 = luma in FP32, output within one of the reference per channel
     uint16_t dq_cache[3][64];
     int coef_limit = 0;            // 2^15 / largest quantiser: the generic kernels and the tolerance mode of the fused kernel
-    int coef_limit_exact = 0;      // 2^23 / largest quantiser: the fused kernel's exact mode (error 2e-7 against a guard band of 3.8e-6)
+    int coef_limit_exact = 0;      // 2^23 / largest quantiser: the fused kernel's exact mode (fast path + reference sum err by <= 1.2e-6 against a guard band of 3.8e-6)
     bool dq_valid = false;
     int force_exact = 0;           // 0 normal, 1 everything through the reference-order path, 2 (f32 variant) through level 2,
                                    // 3 (f32 variant) through the per-lane evaluator of the queue-overflow case
@@ -524,9 +524,13 @@ static int upload_dequant(jpezy_ctx* c, const uint16_t qt[4][64], const uint8_t 
     for (int k = 0; k < 3; ++k)
         for (int i = 0; i < 64; ++i) qmax = sel[k][i] > qmax ? sel[k][i] : qmax;
     c->coef_limit = 32768 / qmax;
-    // Fused kernel, exact mode: with |c * Q| <= 2^23 every dequantised input is below 2^21, the two FP64 butterfly passes err by
-    // at most (8 * 6 * 8 + 6 * 64) * 2^21 * 2^-53 = 1.8e-7 -- a twentieth of the 2^-18 guard band.  Every 8-bit quantiser table
-    // gives a limit >= 32768: no int16 coefficient can exceed it and the kernel without the range test is launched.
+    // Fused kernel, exact mode: with |c * Q| <= 2^23 every dequantised input is below 2^21 and the two FP64 butterfly passes err
+    // by at most (8 * 6 * 8 + 6 * 64) * 2^21 * 2^-53 = 1.8e-7.  The value they must truncate like -- the reference's own
+    // reference-order sum of 64 such terms -- carries a rounding error of its own, at most 64 partial sums of up to 2^27 each
+    // rounded to 2^-53 relative and divided by 4: 64 * 2^27 * 2^-53 / 4 = 2.4e-7 ... 1e-6 by the coarsest count.  Together
+    // at most 1.2e-6 against the 2^-18 = 3.8e-6 guard band: a margin of about three (not twenty, as this comment used to say).
+    // Every 8-bit quantiser table gives a limit >= 32768: no int16 coefficient can exceed it and the kernel without the range
+    // test is launched (tests/test_gpu_tolerance.py::test_all_coefficients_at_the_int16_extremes_with_q255).
     c->coef_limit_exact = (1 << 23) / qmax;
     c->dq_valid = true;
     return JPEZY_OK;
@@ -1264,8 +1268,10 @@ int huffdec_streams(jpezy_ctx* c, const std::vector<DevStream>& streams, const s
     }
     lap("confirm + refine");
     // 3. block index of every lane, coefficients, DC predictors -- for the streams that converged
-    for (unsigned k = 0; k < nf; ++k) active[k] = converged[k] ? 1u : 0u;
-    HIP_TRY(hipMemcpyAsync(d_active, active.data(), (size_t)nf * 4, hipMemcpyHostToDevice, s));
+    // (a vector of its own: the last refinement pass may still have an upload of `active` in flight from pageable memory)
+    std::vector<unsigned> emit_active(nf);
+    for (unsigned k = 0; k < nf; ++k) emit_active[k] = converged[k] ? 1u : 0u;
+    HIP_TRY(hipMemcpyAsync(d_active, emit_active.data(), (size_t)nf * 4, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(c->b_cnt.p, d_nblocks, total_slots * 4, hipMemcpyDeviceToDevice, s));
     unsigned long long* d_bb = (unsigned long long*)c->b_prop.p;          // (the proposals are dead: same buffer)
     HIP_TRY(E::launch_scan_u32((const uint32_t*)c->b_cnt.p, d_bb, total_slots, (unsigned long long*)c->e_tmp.p, s));
@@ -1403,6 +1409,13 @@ try {
     // 5 MB scan costs the host 0.3-0.5 ms, a third of the whole call.  n is the upper bound until then.
     const uint8_t* scan = data + setup.scan_pos;
     size_t n = len - setup.scan_pos;
+    {
+        // A file may carry a long tail behind its scan (a second image, appended data): what is uploaded, counted and allocated
+        // for is capped at what the frame's blocks can take at most -- 64 coefficients of a 16-bit code plus 11 value bits
+        // each, every byte stuffed: 432 bytes per block.  All blocks are decoded within that many bytes or the stream is bad.
+        const size_t cap = (total / 64) * 432 + 4096;
+        if (n > cap) n = cap;
+    }
     if (n == 0 || n < c->h_min_bytes) return read_jpeg_host_to_device(c, data, len, info, d_coeffs, total);
 
     hipStream_t s = c->stream;
@@ -1738,9 +1751,11 @@ try {
             if (!tabs) return;
             // (the file goes up from its first scan byte to its end: the device finds the marker that ends the entropy-coded segment)
             const uint8_t* scan = data[i] + cd.ff.setup.scan_pos;
-            const size_t ns = len[i] - cd.ff.setup.scan_pos;
+            size_t ns = len[i] - cd.ff.setup.scan_pos;
             const size_t nblk = (size_t)fi.mcu_cols * fi.mcu_rows * (size_t)fi.blocks_per_mcu;
-            if (ns == 0 || ns >= 0xFFFFFFFFull || nblk > 4 * len[i] || nblk >= 0xFFFFFFFFull) return;
+            if (ns == 0 || nblk > 4 * len[i] || nblk >= 0xFFFFFFFFull) return;
+            ns = std::min(ns, nblk * 432 + 4096);          // a long tail behind the scan is not uploaded (see jpezy_read_jpeg_gpu)
+            if (ns >= 0xFFFFFFFFull) return;
             cd.ff.index = i; cd.ff.scan = scan; cd.ff.n = ns;
             cd.good = true;
         };
@@ -1875,7 +1890,12 @@ try {
         w->is_batch_child = true;
         c->workers.push_back(w);
     }
-    for (int k = 0; k < nw; ++k) c->workers[k]->h_min_bytes = c->h_min_bytes;
+    // the per-file workers decode the files the grouped form declines: same knobs as the parent, or one batch would mix modes
+    for (int k = 0; k < nw; ++k) {
+        c->workers[k]->h_min_bytes = c->h_min_bytes;
+        c->workers[k]->dec_tolerance = c->dec_tolerance;
+        c->workers[k]->force_exact = c->force_exact;
+    }
     std::vector<std::string> msg((size_t)n);
     auto work = [&](int k) {
         jpezy_ctx* w = c->workers[(size_t)k];

@@ -24,6 +24,7 @@
 #include <atomic>
 #include <condition_variable>
 #include <cstring>
+#include <exception>
 #include <functional>
 #include <mutex>
 #include <string>
@@ -80,6 +81,26 @@ public:
         std::vector<ChunkPlan> plans((size_t)n_chunks);
         for (int c = 0; c < n_chunks; ++c) plans[(size_t)c] = plan(c);
 
+        if (n_chunks == 1) {
+            // a call that fits one chunk (small frames): nothing to overlap -- the plain staged copy on the calling thread,
+            // without six thread starts and their event round trips
+            for (const Segment& sg : plans[0].in) std::memcpy(pin_in_[0] + sg.slot_off, sg.host, sg.bytes);
+            for (const Segment& sg : plans[0].in) {
+                e = hipMemcpyAsync(dev_in_[0] + sg.slot_off, pin_in_[0] + sg.slot_off, sg.bytes, hipMemcpyHostToDevice, compute);
+                if (e != hipSuccess) { if (err) *err = "host pipeline: hipMemcpyAsync (upload) failed"; return e; }
+            }
+            e = kernel(0, dev_in_[0], dev_out_[0], compute);
+            for (const Segment& sg : plans[0].out) {
+                if (e != hipSuccess) break;
+                e = hipMemcpyAsync(pin_out_[0] + sg.slot_off, dev_out_[0] + sg.slot_off, sg.bytes, hipMemcpyDeviceToHost, compute);
+            }
+            const hipError_t es = hipStreamSynchronize(compute);
+            if (e == hipSuccess) e = es;
+            if (e != hipSuccess) { if (err) *err = std::string("host pipeline: ") + hipGetErrorString(e); return e; }
+            for (const Segment& sg : plans[0].out) std::memcpy(sg.host, pin_out_[0] + sg.slot_off, sg.bytes);
+            return hipSuccess;
+        }
+
         // per-chunk progress: 0 nothing, 1 upload issued, 2 download issued, 3 delivered to the caller
         std::vector<std::atomic<int>> state((size_t)n_chunks);
         for (auto& s : state) s.store(0);
@@ -134,9 +155,33 @@ public:
                 set_state(c, 3);
             }
         };
+        // Joined on every way out of this scope: an exception below (a thread that cannot be started, an allocation, a
+        // throwing kernel callback) first raises `failed` -- the workers' waits all watch it -- and then joins them, instead
+        // of destroying joinable threads (std::terminate) before the C-ABI's catch can turn it into an error code.
         std::vector<std::thread> threads;
-        for (int k = 0; k < n_feed; ++k) threads.emplace_back(feeder, k);
-        for (int k = 0; k < n_drain; ++k) threads.emplace_back(drainer, k);
+        struct Joiner {
+            std::vector<std::thread>& ts;
+            std::atomic<int>& failed;
+            std::condition_variable& cv;
+            ~Joiner()
+            {
+                bool running = false;
+                for (auto& t : ts) running = running || t.joinable();
+                if (running && std::uncaught_exceptions() > 0) {
+                    int expected = 0;
+                    failed.compare_exchange_strong(expected, (int)hipErrorUnknown);
+                    cv.notify_all();
+                }
+                for (auto& t : ts) if (t.joinable()) t.join();
+            }
+        } joiner{ threads, failed, cv };
+        threads.reserve((size_t)(n_feed + n_drain));
+        try {
+            for (int k = 0; k < n_feed; ++k) threads.emplace_back(feeder, k);
+            for (int k = 0; k < n_drain; ++k) threads.emplace_back(drainer, k);
+        } catch (const std::exception&) {
+            fail(hipErrorOutOfMemory, "starting a copy thread");
+        }
 
         for (int c = 0; c < n_chunks && !failed.load(); ++c) {
             const int slot = c % RING;

@@ -573,7 +573,9 @@ __device__ __forceinline__ int ld_coef(const int16_t* p)
 // Bound: a wave whose raw coefficients all satisfy |c| <= coef_limit (|c * Q| <= 2^15; otherwise the wave takes the exact path
 // for every sample, as the exact kernel does) has |in[u][v]| <= 2^13, so sum |in| <= 2^19 over a block and the FP32 result of the
 // two butterfly passes (at most 13 roundings on any input->output path, dequantiser constants and level shift rounded once
-// each) is within (13 + 2) * 2^-24 * 2^19 = 0.47 < 1 of the exact sample value: the truncated samples differ by at most one.
+// each) is within (13 + 2) * 2^-24 * 2^19 = 0.47 of the exact sample value; the butterflies' cosine constants are FP32
+// roundings too (relative 2^-24 each on up to two factors per path: another 0.25 ... 0.4 by the same norm-wise count), so the
+// rigorous figure is 0.7 ... 0.9 -- still below 1: the truncated samples differ by at most one.
 // MODE: 0 = exact, with the coefficient range test; 1 = exact, no range test (8-bit quantiser tables: see launch_dequant_idct);
 // 2 = tolerance mode (always with the range test: the FP32 bound above needs it)
 template <bool GRAY, bool ALIGNED, bool FORCE_EXACT, int MODE>

@@ -459,3 +459,24 @@ def test_decode_jpeg_batch_large_planes(J, ctx, oracle):
             for q in (1, 2, 3):
                 assert np.array_equal(got[i][q], one[q]), (i, q)
 
+
+
+def test_long_tail_behind_the_scan_is_not_decoded_or_uploaded(J, ctx, oracle):
+    """a file with megabytes behind its EOI (a second image, appended data -- 0xFF bytes and marker look-alikes
+    included) decodes to the same coefficients as the file without them, single file and batch; the part that goes up to the
+    device is capped by what the frame's blocks can take (432 bytes per block)."""
+    W, H = 256, 128
+    r, g, b = oracle.synth_rgb(W, H, frame=11)
+    jpg = oracle.encode_jpeg(r, g, b, W, H)
+    rng = np.random.default_rng(3)
+    tail = rng.integers(0, 256, 6 << 20, dtype=np.uint8).tobytes()
+    second = oracle.encode_jpeg(*oracle.synth_rgb(W, H, frame=12), W, H)
+    info, want = J.read_jpeg(jpg)
+    for extra in (tail, second + tail, b"\xff" * 100000, b"\xff\x00" * 50000):
+        ginfo, got = ctx.read_jpeg_gpu(jpg + extra)
+        assert ctx.last_huffdec_passes() > 0
+        assert np.array_equal(got.cpu().numpy(), want)
+    want_planes = oracle.decode_jpeg(jpg, False)
+    for info2, rr, gg, bb in ctx.decode_jpeg_batch([jpg + tail, jpg, jpg + second], gray=False):
+        for a, e in zip((rr, gg, bb), want_planes[-3:]):
+            assert np.array_equal(a, np.asarray(e).reshape(-1)[: W * H])

@@ -154,3 +154,48 @@ def test_config4_gray_8k_decode(J, tctx, oracle):
     got = tctx.dequant_idct(co6, W, H, gray=True)
     assert _maxdiff(got, ref) <= TOLERANCE
     assert np.array_equal(got[0], got[1]) and np.array_equal(got[0], got[2])
+
+
+def test_all_coefficients_at_the_int16_extremes_with_q255(J, tctx, oracle):
+    """the largest dequantised magnitudes the exact fast path may see -- every one of the 64 coefficients at
+    +-32767 / -32768 with Q = 255 (|c * Q| = 2^23: 8-bit tables have no range test), luma and chroma blocks, sign patterns that
+    maximise single samples (the sign of every basis function at a chosen pixel) and alternating ones -- bit-exact in the
+    default mode, within one in tolerance mode (there the range test sends such waves to the exact path)."""
+    W, H = 64, 32
+    mc, mr = J.mcu_grid(W, H)
+    cosx = np.array([[np.cos((2 * x + 1) * u * np.pi / 16) for x in range(8)] for u in range(8)])
+    zz = oracle.constants()["zz"]
+    co = np.zeros((mr, mc, 6, 64), np.int16)
+    rng = np.random.default_rng(255)
+    k = 0
+    for my in range(mr):
+        for mx in range(mc):
+            for b in range(6):
+                if k % 4 == 0:       # the sign pattern that piles every term up at pixel (y, x)
+                    y, x = int(rng.integers(8)), int(rng.integers(8))
+                    sgn = np.sign(np.outer(cosx[:, y], cosx[:, x])).reshape(64)       # natural order [v][u]
+                    nat = np.where(sgn >= 0, 32767, -32768)
+                elif k % 4 == 1:
+                    nat = np.where(np.arange(64) % 2 == 0, 32767, -32768)
+                elif k % 4 == 2:
+                    nat = np.full(64, -32768)
+                else:
+                    nat = rng.choice(np.array([32767, -32768]), 64)
+                co[my, mx, b] = nat[zz]                                           # zig-zag position n holds natural index zz[n]
+                k += 1
+    qtab = type(J.api.annex_k_tables().qt)()
+    info = oracle.make_info(W, H)
+    for t in range(4):
+        for i in range(64):
+            qtab[t][i] = 255
+            info.qt[t][i] = 255
+    exact = J.Context(0)
+    try:
+        for gray in (False, True):
+            want = oracle.decode_planes(co, info, gray)
+            got = exact.dequant_idct(co, W, H, qt=qtab, gray=gray)
+            for a, e in zip(got, want):
+                assert np.array_equal(a, e)
+            assert _maxdiff(tctx.dequant_idct(co, W, H, qt=qtab, gray=gray), want) <= TOLERANCE
+    finally:
+        exact.close()

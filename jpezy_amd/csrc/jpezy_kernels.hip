@@ -558,6 +558,9 @@ __device__ __forceinline__ int ld_coef(const int16_t* p)
     return v;
 }
 
+#ifndef JPEZY_DEC_FULLLINE
+#define JPEZY_DEC_FULLLINE 1          // colour planes leave as whole 128-byte lines (see the store section of dequant_idct_kernel)
+#endif
 // waves per SIMD the register budget is set for (colour: 87 VGPRs since the chroma column pass runs after the luma halves)
 #ifndef JPEZY_DEC_WAVES
 #define JPEZY_DEC_WAVES 5
@@ -958,9 +961,11 @@ __global__ __launch_bounds__(64 * WPB, GRAY ? JPEZY_DEC_WAVES_GRAY : JPEZY_DEC_W
 #pragma unroll
         for (int q = 0; q < 4; ++q) Rw[q] = Gw[q] = Bw[q] = clamp_pack4(Y + 4 * q);
     }
-#ifdef JPEZY_DEC_FULLLINE
-    // Experiment (round 3): the two waves of a workgroup hold the two 64-byte halves of every 128-byte line of their 16 pixel rows.
-    // They swap through LDS so that wave 0 stores rows 0..7 and wave 1 rows 8..15 of BOTH quads: eight lanes = one whole line.
+#if JPEZY_DEC_FULLLINE
+    // The two waves of a workgroup hold the two 64-byte halves of every 128-byte line of their 16 pixel rows.  They swap through
+    // LDS so that wave 0 stores rows 0..7 and wave 1 rows 8..15 of BOTH quads: eight lanes = one whole line.  The launch takes the
+    // same time either way (34.2 us per 4096^2 frame, three interleaved rounds), but half-line non-temporal stores are counted --
+    // and moved -- as 63.8 MB of writes for 50.3 MB of planes; whole lines bring WRITE_SIZE to 49.2 MB (profiles/r04_dec_traffic.txt).
     if (ALIGNED && !GRAY && WPB == 2) {
         const unsigned q0 = blockIdx.x * 2u;                                         // the workgroup's first quad
         const int qx0 = (int)q0 - (int)fast_div(q0, p.qpr_magic, p.qpr_shift) * p.quads_per_row;

@@ -62,14 +62,12 @@ typedef float f2 __attribute__((ext_vector_type(2)));   // an aligned VGPR (or S
 // loads its own 64-byte segments of 16 rows per instruction straight into registers -- the shape the texture addresser
 // handles worst (tools/ubench/mem_pattern.hip: the kernel's memory pattern alone, no arithmetic, 22.4 us per 4096^2
 // frame in that shape against 19.4 us in whole 256-byte pieces).
-#ifndef JPEZY_EWPB
-#define JPEZY_EWPB 4
-#endif
+// The launcher picks the 4-wave form where a row of quads divides into groups of four (4096 and 7680 wide frames: 64 and 120
+// quads per row) and 2-wave workgroups with direct loads elsewhere (1920 wide: 30 quads -- groups of four would leave two of
+// every 32 wave slots idle, measured +3.8 % on the 32 x 1080p batch).
 #ifndef JPEZY_COOP_LOAD
 #define JPEZY_COOP_LOAD 1
 #endif
-constexpr int EWPB = JPEZY_EWPB;
-static_assert(!JPEZY_COOP_LOAD || EWPB == 4, "the cooperative load is written for 4 waves: 4 x 4 rows of 256 bytes");
 
 // Level-1 guard bands on t = v/Q: DeviceTables::delta1[table][j].  Norm-wise bound of the FP32 error of F[i][j]:
 // gamma_13 * sum|cos_i| * sum|cos_j| * 128 (at most 13 roundings on any input->output path, u = 2^-24), times the
@@ -459,7 +457,7 @@ __device__ __forceinline__ float pick(const f2* A, int x) { return x < 4 ? A[x].
 #define PHASE_STAMP(k) do { } while (0)
 #endif
 
-template <bool GRAY, bool ALIGNED, int FORCE>
+template <bool GRAY, bool ALIGNED, int FORCE, int EWPB>
 __global__ __launch_bounds__(64 * EWPB, JPEZY_F32_WAVES) void fdct_quant_f32_kernel(EncParams p)
 {
 #if defined(JPEZY_TRACE) && JPEZY_TRACE >= 3
@@ -468,7 +466,7 @@ __global__ __launch_bounds__(64 * EWPB, JPEZY_F32_WAVES) void fdct_quant_f32_ker
     PHASE_STAMP(0);
     __shared__ __attribute__((aligned(16))) uint32_t lds_all[EWPB][WAVE_LDS_DWORDS];
     constexpr int BPM = GRAY ? 4 : 6;
-    constexpr bool COOP = ALIGNED && JPEZY_COOP_LOAD;
+    constexpr bool COOP = ALIGNED && EWPB == 4 && JPEZY_COOP_LOAD;     // (the cooperative load is written for 4 waves: 4 x 4 rows of 256 bytes)
     static_assert(!COOP || 3 * 4096 <= EWPB * WAVE_LDS_DWORDS * 4, "the pixel staging area lies over the waves' slices");
 
     // WPB waves per workgroup; the wave index is made an SGPR so that everything derived from it (quad position, plane
@@ -860,32 +858,39 @@ __global__ __launch_bounds__(64 * EWPB, JPEZY_F32_WAVES) void fdct_quant_f32_ker
 
 }  // namespace f32
 
-template <bool GRAY, bool ALIGNED>
+template <bool GRAY, bool ALIGNED, int EW>
 static void enc_f32_launch2(const EncParams& p, int force, dim3 grid, hipStream_t s)
 {
     if (force == 1)
-        hipLaunchKernelGGL((f32::fdct_quant_f32_kernel<GRAY, ALIGNED, 1>), grid, dim3(64 * f32::EWPB), 0, s, p);
+        hipLaunchKernelGGL((f32::fdct_quant_f32_kernel<GRAY, ALIGNED, 1, EW>), grid, dim3(64 * EW), 0, s, p);
     else if (force == 2)
-        hipLaunchKernelGGL((f32::fdct_quant_f32_kernel<GRAY, ALIGNED, 2>), grid, dim3(64 * f32::EWPB), 0, s, p);
+        hipLaunchKernelGGL((f32::fdct_quant_f32_kernel<GRAY, ALIGNED, 2, EW>), grid, dim3(64 * EW), 0, s, p);
     else if (force == 3)
-        hipLaunchKernelGGL((f32::fdct_quant_f32_kernel<GRAY, ALIGNED, 3>), grid, dim3(64 * f32::EWPB), 0, s, p);
+        hipLaunchKernelGGL((f32::fdct_quant_f32_kernel<GRAY, ALIGNED, 3, EW>), grid, dim3(64 * EW), 0, s, p);
     else
-        hipLaunchKernelGGL((f32::fdct_quant_f32_kernel<GRAY, ALIGNED, 0>), grid, dim3(64 * f32::EWPB), 0, s, p);
+        hipLaunchKernelGGL((f32::fdct_quant_f32_kernel<GRAY, ALIGNED, 0, EW>), grid, dim3(64 * EW), 0, s, p);
 }
 
 hipError_t launch_fdct_quant_f32(const EncParams& p0, bool gray, int force, hipStream_t stream)
 {
     EncParams p = p0;
-    p.groups_per_row = (p.quads_per_row + f32::EWPB - 1) / f32::EWPB;
+    const bool al = (p.W % 16 == 0) && (p.plane_stride % 16 == 0) &&
+                    (((uintptr_t)p.r | (uintptr_t)p.g | (uintptr_t)p.b) % 16 == 0);
+    // four quads per workgroup with the cooperative load where the rows divide evenly, two with direct loads elsewhere
+    const int ew = (al && JPEZY_COOP_LOAD && p.quads_per_row % 4 == 0) ? 4 : 2;
+    p.groups_per_row = (p.quads_per_row + ew - 1) / ew;
     const long groups = (long)p.mcu_rows * p.groups_per_row;
     if (groups <= 0 || p.n_frames <= 0) return hipSuccess;
     if (p.n_frames > 65535) return hipErrorInvalidValue;               // grid.y limit; callers chunk larger batches
     fast_div_setup((unsigned)p.groups_per_row, &p.gpr_magic, &p.gpr_shift);
     const dim3 grid((unsigned)groups, (unsigned)p.n_frames);
-    const bool al = (p.W % 16 == 0) && (p.plane_stride % 16 == 0) &&
-                    (((uintptr_t)p.r | (uintptr_t)p.g | (uintptr_t)p.b) % 16 == 0);
-    if (gray) { if (al) enc_f32_launch2<true, true>(p, force, grid, stream); else enc_f32_launch2<true, false>(p, force, grid, stream); }
-    else      { if (al) enc_f32_launch2<false, true>(p, force, grid, stream); else enc_f32_launch2<false, false>(p, force, grid, stream); }
+    if (ew == 4) {
+        if (gray) enc_f32_launch2<true, true, 4>(p, force, grid, stream); else enc_f32_launch2<false, true, 4>(p, force, grid, stream);
+    } else if (gray) {
+        if (al) enc_f32_launch2<true, true, 2>(p, force, grid, stream); else enc_f32_launch2<true, false, 2>(p, force, grid, stream);
+    } else {
+        if (al) enc_f32_launch2<false, true, 2>(p, force, grid, stream); else enc_f32_launch2<false, false, 2>(p, force, grid, stream);
+    }
     return hipGetLastError();
 }
 

@@ -1,6 +1,6 @@
 // jpezy_huffdec_core.h -- the part of the GPU Huffman decoder that is plain arithmetic: the table format, the host-side
 // table builder and the one-symbol decode step.  Included by the kernels (jpezy_huffdec.hip, through jpezy_huffdec.h), by the
-// context code that builds the tables (jpezy_capi.hip) and -- compiled by g++ with AddressSanitizer and UBSan, no HIP involved --
+// context code that builds the tables (jpezy_capi_huffdec.hip) and -- compiled by g++ with AddressSanitizer and UBSan, no HIP involved --
 // by tests/fuzz/huffdec_core_fuzz.cpp, which walks whole scans with the same step and compares with the host decoder
 // (the CPU test suite's view of the round-3 decoder: tests/test_host_codec.py).
 #pragma once

@@ -54,7 +54,11 @@ def test_golden_fixtures(J, ctx, golden_dir, name):
 
 
 SIZES = [(1, 1), (7, 5), (16, 16), (15, 17), (31, 33), (64, 64), (65, 47), (100, 100), (256, 16), (16, 256),
-         (129, 255), (640, 480), (720, 486)]
+         (129, 255), (640, 480), (720, 486),
+         # widths whose rows of quads divide by four take the 4-wave workgroups with the cooperative 256-byte row loads:
+         # whole groups (1024), a last quad with one live MCU (976 = 61 MCUs), pieces clamped inside a group (208 = 13 MCUs),
+         # a bottom band shorter than an MCU row; 1920 x 24 takes the 2-wave form next to them
+         (1024, 16), (976, 33), (208, 40), (2048, 7), (1920, 24)]
 
 
 @pytest.mark.parametrize("size", SIZES)

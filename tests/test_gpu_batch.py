@@ -199,3 +199,52 @@ def test_one_frame_split_by_mcu_row_bands_on_the_gpu(oracle, W, H, gray, band_ro
             assert np.array_equal(got[lo:hi].cpu().numpy().reshape(-1), np.ascontiguousarray(want).reshape(-1))
     finally:
         ctx.close()
+
+
+_RCCL_WORLD1 = r'''
+import os, sys
+import numpy as np
+import torch
+import torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+import jpezy_amd as J
+from jpezy_amd import sharding
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+torch.cuda.set_device(0)
+dev = torch.device("cuda", 0)
+dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%s" % sys.argv[2], rank=0, world_size=1)
+try:
+    W, H, F = 256, 64, 5
+    cpf = J.coeff_count(W, H)
+    g = torch.Generator(device=dev); g.manual_seed(7)
+    planes = [torch.randint(0, 256, (F, W * H), dtype=torch.uint8, device=dev, generator=g) for _ in range(3)]
+    ctx = J.Context(0)
+    local = torch.empty((F, cpf), dtype=torch.int16, device=dev)
+    ctx.fdct_quant_dev(planes[0], planes[1], planes[2], W, H, local, n_frames=F, plane_stride=W * H)
+    # the monolithic gather is ONE RCCL all_gather (world 1: a device-to-device copy by an RCCL kernel of this process's
+    # communicator); padded shards as at N > 1
+    full = sharding.gather_coefficients(local.reshape(-1), F, cpf)
+    t = torch.ones(1, device=dev)
+    dist.all_reduce(t)
+    torch.cuda.synchronize()
+    assert torch.equal(full, local) and float(t[0]) == 1.0
+    print("rccl world 1 ok", dist.get_backend())
+finally:
+    dist.destroy_process_group()
+'''
+
+
+def test_rccl_communicator_and_all_gather_on_one_gpu(tmp_path):
+    """What a one-GPU box can execute of RCCL: the nccl backend's communicator is created for this GPU and the monolithic
+    coefficient gather (`sharding.gather_coefficients`: one all_gather, byte-typed, padded shards) and an all_reduce run through
+    it at world size 1 -- the library, the HSA IPC mode and torch's binding are exercised; links between GPUs are not (no
+    multi-GPU number exists, DESIGN.md section 8).  In a subprocess: the default process group must not leak into the suite."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    script = tmp_path / "rccl_world1.py"
+    script.write_text(_RCCL_WORLD1)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    p = subprocess.run([sys.executable, str(script), str(ROOT), str(port)], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
+    assert "rccl world 1 ok nccl" in p.stdout

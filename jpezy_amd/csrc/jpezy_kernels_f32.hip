@@ -353,9 +353,6 @@ __device__ __forceinline__ int dc_lookup(float sum, const signed char* dcq)
 __device__ __forceinline__ void quant_block_column(const f2* F, const f2* ks, f2 dd, float th, int j, int dc,
                                                    bool live, char* base, uint32_t zz_lo, uint32_t zz_hi, int blk_off, int blk,
                                                    unsigned* queue, bool force
-#ifdef JPEZY_ZZ_HOIST
-                                                   , const unsigned* zaddr
-#endif
 #ifdef JPEZY_DUMP_T
                                                    , float* dump_quad
 #endif
@@ -413,13 +410,9 @@ __device__ __forceinline__ void quant_block_column(const f2* F, const f2* ks, f2
 #pragma unroll
     for (int pp = 1; pp <= 8; ++pp) {      // p = 0 last: it waits for the DC lookup
         const int p = pp & 7;
-#ifdef JPEZY_ZZ_HOIST
-        typedef __attribute__((address_space(3))) int16_t lds_i16;
-        *reinterpret_cast<lds_i16*>(zaddr[p] + (unsigned)blk_off) = (int16_t)q[p];
-#else
+        // (one SDWA add per store; the eight addresses formed once per lane and kept in registers measured 1 us slower)
         const uint32_t off = ((p < 4 ? zz_lo : zz_hi) >> (8 * (p & 3))) & 0xFFu;
         *reinterpret_cast<int16_t*>(base + off + blk_off) = (int16_t)q[p];
-#endif
     }
 }
 
@@ -654,19 +647,6 @@ __global__ __launch_bounds__(64 * EWPB, JPEZY_F32_WAVES) void fdct_quant_f32_ker
     const uint32_t zz_lo = lcol->zz_lo, zz_hi = lcol->zz_hi;
     const signed char* dcq_l = p.dcq_luma;
     const signed char* dcq_c = p.dcq_chroma;
-#ifdef JPEZY_ZZ_HOIST
-    // the eight staging addresses of this lane's block column, formed once (the three blocks are immediates apart); the
-    // empty asm keeps hipcc from re-deriving them at every store
-    unsigned zaddr[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        zaddr[k] = (unsigned)(uintptr_t)sbase + (((k < 4 ? zz_lo : zz_hi) >> (8 * (k & 3))) & 0xFFu);
-        asm("" : "+v"(zaddr[k]));
-    }
-#define ZZ_ARG , zaddr
-#else
-#define ZZ_ARG
-#endif
     {
         f2 ks[4];
 #pragma unroll
@@ -677,14 +657,14 @@ __global__ __launch_bounds__(64 * EWPB, JPEZY_F32_WAVES) void fdct_quant_f32_ker
             f2 F[4];
             fdct8p(TP, F, kc);
             const int dc_top = dc_lookup(F[0].x, dcq_l);
-            quant_block_column(F, ks, dd, th, j, dc_top, live, sbase, zz_lo, zz_hi, 0, m * BPM + bx, queue, FORCE != 0 ZZ_ARG DUMP_ARG);
+            quant_block_column(F, ks, dd, th, j, dc_top, live, sbase, zz_lo, zz_hi, 0, m * BPM + bx, queue, FORCE != 0 DUMP_ARG);
         }
         __builtin_amdgcn_sched_barrier(0);
         {
             f2 F[4];
             fdct8p(BT, F, kc);
             const int dc_bot = dc_lookup(F[0].x, dcq_l);
-            quant_block_column(F, ks, dd, th, j, dc_bot, live, sbase, zz_lo, zz_hi, 2 * STG_BLK, m * BPM + 2 + bx, queue, FORCE != 0 ZZ_ARG DUMP_ARG);
+            quant_block_column(F, ks, dd, th, j, dc_bot, live, sbase, zz_lo, zz_hi, 2 * STG_BLK, m * BPM + 2 + bx, queue, FORCE != 0 DUMP_ARG);
         }
     }
 
@@ -711,7 +691,7 @@ __global__ __launch_bounds__(64 * EWPB, JPEZY_F32_WAVES) void fdct_quant_f32_ker
 #pragma unroll
         for (int k = 0; k < 4; ++k) ks[k] = f2{ lcol[8].ks[2 * k], lcol[8].ks[2 * k + 1] };
         const f2 dd = { lcol[8].delta1[0], lcol[8].delta1[1] };
-        quant_block_column(Fc, ks, dd, lcol[8].th, j, dc_c, live, sbase, zz_lo, zz_hi, 4 * STG_BLK, m * BPM + 4 + bx, queue, FORCE != 0 ZZ_ARG DUMP_ARG);
+        quant_block_column(Fc, ks, dd, lcol[8].th, j, dc_c, live, sbase, zz_lo, zz_hi, 4 * STG_BLK, m * BPM + 4 + bx, queue, FORCE != 0 DUMP_ARG);
     }
     wave_sync();
     PHASE_STAMP(6);

@@ -34,13 +34,24 @@ int read_jpeg_host_to_device(jpezy_ctx* c, const uint8_t* data, size_t len, jpez
 //     residue (<= 64) or have fallen to 3/4 of the launch before; never more than MAX_LAUNCHES.
 // A file that drops out goes to the host decoder, whose result is the same.
 // (tools/fuzz_huffdec.py with JPEZY_HUFFDEC_DEBUG=1 prints the lanes moved per launch; JPEZY_HUFFDEC_PATIENT=1 lifts the budget.)
+// The numbers are in units of 1,024 bits of stream: with subsequences of L bits a step is 1024 / L times cheaper and a correction has that
+// many more lanes to cross.
 struct RefineBudget {
-    static constexpr int FIRST_STEPS = 8, STEPS = 64, MAX_LAUNCHES = 12;
+    static constexpr int MAX_LAUNCHES = 12;
+    int first_steps, steps;
+    unsigned residue;
+    explicit RefineBudget(unsigned subseq_bits)
+    {
+        const int k = subseq_bits >= 1024u ? 1 : (int)(1024u / subseq_bits);
+        first_steps = 8 * k;
+        steps = 64 * k > 256 ? 256 : 64 * k;
+        residue = 64u * (unsigned)k;
+    }
     // may refinement launch `launch` (1-based, after the first launch) run, given the lanes that moved in the two launches before it?
     bool go_on(int launch, unsigned moved_before, unsigned moved_last) const
     {
         if (launch > MAX_LAUNCHES) return false;
-        if (launch <= 2 || moved_last <= 64u) return true;
+        if (launch <= 2 || moved_last <= residue) return true;
         return (unsigned long long)moved_last * 4u <= (unsigned long long)moved_before * 3u;
     }
 };
@@ -169,14 +180,14 @@ int jpezy_internal_huffdec_streams(jpezy_ctx* c, const std::vector<DevStream>& s
     std::vector<unsigned> active(nf), prev_moved(nf, 0u);
     std::vector<char> converged(nf, 0), dead(nf, 0);
     for (unsigned k = 0; k < nf; ++k) { active[k] = usable[k] ? 1u : 0u; dead[k] = !usable[k]; }
-    RefineBudget budget;
+    const RefineBudget budget(L);
     for (int pass = 0; pass <= RefineBudget::MAX_LAUNCHES; ++pass) {
         bool any = false;
         for (unsigned k = 0; k < nf; ++k) any = any || active[k];
         if (!any) break;
         HIP_TRY(hipMemcpyAsync(d_active, active.data(), (size_t)nf * 4, hipMemcpyHostToDevice, s));
         HIP_TRY(HD::launch_sync_batch(d_S, (const uint32_t*)c->b_U.p, d_F, d_wg_file, d_wg_first, n_wg, d_active, d_exit, d_last, d_nblocks,
-                                      pass == 0 ? RefineBudget::FIRST_STEPS : RefineBudget::STEPS, s));
+                                      pass == 0 ? budget.first_steps : budget.steps, s));
         HIP_TRY(hipMemcpyAsync(F.data(), d_F, sizeof(HD::BatchFile) * nf, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
         for (unsigned k = 0; k < nf; ++k) {
@@ -453,16 +464,16 @@ try {
             if (dbg) dbg_moved.push_back(moved);
             return JPEZY_OK;
         };
-        if (int r2 = pass(RefineBudget::FIRST_STEPS)) return r2;
+        const RefineBudget budget(L);
+        if (int r2 = pass(budget.first_steps)) return r2;
         converged = !pending;
         const unsigned wrong = mv[3];            // proposals the confirmation step did not bear out
         const bool patient = dbg && std::getenv("JPEZY_HUFFDEC_PATIENT") != nullptr;      // diagnostic: show where the launches would have led
         if (!converged && (wrong <= n_sub / 2 + 16 || patient)) {
-            RefineBudget budget;
             unsigned prev = moved;
             for (int it = 1; !converged && (patient ? it <= 40 : budget.go_on(it, prev, moved)); ++it) {
                 prev = moved;
-                if (int r2 = pass(RefineBudget::STEPS)) return r2;
+                if (int r2 = pass(budget.steps)) return r2;
                 converged = !pending;
             }
         }

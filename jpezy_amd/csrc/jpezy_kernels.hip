@@ -558,6 +558,23 @@ __device__ __forceinline__ int ld_coef(const int16_t* p)
     return v;
 }
 
+// floor(x) / floor(-x) as an int in one instruction (v_cvt_flr_i32_f32; asm: the compiler only forms it under fast-math flags)
+__device__ __forceinline__ int cvt_floor(float x)
+{
+    int r;
+    asm("v_cvt_flr_i32_f32_e32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+__device__ __forceinline__ int cvt_floor_neg(float x)
+{
+    int r;
+    asm("v_cvt_flr_i32_f32_e64 %0, -%1" : "=v"(r) : "v"(x));
+    return r;
+}
+#ifndef JPEZY_DEC_INT_COLOUR
+#define JPEZY_DEC_INT_COLOUR 1        // integer colour offsets (step 5 of dequant_idct_kernel); 0: doubles for every wave, as until round 3
+#endif
+constexpr float DEC_CHROMA_BAND = 5e-5f, DEC_CHROMA_GATE = 512.f;      // tests/test_colour_offsets.py
 #ifndef JPEZY_DEC_FULLLINE
 #define JPEZY_DEC_FULLLINE 1          // colour planes leave as whole 128-byte lines (see the store section of dequant_idct_kernel)
 #endif
@@ -934,9 +951,59 @@ __global__ __launch_bounds__(64 * WPB, GRAY ? JPEZY_DEC_WAVES_GRAY : JPEZY_DEC_W
         }
     }
 
-    // ---- 5. YCbCr -> RGB in the reference's exact order (ref :567-578), clamp, pack, store ----
+    // ---- 5. YCbCr -> RGB (ref :567-578), clamp, pack, store ----
+    // Y, U = Cb - 128, V = Cr - 128 are integers, so each of r = Y + 1.402 V, g = Y - 0.3441 U - 0.7139 V, b = Y + 1.7718 U is Y plus a
+    // term of the chroma sample alone, and revise_value(trunc(Y + t)) == clamp(Y + floor(t)) unless t is an integer whose double
+    // evaluation may fall on either side (negative values clamp to 0 under both roundings).  1.402 V is a multiple of 0.002 and
+    // 1.7718 U of 0.0002 -- integral only at zero, where the products are exact --, and c = 0.3441 U + 0.7139 V is a multiple of
+    // 0.0001: integral for one pair in 10,000.  Round 4: three integer offsets per chroma sample from FP32 arithmetic (floor-
+    // converting v_cvt_flr_i32_f32: the FP32 error is below 3.4e-5 inside |U|, |V| <= 512, a third of the lattice spacing), three
+    // integer additions per pixel; a chroma sample whose c is within 5e-5 of a NON-ZERO integer is one of those pairs (U = V = 0,
+    // every gray pixel, has c = 0 exactly and the reference subtracts two zeros), and a wave that holds one -- or a chroma sample
+    // outside the gate, or forced samples (their range is not bounded) -- converts in doubles, the reference's own sequence, as
+    // every wave did before.  tests/test_colour_offsets.py enumerates every pair inside the gate: offsets equal to the integer
+    // floors, flags equal to the integral pairs, results equal to the reference's formula.  (The conversion was 236 of the kernel's
+    // 767 vector instructions, all of the slow class: 34.2 -> see DESIGN.md 4.2.)
     uint32_t Rw[4], Gw[4], Bw[4];
+    bool int_colour = false;
+#if JPEZY_DEC_INT_COLOUR
     if (!GRAY) {
+        int oR[8], oG[8], oB[8];
+        float kmin = 2.f, amax = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const float uf = (float)Cb[c], vf = (float)Cr[c];
+            const float cc = FMAF(0.3441f, uf, 0.7139f * vf);
+            oR[c] = cvt_floor(1.402f * vf);
+            oB[c] = cvt_floor(1.7718f * uf);
+            oG[c] = cvt_floor_neg(cc);
+            const float n = __builtin_rintf(cc);                                           // v_rndne_f32
+            kmin = __builtin_fminf(kmin, __builtin_fmaxf(__builtin_fabsf(cc - n), 1.f - __builtin_fabsf(n)));
+            amax = __builtin_fmaxf(__builtin_fmaxf(amax, __builtin_fabsf(uf)), __builtin_fabsf(vf));
+        }
+        int_colour = !force && !wave_any(kmin <= DEC_CHROMA_BAND || !(amax <= DEC_CHROMA_GATE));
+        if (int_colour) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                int ri[4], gi[4], bi[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int c = 2 * q + (k >> 1);
+                    ri[k] = Y[4 * q + k] + oR[c];
+                    gi[k] = Y[4 * q + k] + oG[c];
+                    bi[k] = Y[4 * q + k] + oB[c];
+                }
+                Rw[q] = clamp_pack4(ri);
+                Gw[q] = clamp_pack4(gi);
+                Bw[q] = clamp_pack4(bi);
+            }
+        }
+    }
+#endif
+    if (GRAY) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) Rw[q] = Gw[q] = Bw[q] = clamp_pack4(Y + 4 * q);
+    } else if (!int_colour) {              // the reference's exact order in doubles
 #pragma unroll
         for (int q = 0; q < 4; ++q) {              // four pixels = two chroma samples -> one word of each plane
             int ri[4], gi[4], bi[4];
@@ -957,9 +1024,6 @@ __global__ __launch_bounds__(64 * WPB, GRAY ? JPEZY_DEC_WAVES_GRAY : JPEZY_DEC_W
             Gw[q] = clamp_pack4(gi);
             Bw[q] = clamp_pack4(bi);
         }
-    } else {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) Rw[q] = Gw[q] = Bw[q] = clamp_pack4(Y + 4 * q);
     }
 #if JPEZY_DEC_FULLLINE
     // The two waves of a workgroup hold the two 64-byte halves of every 128-byte line of their 16 pixel rows.  They swap through

@@ -363,16 +363,16 @@ try {
     hipStream_t s = c->stream;
     const size_t chunk = HD::chunk_bytes(), nc = (n + chunk - 1) / chunk;
     const unsigned L = HD::subseq_bits();
-    const unsigned n_sub_max = (unsigned)((n * 8 + L - 1) / L);      // before the stuffing is removed; buffers are sized for it
+    const unsigned n_sub_max = (unsigned)((n * 8 + L - 1) / L);      // before the stuffing is removed; buffers and launches are sized for it
     unsigned n_sub = n_sub_max;
-    const size_t u_bytes = ((size_t)n_sub * L / 8 + 64 + 3) & ~(size_t)3;
+    const size_t u_bytes = ((size_t)n_sub_max * L / 8 + 64 + 3) & ~(size_t)3;
     if (int r2 = c->h_scan.reserve(n + 64)) return r2;
     if (int r2 = c->h_U.reserve(u_bytes)) return r2;
     if (int r2 = c->h_cnt.reserve(std::max(nc, (size_t)n_sub) * sizeof(uint32_t))) return r2;
     if (int r2 = c->h_off.reserve((std::max(nc, (size_t)n_sub) + 1) * sizeof(unsigned long long))) return r2;
     if (int r2 = c->h_state.reserve((size_t)n_sub * 3 * sizeof(uint32_t))) return r2;
     if (int r2 = c->h_setup.reserve(sizeof(HD::Setup))) return r2;
-    if (int r2 = c->h_small.reserve(64)) return r2;
+    if (int r2 = c->h_small.reserve(sizeof(HD::ScanState))) return r2;
     size_t max_dc = 0;
     for (int i = 0; i < info->ncomp; ++i) max_dc = std::max(max_dc, nmcu * (size_t)(info->H[i] * info->V[i]));
     if (int r2 = c->h_dc.reserve(std::max((2 * max_dc + 2), (size_t)n_sub) * sizeof(unsigned long long))) return r2;
@@ -405,58 +405,72 @@ try {
         S.bpm = period;
         if (!jpezy_dev::huffdec::pack_td_sequence(seq, period, &S.tdmask)) return read_jpeg_host_to_device(c, data, len, info, d_coeffs, total);
     }
-    HIP_TRY(hipMemcpyAsync(c->h_setup.p, &S, sizeof S, hipMemcpyHostToDevice, s));
+    // Round 4: the whole chain below is enqueued with ONE look by the host before the coefficient pass (round 3: three -- after the unstuffing, after
+    // every synchronisation launch).  What the host used to fetch in between -- where the segment ends, how many subsequences hold data -- stays in a
+    // ScanState on the device; launches are sized for the upper bound n_sub_max and their workgroups leave when they lie beyond the data.  A second
+    // synchronisation launch is enqueued blindly behind the first: it leaves at once when the first one settled everything (or found a stream
+    // that does not synchronise).  The tables go up only when they differ from the ones the context already holds (profiles/r04_huffdec_*).
+    if (c->h_setup_host.size() != sizeof S || std::memcmp(c->h_setup_host.data(), &S, sizeof S) != 0) {
+        c->h_setup_host.assign(reinterpret_cast<const uint8_t*>(&S), reinterpret_cast<const uint8_t*>(&S) + sizeof S);
+        // (from the context's own copy: it outlives the asynchronous upload)
+        HIP_TRY(hipMemcpyAsync(c->h_setup.p, c->h_setup_host.data(), sizeof S, hipMemcpyHostToDevice, s));
+    }
     HIP_TRY(hipMemcpyAsync(c->h_scan.p, scan, n, hipMemcpyHostToDevice, s));
 
     // 1. find the end of the segment, remove the byte stuffing
-    unsigned long long* d_marker = (unsigned long long*)c->h_small.p + 4;     // bytes 32..39 of h_small: first marker; 40..47: stuffing bytes removed
+    HD::ScanState* d_st = (HD::ScanState*)c->h_small.p;
     HIP_TRY(hipMemsetAsync(c->h_U.p, 0, u_bytes, s));
-    HIP_TRY(hipMemsetAsync(d_marker, 0xFF, sizeof(unsigned long long), s));
-    HIP_TRY(hipMemsetAsync(d_marker + 1, 0, sizeof(unsigned long long), s));
-    HIP_TRY(HD::launch_unstuff_count((const uint8_t*)c->h_scan.p, n, (uint32_t*)c->h_cnt.p, d_marker, s));
+    HIP_TRY(HD::launch_scan_state_init(d_st, s));
+    HIP_TRY(HD::launch_unstuff_count((const uint8_t*)c->h_scan.p, n, (uint32_t*)c->h_cnt.p, d_st, s));
     HIP_TRY(E::launch_scan_u32((const uint32_t*)c->h_cnt.p, (unsigned long long*)c->h_off.p, nc, (unsigned long long*)c->e_tmp.p, s));
-    HIP_TRY(HD::launch_unstuff_copy((const uint8_t*)c->h_scan.p, n, d_marker, (const unsigned long long*)c->h_off.p, (uint8_t*)c->h_U.p, d_marker + 1, s));
-    unsigned long long seg[2] = { 0, 0 };
-    HIP_TRY(hipMemcpyAsync(seg, d_marker, sizeof seg, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    if (seg[0] < n) n = (size_t)seg[0];
-    const unsigned long long removed = seg[1];
-    if (n == 0 || removed > n) return read_jpeg_host_to_device(c, data, len, info, d_coeffs, total);
-    // only the subsequences that hold real data are decoded: behind them U is zero padding, which no decoder ever
-    // falls into step on (a periodic stream), so it would be walked lane by lane
-    n_sub = (unsigned)(((n - removed) * 8 + L - 1) / L);
-    if (n_sub == 0) return read_jpeg_host_to_device(c, data, len, info, d_coeffs, total);
+    HIP_TRY(HD::launch_unstuff_copy((const uint8_t*)c->h_scan.p, n, (const unsigned long long*)c->h_off.p, (uint8_t*)c->h_U.p, d_st, s));
 
-    // 2. synchronisation passes until no exit state changes
+    // 2. speculation: every lane decodes through its own and the next subsequences from a guess; the farthest-travelled proposal for every
+    // boundary becomes the initial exit state (h_dc doubles as the proposal scratch).  Then synchronisation passes until no exit state changes.
     uint32_t* d_exit = (uint32_t*)c->h_state.p;
-    uint32_t* d_last = d_exit + n_sub;
-    unsigned* d_nblocks = (unsigned*)(d_last + n_sub);
-    unsigned* d_changed = (unsigned*)c->h_small.p + 4;     // [0] lanes that moved, [1] lanes left pending, [2] moved workgroup boundaries (bytes 16..31 of h_small)
-    unsigned* d_error = (unsigned*)c->h_small.p + 1;
-    unsigned long long* d_lastbit = (unsigned long long*)c->h_small.p + 1;
-    // speculation: every lane decodes through its own and the next 12 subsequences from a guess; the farthest-travelled
-    // proposal for every boundary becomes the initial exit state (h_dc doubles as the proposal scratch)
-    HIP_TRY(HD::launch_speculate((const HD::Setup*)c->h_setup.p, (const uint32_t*)c->h_U.p, u_bytes / 4, n_sub,
+    uint32_t* d_last = d_exit + n_sub_max;
+    unsigned* d_nblocks = (unsigned*)(d_last + n_sub_max);
+    HIP_TRY(HD::launch_speculate((const HD::Setup*)c->h_setup.p, (const uint32_t*)c->h_U.p, u_bytes / 4, n_sub_max, d_st,
                                  (unsigned long long*)c->h_dc.p, d_exit, d_last, d_nblocks, s));
+    HD::ScanState st;
     std::vector<uint32_t> dbg_spec;
     std::vector<unsigned> dbg_moved;
     const bool dbg = std::getenv("JPEZY_HUFFDEC_DEBUG") != nullptr;
     if (dbg) {
-        dbg_spec.resize(n_sub);
-        HIP_TRY(hipMemcpyAsync(dbg_spec.data(), d_exit, (size_t)n_sub * 4, hipMemcpyDeviceToHost, s));
+        dbg_spec.resize(n_sub_max);
+        HIP_TRY(hipMemcpyAsync(dbg_spec.data(), d_exit, (size_t)n_sub_max * 4, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
     }
+    const RefineBudget budget(L);
+    auto sync_launch = [&](unsigned* changed, const unsigned* prev, int max_inner) -> hipError_t {
+        return HD::launch_sync((const HD::Setup*)c->h_setup.p, (const uint32_t*)c->h_U.p, u_bytes / 4, n_sub_max, d_st, d_exit, d_last, d_nblocks,
+                               changed, prev, max_inner, s);
+    };
+    HIP_TRY(sync_launch(d_st->changed, nullptr, budget.first_steps));           // confirmation + the first propagation steps
+    HIP_TRY(sync_launch(d_st->changed2, d_st->changed, budget.steps));          // refinement launch 1, if there is anything left for it
+    HIP_TRY(hipMemcpyAsync(&st, d_st, sizeof st, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (st.first_marker < n) n = (size_t)st.first_marker;
+    const unsigned long long removed = st.removed;
+    n_sub = st.n_sub;
+    // only the subsequences that hold real data were decoded: behind them U is zero padding, which no decoder ever
+    // falls into step on (a periodic stream), so it would be walked lane by lane
+    if (n == 0 || removed > n || n_sub == 0 || n_sub > n_sub_max) return read_jpeg_host_to_device(c, data, len, info, d_coeffs, total);
+
     bool converged = false;
-    int passes = 0;
-    // confirmation and refinement (RefineBudget above)
+    int passes = 1;
     {
-        unsigned moved = 0, mv[4] = { 0, 0, 0, 0 };
-        bool pending = false;        // lanes left with a stale entry state, or a moved workgroup boundary: not the fixed point yet
-        auto pass = [&](int max_inner) -> int {
-            HIP_TRY(hipMemsetAsync(d_changed, 0, sizeof mv, s));
-            HIP_TRY(HD::launch_sync((const HD::Setup*)c->h_setup.p, (const uint32_t*)c->h_U.p, u_bytes / 4, n_sub, d_exit, d_last, d_nblocks,
-                                    d_changed, max_inner, s));
-            HIP_TRY(hipMemcpyAsync(mv, d_changed, sizeof mv, hipMemcpyDeviceToHost, s));
+        unsigned moved = st.changed[0];
+        bool pending = st.changed[1] != 0 || st.changed[2] != 0;        // lanes left with a stale entry state, or a moved workgroup boundary: not the fixed point yet
+        if (dbg) dbg_moved.push_back(moved);
+        converged = !pending;
+        const unsigned wrong = st.changed[3];            // proposals the confirmation step did not bear out
+        const bool patient = dbg && std::getenv("JPEZY_HUFFDEC_PATIENT") != nullptr;      // diagnostic: show where the launches would have led
+        auto pass = [&](int max_inner) -> int {          // further launches, one look each (rare: 1 % of the fuzz corpus)
+            unsigned mv[4] = { 0, 0, 0, 0 };
+            HIP_TRY(hipMemsetAsync(d_st->changed, 0, sizeof mv, s));
+            HIP_TRY(sync_launch(d_st->changed, nullptr, max_inner));
+            HIP_TRY(hipMemcpyAsync(mv, d_st->changed, sizeof mv, hipMemcpyDeviceToHost, s));
             HIP_TRY(hipStreamSynchronize(s));
             moved = mv[0];
             pending = mv[1] != 0 || mv[2] != 0;
@@ -464,18 +478,27 @@ try {
             if (dbg) dbg_moved.push_back(moved);
             return JPEZY_OK;
         };
-        const RefineBudget budget(L);
-        if (int r2 = pass(budget.first_steps)) return r2;
-        converged = !pending;
-        const unsigned wrong = mv[3];            // proposals the confirmation step did not bear out
-        const bool patient = dbg && std::getenv("JPEZY_HUFFDEC_PATIENT") != nullptr;      // diagnostic: show where the launches would have led
-        if (!converged && (wrong <= n_sub / 2 + 16 || patient)) {
+        if (!converged && wrong <= n_sub / 2 + 16) {
+            // the blind launch was refinement launch 1
             unsigned prev = moved;
-            for (int it = 1; !converged && (patient ? it <= 40 : budget.go_on(it, prev, moved)); ++it) {
+            moved = st.changed2[0];
+            pending = st.changed2[1] != 0 || st.changed2[2] != 0;
+            ++passes;
+            if (dbg) dbg_moved.push_back(moved);
+            converged = !pending;
+            for (int it = 2; !converged && (patient ? it <= 40 : budget.go_on(it, prev, moved)); ++it) {
                 prev = moved;
                 if (int r2 = pass(budget.steps)) return r2;
                 converged = !pending;
             }
+        } else if (!converged && patient) {
+            unsigned prev = moved;
+            for (int it = 1; !converged && it <= 40; ++it) {
+                prev = moved;
+                if (int r2 = pass(budget.steps)) return r2;
+                converged = !pending;
+            }
+            (void)prev;
         }
     }
     if (dbg) {
@@ -493,24 +516,18 @@ try {
     if (!converged) return read_jpeg_host_to_device(c, data, len, info, d_coeffs, total);
 
     // 3. global block index of every lane, coefficients, DC predictors
-    HIP_TRY(hipMemcpyAsync(c->h_cnt.p, d_nblocks, (size_t)n_sub * 4, hipMemcpyDeviceToDevice, s));
-    HIP_TRY(E::launch_scan_u32((const uint32_t*)c->h_cnt.p, (unsigned long long*)c->h_off.p, n_sub, (unsigned long long*)c->e_tmp.p, s));
+    HIP_TRY(E::launch_scan_u32((const uint32_t*)d_nblocks, (unsigned long long*)c->h_off.p, n_sub_max, (unsigned long long*)c->e_tmp.p, s));
     HIP_TRY(hipMemsetAsync(d_coeffs, 0, total * sizeof(int16_t), s));
-    HIP_TRY(hipMemsetAsync(d_error, 0, sizeof(unsigned), s));
-    HIP_TRY(hipMemsetAsync(d_lastbit, 0xFF, sizeof(unsigned long long), s));
-    HIP_TRY(HD::launch_emit((const HD::Setup*)c->h_setup.p, (const uint32_t*)c->h_U.p, u_bytes / 4, n_sub, d_exit,
-                            (const unsigned long long*)c->h_off.p, d_coeffs, d_error, d_lastbit, s));
+    HIP_TRY(HD::launch_emit((const HD::Setup*)c->h_setup.p, (const uint32_t*)c->h_U.p, u_bytes / 4, n_sub_max, d_st, d_exit,
+                            (const unsigned long long*)c->h_off.p, d_coeffs, s));
     {   // DC differences -> values, all components in three launches (round 2: gather, two-launch scan, scatter per component = twelve)
         const StreamGeom g = jpezy_internal_stream_geom(*info);
         HIP_TRY(HD::launch_dc_prefix(d_coeffs, g.bpm, g.ncomp, g.cstart, g.ccount, nmcu, (int*)c->h_dc.p, s));
     }
-    unsigned error = 0;
-    unsigned long long last_bit = 0;
-    HIP_TRY(hipMemcpyAsync(&error, d_error, sizeof error, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(&last_bit, d_lastbit, sizeof last_bit, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(&st, d_st, sizeof st, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     // an invalid code, or a last block that is not complete inside the real data: the host decoder decides
-    if (error || last_bit > (unsigned long long)(n - removed) * 8) return read_jpeg_host_to_device(c, data, len, info, d_coeffs, total);
+    if (st.error || st.last_bit > (unsigned long long)(n - removed) * 8) return read_jpeg_host_to_device(c, data, len, info, d_coeffs, total);
     c->h_last_passes = passes;
     return JPEZY_OK;
 }

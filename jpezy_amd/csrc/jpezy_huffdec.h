@@ -51,26 +51,42 @@ hipError_t launch_emit_batch(const Setup* setups, const uint32_t* U, BatchFile* 
 hipError_t launch_stream_per_lane(const Setup* setups, const uint32_t* U, BatchFile* F, unsigned n_files, int16_t* coeffs, hipStream_t s);
 hipError_t launch_dc_prefix_batch(int16_t* coeffs, const BatchFile* F, const unsigned* active, unsigned n_files, hipStream_t s);
 
+// ---- single scan.  Round 4: the whole chain is enqueued without a host synchronisation in between -- the numbers the host used to fetch
+// after the unstuffing (where the segment ends, how many subsequences hold data) stay on the device in a ScanState, which the kernels read.
+struct ScanState {
+    unsigned pad0;
+    unsigned error;                     // emit launch: an invalid code
+    unsigned long long last_bit;        // emit launch: the bit behind the last block (all ones: not reached)
+    unsigned changed[4];                // first synchronisation launch (see launch_sync)
+    unsigned long long first_marker;    // offset of the first marker in the uploaded bytes (all ones: none)
+    unsigned long long removed;         // stuffing bytes removed in front of it
+    unsigned changed2[4];               // second synchronisation launch
+    unsigned n_sub;                     // subsequences that hold data
+    unsigned pad1[3];
+};
+static_assert(sizeof(ScanState) == 80, "ScanState is read back in one copy");
+hipError_t launch_scan_state_init(ScanState* st, hipStream_t s);
 // S: the file from the first byte of the scan on (n_max bytes).  The count launch also finds where the entropy-coded segment ends
-// (*first_marker, which the caller sets to all ones beforehand: offset of the first 0xFF that is followed by anything but 0x00 or is the last
-// byte; still all ones when there is none); the copy launch stops there and leaves the stuffing bytes it removed in totals[0] (the caller
-// sets it to 0 beforehand).
-hipError_t launch_unstuff_count(const uint8_t* S, size_t n_max, uint32_t* counts, unsigned long long* first_marker, hipStream_t s);
-hipError_t launch_unstuff_copy(const uint8_t* S, size_t n_max, const unsigned long long* first_marker, const unsigned long long* removed_before,
-                               uint8_t* U, unsigned long long* totals, hipStream_t s);
+// (st->first_marker: offset of the first 0xFF that is followed by anything but 0x00 or is the last byte; still all ones when there is none);
+// the copy launch stops there and leaves the stuffing bytes it removed and the number of subsequences in st.
+hipError_t launch_unstuff_count(const uint8_t* S, size_t n_max, uint32_t* counts, ScanState* st, hipStream_t s);
+hipError_t launch_unstuff_copy(const uint8_t* S, size_t n_max, const unsigned long long* removed_before, uint8_t* U, ScanState* st, hipStream_t s);
 // speculation pass: fills exit_state with the best available guess of every subsequence's true exit state
-// (proposal: n_sub uint64 of scratch); also puts last_entry and nblocks into their state before the first synchronisation launch
-hipError_t launch_speculate(const Setup* S, const uint32_t* U, size_t u_words, unsigned n_sub, unsigned long long* proposal,
+// (proposal: n_sub_max uint64 of scratch); also puts last_entry and nblocks into their state before the first synchronisation launch.
+// n_sub_max sizes the launches, st->n_sub says which lanes have data.
+hipError_t launch_speculate(const Setup* S, const uint32_t* U, size_t u_words, unsigned n_sub_max, const ScanState* st, unsigned long long* proposal,
                             uint32_t* exit_state, uint32_t* last_entry, unsigned* nblocks, hipStream_t s);
 // u_words: 32-bit words of U that may be read (the rest of a workgroup's window reads as zero)
 // changed[0] += number of lanes whose exit state moved, changed[1] += lanes left pending by the max_inner cut-off, changed[2] += moved lanes that
 // are a workgroup's last (the next workgroup may not have seen the new value), changed[3] += lanes whose first decode of the launch moved their state.  changed[1] == 0 && changed[2] == 0 after a launch: the states are
 // the fixed point, i.e. the sequential decode.  max_inner: propagation steps inside a workgroup (1: every lane decodes once from its
 // predecessor's current exit state and nothing more); a workgroup none of whose lanes has a new entry state leaves at once.
-hipError_t launch_sync(const Setup* S, const uint32_t* U, size_t u_words, unsigned n_sub, uint32_t* exit_state, uint32_t* last_entry,
-                       unsigned* nblocks, unsigned* changed, int max_inner, hipStream_t s);
-hipError_t launch_emit(const Setup* S, const uint32_t* U, size_t u_words, unsigned n_sub, const uint32_t* exit_state,
-                       const unsigned long long* blocks_before, int16_t* out, unsigned* error, unsigned long long* last_bit, hipStream_t s);
+// prev (may be null): the counters of the launch before this one -- nothing pending there, or more than half of the proposals wrong at its
+// first step (a stream that does not synchronise: the host decoder's), and this launch leaves at once: it can be enqueued blindly.
+hipError_t launch_sync(const Setup* S, const uint32_t* U, size_t u_words, unsigned n_sub_max, const ScanState* st, uint32_t* exit_state, uint32_t* last_entry,
+                       unsigned* nblocks, unsigned* changed, const unsigned* prev, int max_inner, hipStream_t s);
+hipError_t launch_emit(const Setup* S, const uint32_t* U, size_t u_words, unsigned n_sub_max, ScanState* st, const uint32_t* exit_state,
+                       const unsigned long long* blocks_before, int16_t* out, hipStream_t s);
 // DC differences -> values for all components of one scan in three launches (component q owns blocks [cstart[q], cstart[q] + ccount[q]) of
 // every MCU); scratch: dc_prefix_scratch_ints(nmcu, largest ccount) ints
 size_t dc_prefix_scratch_ints(size_t nmcu, unsigned max_count);

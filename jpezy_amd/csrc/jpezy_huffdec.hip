@@ -144,13 +144,15 @@ __device__ __forceinline__ void run_subsequence(const uint16_t* tabs, unsigned b
 // i + r is, for growing r, more and more likely the true one.  Every boundary j keeps the proposal of the lane that has
 // come the longest way (largest r; lane 0, whose entry state is the true one, outranks everybody), via atomicMax on
 // (r << 32 | state).  The refinement launches below then only have to confirm these states.
-__global__ __launch_bounds__(WGS) void spec_kernel(const Setup* gS, const uint32_t* U, size_t u_words, unsigned n_sub,
+__global__ __launch_bounds__(WGS) void spec_kernel(const Setup* gS, const uint32_t* U, size_t u_words, const ScanState* st,
                                                    unsigned long long* proposal, unsigned overflow)
 {
     __shared__ Setup S;
     __shared__ uint32_t win[WINDOW_WORDS];
-    load_setup(S, gS);
+    const unsigned n_sub = st->n_sub;
     const unsigned i0 = blockIdx.x * WGS, i = i0 + threadIdx.x;
+    if (i0 >= n_sub) return;                                         // (workgroup-uniform: the launch is sized before the stuffing is counted)
+    load_setup(S, gS);
     load_window(win, U, i0, u_words);
     __syncthreads();
     if (i >= n_sub) return;
@@ -185,13 +187,17 @@ __global__ void adopt_proposals_kernel(const unsigned long long* proposal, unsig
 // only when its entry state changed), so a true entry state at the workgroup's first lane -- or a lane that falls into
 // step with the true decode by itself -- propagates through the whole workgroup within the launch.  Launches are
 // repeated until no exit state changes anywhere (jpezy_capi.hip): two or three in practice.
-__global__ __launch_bounds__(WGS) void sync_kernel(const Setup* gS, const uint32_t* U, size_t u_words, unsigned n_sub, uint32_t* exit_state,
-                                                   uint32_t* last_entry, unsigned* nblocks_out, unsigned* changed, int max_inner)
+__global__ __launch_bounds__(WGS) void sync_kernel(const Setup* gS, const uint32_t* U, size_t u_words, const ScanState* st, uint32_t* exit_state,
+                                                   uint32_t* last_entry, unsigned* nblocks_out, unsigned* changed, const unsigned* prev, int max_inner)
 {
     __shared__ Setup S;
     __shared__ uint32_t win[WINDOW_WORDS];
     __shared__ uint32_t sh_exit[WGS + 1];
+    const unsigned n_sub = st->n_sub;
     const unsigned i0 = blockIdx.x * WGS, t = threadIdx.x, i = i0 + t;
+    if (i0 >= n_sub) return;
+    // enqueued blindly behind another launch: nothing left to do, or a stream that does not synchronise (RefineBudget in jpezy_capi_huffdec.hip)
+    if (prev && ((prev[1] == 0u && prev[2] == 0u) || prev[3] > n_sub / 2u + 16u)) return;
     const bool live = i < n_sub;
     uint32_t my_last = live ? last_entry[i] : 0u, my_exit = live ? exit_state[i] : 0u;
     const uint32_t exit_before = my_exit;
@@ -250,14 +256,17 @@ __global__ __launch_bounds__(WGS) void sync_kernel(const Setup* gS, const uint32
     }
 }
 
-__global__ __launch_bounds__(WGS) void emit_kernel(const Setup* gS, const uint32_t* U, size_t u_words, unsigned n_sub, const uint32_t* exit_state,
-                                                   const unsigned long long* blocks_before, int16_t* out, unsigned* error,
-                                                   unsigned long long* last_bit)
+__global__ __launch_bounds__(WGS) void emit_kernel(const Setup* gS, const uint32_t* U, size_t u_words, ScanState* st, const uint32_t* exit_state,
+                                                   const unsigned long long* blocks_before, int16_t* out)
 {
     __shared__ Setup S;
     __shared__ uint32_t win[WINDOW_WORDS];
-    load_setup(S, gS);
+    const unsigned n_sub = st->n_sub;
+    unsigned* const error = &st->error;
+    unsigned long long* const last_bit = &st->last_bit;
     const unsigned i0 = blockIdx.x * WGS, i = i0 + threadIdx.x;
+    if (i0 >= n_sub) return;
+    load_setup(S, gS);
     load_window(win, U, i0, u_words);
     __syncthreads();
     if (i >= n_sub) return;
@@ -378,6 +387,15 @@ constexpr int CHUNK = 64;
 // S holds everything from the first byte of the scan to the end of the file (n_max bytes).  The entropy-coded segment ends before the
 // first marker -- a 0xFF followed by anything but 0x00, or a 0xFF that is the file's last byte -- and the count kernel finds it on the
 // way (first_marker: atomicMin, initialised to all ones), so the host never walks the scan: a file goes up as it is.
+__global__ void scan_state_init_kernel(ScanState* st)
+{
+    if (threadIdx.x == 0) {
+        ScanState z = {};
+        z.last_bit = ~0ull;
+        z.first_marker = ~0ull;
+        *st = z;
+    }
+}
 __global__ __launch_bounds__(256) void unstuff_count_kernel(const uint8_t* S, size_t n_max, uint32_t* counts, unsigned long long* first_marker)
 {
     const size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -401,12 +419,12 @@ __global__ __launch_bounds__(256) void unstuff_count_kernel(const uint8_t* S, si
     if (marker != ~0ull) atomicMin(first_marker, marker);
 }
 // totals[0] = stuffing bytes removed in front of the marker
-__global__ __launch_bounds__(256) void unstuff_copy_kernel(const uint8_t* S, size_t n_max, const unsigned long long* first_marker,
-                                                           const unsigned long long* removed_before, uint8_t* U, unsigned long long* totals)
+__global__ __launch_bounds__(256) void unstuff_copy_kernel(const uint8_t* S, size_t n_max, const unsigned long long* removed_before, uint8_t* U,
+                                                           ScanState* st)
 {
     const size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t b0 = c * CHUNK;
-    const unsigned long long fm = *first_marker;
+    const unsigned long long fm = st->first_marker;
     const size_t n = fm < n_max ? (size_t)fm : n_max;
     if (b0 >= n) return;
     const unsigned long long rb = removed_before[c];
@@ -420,7 +438,10 @@ __global__ __launch_bounds__(256) void unstuff_copy_kernel(const uint8_t* S, siz
         *dst++ = v;
         prev = v;
     }
-    if (e == n) totals[0] = rb + cnt;
+    if (e == n) {                                    // the chunk that holds the segment's last byte
+        st->removed = rb + cnt;
+        st->n_sub = (unsigned)((((unsigned long long)n - (rb + cnt)) * 8 + SUBSEQ_BITS - 1) / SUBSEQ_BITS);
+    }
 }
 
 // ======================================================================================================
@@ -724,22 +745,26 @@ hipError_t launch_stream_per_lane(const Setup* setups, const uint32_t* U, BatchF
 unsigned subseq_bits() { return SUBSEQ_BITS; }
 size_t chunk_bytes() { return CHUNK; }
 
-hipError_t launch_unstuff_count(const uint8_t* S, size_t n_max, uint32_t* counts, unsigned long long* first_marker, hipStream_t s)
+hipError_t launch_scan_state_init(ScanState* st, hipStream_t s)
+{
+    hipLaunchKernelGGL(scan_state_init_kernel, dim3(1), dim3(64), 0, s, st);
+    return hipGetLastError();
+}
+hipError_t launch_unstuff_count(const uint8_t* S, size_t n_max, uint32_t* counts, ScanState* st, hipStream_t s)
 {
     const size_t nc = (n_max + CHUNK - 1) / CHUNK;
     if (!nc) return hipSuccess;
-    hipLaunchKernelGGL(unstuff_count_kernel, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, s, S, n_max, counts, first_marker);
+    hipLaunchKernelGGL(unstuff_count_kernel, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, s, S, n_max, counts, &st->first_marker);
     return hipGetLastError();
 }
-hipError_t launch_unstuff_copy(const uint8_t* S, size_t n_max, const unsigned long long* first_marker, const unsigned long long* removed_before,
-                               uint8_t* U, unsigned long long* totals, hipStream_t s)
+hipError_t launch_unstuff_copy(const uint8_t* S, size_t n_max, const unsigned long long* removed_before, uint8_t* U, ScanState* st, hipStream_t s)
 {
     const size_t nc = (n_max + CHUNK - 1) / CHUNK;
     if (!nc) return hipSuccess;
-    hipLaunchKernelGGL(unstuff_copy_kernel, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, s, S, n_max, first_marker, removed_before, U, totals);
+    hipLaunchKernelGGL(unstuff_copy_kernel, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, s, S, n_max, removed_before, U, st);
     return hipGetLastError();
 }
-hipError_t launch_speculate(const Setup* S, const uint32_t* U, size_t u_words, unsigned n_sub, unsigned long long* proposal,
+hipError_t launch_speculate(const Setup* S, const uint32_t* U, size_t u_words, unsigned n_sub, const ScanState* st, unsigned long long* proposal,
                             uint32_t* exit_state, uint32_t* last_entry, unsigned* nblocks, hipStream_t s)
 {
     hipLaunchKernelGGL(init_state_kernel, dim3((n_sub + 255) / 256), dim3(256), 0, s, proposal, last_entry, nblocks, n_sub);
@@ -748,22 +773,21 @@ hipError_t launch_speculate(const Setup* S, const uint32_t* U, size_t u_words, u
         const int v = e ? std::atoi(e) : OVERFLOW_DEFAULT;
         return (unsigned)(v < 0 ? 0 : v > OVERFLOW ? OVERFLOW : v);
     }();
-    hipLaunchKernelGGL(spec_kernel, dim3((n_sub + WGS - 1) / WGS), dim3(WGS), 0, s, S, U, u_words, n_sub, proposal, overflow);
+    hipLaunchKernelGGL(spec_kernel, dim3((n_sub + WGS - 1) / WGS), dim3(WGS), 0, s, S, U, u_words, st, proposal, overflow);
     hipLaunchKernelGGL(adopt_proposals_kernel, dim3((n_sub + 255) / 256), dim3(256), 0, s, proposal, n_sub, exit_state);
     return hipGetLastError();
 }
-hipError_t launch_sync(const Setup* S, const uint32_t* U, size_t u_words, unsigned n_sub, uint32_t* exit_state, uint32_t* last_entry,
-                       unsigned* nblocks, unsigned* changed, int max_inner, hipStream_t s)
+hipError_t launch_sync(const Setup* S, const uint32_t* U, size_t u_words, unsigned n_sub, const ScanState* st, uint32_t* exit_state, uint32_t* last_entry,
+                       unsigned* nblocks, unsigned* changed, const unsigned* prev, int max_inner, hipStream_t s)
 {
-    hipLaunchKernelGGL(sync_kernel, dim3((n_sub + WGS - 1) / WGS), dim3(WGS), 0, s, S, U, u_words, n_sub, exit_state, last_entry, nblocks, changed,
+    hipLaunchKernelGGL(sync_kernel, dim3((n_sub + WGS - 1) / WGS), dim3(WGS), 0, s, S, U, u_words, st, exit_state, last_entry, nblocks, changed, prev,
                        max_inner < 1 ? 1 : max_inner > WGS + 1 ? WGS + 1 : max_inner);
     return hipGetLastError();
 }
-hipError_t launch_emit(const Setup* S, const uint32_t* U, size_t u_words, unsigned n_sub, const uint32_t* exit_state,
-                       const unsigned long long* blocks_before, int16_t* out, unsigned* error, unsigned long long* last_bit, hipStream_t s)
+hipError_t launch_emit(const Setup* S, const uint32_t* U, size_t u_words, unsigned n_sub, ScanState* st, const uint32_t* exit_state,
+                       const unsigned long long* blocks_before, int16_t* out, hipStream_t s)
 {
-    hipLaunchKernelGGL(emit_kernel, dim3((n_sub + WGS - 1) / WGS), dim3(WGS), 0, s, S, U, u_words, n_sub, exit_state, blocks_before, out, error,
-                       last_bit);
+    hipLaunchKernelGGL(emit_kernel, dim3((n_sub + WGS - 1) / WGS), dim3(WGS), 0, s, S, U, u_words, st, exit_state, blocks_before, out);
     return hipGetLastError();
 }
 size_t dc_prefix_scratch_ints(size_t nmcu, unsigned max_count) { return 3 * ((nmcu * max_count + DC_PER_WG - 1) / DC_PER_WG + 1); }

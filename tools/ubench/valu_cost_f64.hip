@@ -52,6 +52,18 @@ DEFM(cvt_pk_i16, "v_cvt_pk_i16_i32 %1, %3, %5")
 DEFM(alignbit, "v_alignbit_b32 %1, %3, %5, 7")
 DEFM(lshlrev, "v_lshlrev_b32 %1, 3, %3")
 DEFM(bfe_i32, "v_bfe_i32 %1, %3, 16, 16")
+DEFM(lshl_b64, "v_lshlrev_b64 %0, %3, %2")
+DEFM(lshr_b64, "v_lshrrev_b64 %0, %3, %2")
+DEFM(ffbh_u32, "v_ffbh_u32 %1, %3")
+DEFM(bcnt_u32, "v_bcnt_u32_b32 %1, %3, %5")
+DEFM(lshl_b32_vv, "v_lshlrev_b32 %1, %3, %5")
+DEFM(lshr_b32_vv, "v_lshrrev_b32 %1, %3, %5")
+DEFM(or_b32, "v_or_b32 %1, %3, %5")
+DEFM(xor_b32, "v_xor_b32 %1, %3, %5")
+DEFM(max_i32, "v_max_i32 %1, %3, %5")
+DEFM(bfi_b32, "v_bfi_b32 %1, %3, %5, %1")
+DEFM(and_or, "v_and_or_b32 %1, %3, %5, %1")
+DEFM(xad_u32, "v_xad_u32 %1, %3, %5, %1")
 
 typedef void (*kern_t)(float*, float);
 static void run(const char* name, kern_t k, int w)
@@ -73,11 +85,12 @@ static void run(const char* name, kern_t k, int w)
 #define RUN(K) run(#K, K, w);
 int main()
 {
-    for (int w : { 1, 3, 5, 8 }) {
+    for (int w : { 1, 4, 8 }) {
         RUN(add_f64) RUN(mul_f64) RUN(fma_f64) RUN(fract_f64) RUN(cvt_f64_i32) RUN(cvt_i32_f64) RUN(cvt_f64_f32) RUN(cvt_f32_f64)
         RUN(cvt_f32_i32) RUN(cvt_i32_f32) RUN(fma_f32) RUN(mul_lo_u32) RUN(mul_hi_u32) RUN(mad_u32_u24) RUN(mad_i32_i24)
         RUN(ctl_add_f32) RUN(ctl_and_b32) RUN(add_u32) RUN(sub_u32) RUN(lshl_or) RUN(cvt_f32_ub1)
         RUN(min3_u32) RUN(max3_i32) RUN(or3) RUN(add3) RUN(sat_pk_u8) RUN(cvt_pk_i16) RUN(alignbit) RUN(lshlrev) RUN(bfe_i32)
+        RUN(lshl_b64) RUN(lshr_b64) RUN(ffbh_u32) RUN(bcnt_u32) RUN(lshl_b32_vv) RUN(lshr_b32_vv) RUN(or_b32) RUN(xor_b32) RUN(max_i32) RUN(bfi_b32) RUN(and_or) RUN(xad_u32)
     }
     return 0;
 }

@@ -370,7 +370,7 @@ try {
     if (int r2 = c->h_U.reserve(u_bytes)) return r2;
     if (int r2 = c->h_cnt.reserve(std::max(nc, (size_t)n_sub) * sizeof(uint32_t))) return r2;
     if (int r2 = c->h_off.reserve((std::max(nc, (size_t)n_sub) + 1) * sizeof(unsigned long long))) return r2;
-    if (int r2 = c->h_state.reserve((size_t)n_sub * 3 * sizeof(uint32_t))) return r2;
+    if (int r2 = c->h_state.reserve((size_t)n_sub_max * (3 + 2 * (HD::emit_parts() - 1)) * sizeof(uint32_t))) return r2;
     if (int r2 = c->h_setup.reserve(sizeof(HD::Setup))) return r2;
     if (int r2 = c->h_small.reserve(sizeof(HD::ScanState))) return r2;
     size_t max_dc = 0;
@@ -430,6 +430,8 @@ try {
     uint32_t* d_exit = (uint32_t*)c->h_state.p;
     uint32_t* d_last = d_exit + n_sub_max;
     unsigned* d_nblocks = (unsigned*)(d_last + n_sub_max);
+    uint32_t* d_marks = (uint32_t*)(d_nblocks + n_sub_max);
+    unsigned* d_mark_blocks = (unsigned*)(d_marks + (size_t)n_sub_max * (HD::emit_parts() - 1));
     HIP_TRY(HD::launch_speculate((const HD::Setup*)c->h_setup.p, (const uint32_t*)c->h_U.p, u_bytes / 4, n_sub_max, d_st,
                                  (unsigned long long*)c->h_dc.p, d_exit, d_last, d_nblocks, s));
     HD::ScanState st;
@@ -444,7 +446,7 @@ try {
     const RefineBudget budget(L);
     auto sync_launch = [&](unsigned* changed, const unsigned* prev, int max_inner) -> hipError_t {
         return HD::launch_sync((const HD::Setup*)c->h_setup.p, (const uint32_t*)c->h_U.p, u_bytes / 4, n_sub_max, d_st, d_exit, d_last, d_nblocks,
-                               changed, prev, max_inner, s);
+                               d_marks, d_mark_blocks, changed, prev, max_inner, s);
     };
     HIP_TRY(sync_launch(d_st->changed, nullptr, budget.first_steps));           // confirmation + the first propagation steps
     HIP_TRY(sync_launch(d_st->changed2, d_st->changed, budget.steps));          // refinement launch 1, if there is anything left for it
@@ -518,7 +520,7 @@ try {
     // 3. global block index of every lane, coefficients, DC predictors
     HIP_TRY(E::launch_scan_u32((const uint32_t*)d_nblocks, (unsigned long long*)c->h_off.p, n_sub_max, (unsigned long long*)c->e_tmp.p, s));
     HIP_TRY(hipMemsetAsync(d_coeffs, 0, total * sizeof(int16_t), s));
-    HIP_TRY(HD::launch_emit((const HD::Setup*)c->h_setup.p, (const uint32_t*)c->h_U.p, u_bytes / 4, n_sub_max, d_st, d_exit,
+    HIP_TRY(HD::launch_emit((const HD::Setup*)c->h_setup.p, (const uint32_t*)c->h_U.p, u_bytes / 4, n_sub_max, d_st, d_exit, d_marks, d_mark_blocks,
                             (const unsigned long long*)c->h_off.p, d_coeffs, s));
     {   // DC differences -> values, all components in three launches (round 2: gather, two-launch scan, scatter per component = twelve)
         const StreamGeom g = jpezy_internal_stream_geom(*info);

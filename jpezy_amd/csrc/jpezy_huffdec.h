@@ -83,10 +83,13 @@ hipError_t launch_speculate(const Setup* S, const uint32_t* U, size_t u_words, u
 // predecessor's current exit state and nothing more); a workgroup none of whose lanes has a new entry state leaves at once.
 // prev (may be null): the counters of the launch before this one -- nothing pending there, or more than half of the proposals wrong at its
 // first step (a stream that does not synchronise: the host decoder's), and this launch leaves at once: it can be enqueued blindly.
+// marks / mark_blocks: (emit_parts() - 1) words per subsequence each -- the state at every emit_parts()-th of a subsequence and the blocks completed
+// before it, left by a lane's last walk; the coefficient launch starts a lane at each (emit_parts() times shorter serial walks).
+unsigned emit_parts();
 hipError_t launch_sync(const Setup* S, const uint32_t* U, size_t u_words, unsigned n_sub_max, const ScanState* st, uint32_t* exit_state, uint32_t* last_entry,
-                       unsigned* nblocks, unsigned* changed, const unsigned* prev, int max_inner, hipStream_t s);
+                       unsigned* nblocks, uint32_t* marks, unsigned* mark_blocks, unsigned* changed, const unsigned* prev, int max_inner, hipStream_t s);
 hipError_t launch_emit(const Setup* S, const uint32_t* U, size_t u_words, unsigned n_sub_max, ScanState* st, const uint32_t* exit_state,
-                       const unsigned long long* blocks_before, int16_t* out, hipStream_t s);
+                       const uint32_t* marks, const unsigned* mark_blocks, const unsigned long long* blocks_before, int16_t* out, hipStream_t s);
 // DC differences -> values for all components of one scan in three launches (component q owns blocks [cstart[q], cstart[q] + ccount[q]) of
 // every MCU); scratch: dc_prefix_scratch_ints(nmcu, largest ccount) ints
 size_t dc_prefix_scratch_ints(size_t nmcu, unsigned max_count);

@@ -138,6 +138,24 @@ __device__ __forceinline__ void run_subsequence(const uint16_t* tabs, unsigned b
     while (c.pos < end) decode_step<false>(tabs, bpm, tdmask, c, s, 0, 0, nullptr);
 }
 
+// The same walk, leaving the state at every EMIT_PARTS-th of the subsequence (state at the first code word at or behind the mark, and the blocks
+// completed before it): the coefficient pass starts a lane at each mark, so its serial walks are EMIT_PARTS times shorter (round 4; a lane
+// decodes ~24 bits per microsecond whatever else the chip is doing, and a single file fills a quarter of its lanes).
+constexpr int EMIT_PARTS = 4, PART_BITS = SUBSEQ_BITS / EMIT_PARTS;
+__device__ __forceinline__ void run_subsequence_marks(const uint16_t* tabs, unsigned bpm, unsigned tdmask, Cursor& c, Walk& s, unsigned base,
+                                                      uint32_t* mark, unsigned* mark_blocks)
+{
+#pragma unroll
+    for (int q = 1; q <= EMIT_PARTS; ++q) {               // (unrolled: mark[] stays in registers)
+        const unsigned lim = base + (unsigned)q * PART_BITS;
+        while (c.pos < lim) decode_step<false>(tabs, bpm, tdmask, c, s, 0, 0, nullptr);
+        if (q < EMIT_PARTS) {
+            mark[q - 1] = pack_state(c.pos - lim, s.b, s.k);
+            mark_blocks[q - 1] = s.nblocks;
+        }
+    }
+}
+
 // Speculation: lane i decodes from the guess (0, 0, 0) at the start of its subsequence through OVERFLOW + 1
 // subsequences.  A decoder started at a wrong place is in step with the true one after a few hundred bits -- bit
 // position, zig-zag index and, after some more MCUs, the block phase -- so the state it holds at the end of subsequence
@@ -188,7 +206,8 @@ __global__ void adopt_proposals_kernel(const unsigned long long* proposal, unsig
 // step with the true decode by itself -- propagates through the whole workgroup within the launch.  Launches are
 // repeated until no exit state changes anywhere (jpezy_capi.hip): two or three in practice.
 __global__ __launch_bounds__(WGS) void sync_kernel(const Setup* gS, const uint32_t* U, size_t u_words, const ScanState* st, uint32_t* exit_state,
-                                                   uint32_t* last_entry, unsigned* nblocks_out, unsigned* changed, const unsigned* prev, int max_inner)
+                                                   uint32_t* last_entry, unsigned* nblocks_out, uint32_t* marks, unsigned* mark_blocks,
+                                                   unsigned* changed, const unsigned* prev, int max_inner)
 {
     __shared__ Setup S;
     __shared__ uint32_t win[WINDOW_WORDS];
@@ -212,6 +231,9 @@ __global__ __launch_bounds__(WGS) void sync_kernel(const Setup* gS, const uint32
     const uint16_t* tabs = reinterpret_cast<const uint16_t*>(&S);
     const unsigned bpm = (unsigned)S.bpm, tdmask = S.tdmask;
     bool first_moved = false;                              // this lane's first decode of the launch left another state than it had
+    bool walked = false;
+    uint32_t mk[EMIT_PARTS - 1];                           // the marks of the lane's last walk (the one that counts), stored once at the end
+    unsigned mkb[EMIT_PARTS - 1];
     for (int inner = 0; inner < max_inner; ++inner) {
         const uint32_t entry = sh_exit[t];
         bool redo = live && entry != my_last;
@@ -219,15 +241,18 @@ __global__ __launch_bounds__(WGS) void sync_kernel(const Setup* gS, const uint32
         if (redo) {
             my_last = entry;
             nb = 0;
+            walked = true;
             if (entry & 0x40000000u) {
                 my_exit = STATE_ERR;
+#pragma unroll
+                for (int q = 0; q < EMIT_PARTS - 1; ++q) mk[q] = STATE_ERR;
             } else {
                 Cursor c;
                 c.init(win, t * SUBSEQ_BITS + ((entry >> 16) & 0x3FFFu));
                 Walk wk;
                 wk.init((entry >> 8) & 0xFFu, entry & 0xFFu, tdmask);
                 const unsigned end = (t + 1) * SUBSEQ_BITS;
-                run_subsequence(tabs, bpm, tdmask, c, wk, end);
+                run_subsequence_marks(tabs, bpm, tdmask, c, wk, t * SUBSEQ_BITS, mk, mkb);     // (the lane's last walk is the one that counts)
                 nb = wk.nblocks;
                 my_exit = pack_state(c.pos - end, wk.b, wk.k);
             }
@@ -240,6 +265,13 @@ __global__ __launch_bounds__(WGS) void sync_kernel(const Setup* gS, const uint32
     if (live) {
         last_entry[i] = my_last;
         nblocks_out[i] = nb;
+        if (walked) {
+#pragma unroll
+            for (int q = 0; q < EMIT_PARTS - 1; ++q) {
+                marks[(size_t)i * (EMIT_PARTS - 1) + q] = mk[q];
+                mark_blocks[(size_t)i * (EMIT_PARTS - 1) + q] = mkb[q];
+            }
+        }
         // a launch cut off by max_inner can leave a lane whose predecessor's exit moved after the lane last decoded
         // (A -> B -> A inside the launch leaves exit_before == my_exit): such a lane is still pending and must keep
         // the host iterating, or a stale nblocks/last_entry would pass for the fixed point
@@ -256,37 +288,47 @@ __global__ __launch_bounds__(WGS) void sync_kernel(const Setup* gS, const uint32
     }
 }
 
+// A lane per EMIT_PARTS-th of a subsequence: part 0 starts from the predecessor's exit state, the others from the marks the last
+// synchronisation walk left (sync_kernel).  A workgroup takes WGS / EMIT_PARTS subsequences.
+constexpr int EMIT_SUBS = WGS / EMIT_PARTS;
+constexpr int EMIT_WINDOW_LINEAR = (EMIT_SUBS + 1) * SUBSEQ_BITS / 32 + 16;        // its subsequences plus the overrun of the last symbol
+static_assert(EMIT_WINDOW_LINEAR <= WINDOW_LINEAR && WGS % EMIT_PARTS == 0 && SUBSEQ_BITS % EMIT_PARTS == 0, "emit geometry");
 __global__ __launch_bounds__(WGS) void emit_kernel(const Setup* gS, const uint32_t* U, size_t u_words, ScanState* st, const uint32_t* exit_state,
-                                                   const unsigned long long* blocks_before, int16_t* out)
+                                                   const uint32_t* marks, const unsigned* mark_blocks, const unsigned long long* blocks_before,
+                                                   int16_t* out)
 {
     __shared__ Setup S;
-    __shared__ uint32_t win[WINDOW_WORDS];
+    __shared__ uint32_t win[EMIT_WINDOW_LINEAR + EMIT_WINDOW_LINEAR / 32 + 1];
     const unsigned n_sub = st->n_sub;
     unsigned* const error = &st->error;
     unsigned long long* const last_bit = &st->last_bit;
-    const unsigned i0 = blockIdx.x * WGS, i = i0 + threadIdx.x;
+    const unsigned i0 = blockIdx.x * EMIT_SUBS, ts = threadIdx.x / EMIT_PARTS, q = threadIdx.x % EMIT_PARTS, i = i0 + ts;
     if (i0 >= n_sub) return;
     load_setup(S, gS);
-    load_window(win, U, i0, u_words);
+    {
+        const size_t w0 = (size_t)i0 * (SUBSEQ_BITS / 32);
+        for (unsigned k = threadIdx.x; k < (unsigned)EMIT_WINDOW_LINEAR; k += WGS) win[pad_index(k)] = w0 + k < u_words ? __builtin_bswap32(U[w0 + k]) : 0u;
+    }
     __syncthreads();
     if (i >= n_sub) return;
-    const unsigned long long g0 = blocks_before[i];
+    const unsigned long long g0 = blocks_before[i] + (q ? mark_blocks[(size_t)i * (EMIT_PARTS - 1) + q - 1] : 0u);
     if (g0 >= S.total_blocks) return;                  // everything this lane sees lies behind the last block
-    const uint32_t entry = i ? exit_state[i - 1] : pack_state(0, 0, 0);
+    const uint32_t entry = q ? marks[(size_t)i * (EMIT_PARTS - 1) + q - 1] : i ? exit_state[i - 1] : pack_state(0, 0, 0);
     if (entry & 0x40000000u) { *error = 1u; return; }
     const uint16_t* tabs = reinterpret_cast<const uint16_t*>(&S);
     const unsigned bpm = (unsigned)S.bpm, tdmask = S.tdmask, total = S.total_blocks;
+    const unsigned base = ts * SUBSEQ_BITS + q * PART_BITS;
     Cursor c;
-    c.init(win, threadIdx.x * SUBSEQ_BITS + ((entry >> 16) & 0x3FFFu));
+    c.init(win, base + ((entry >> 16) & 0x3FFFu));
     Walk wk;
     wk.init((entry >> 8) & 0xFFu, entry & 0xFFu, tdmask);
-    const unsigned end = (threadIdx.x + 1) * SUBSEQ_BITS;
+    const unsigned end = base + PART_BITS;
     // stop at the end of the last block: what follows are pad bits, not symbols
     while (c.pos < end && g0 + wk.nblocks < total) {
         if (!decode_step<true>(tabs, bpm, tdmask, c, wk, g0, total, out)) { *error = 1u; return; }
     }
     // exactly one lane completes the last block; the bit behind it, counted from the start of the stream
-    if (g0 + wk.nblocks >= total) *last_bit = (unsigned long long)i0 * SUBSEQ_BITS + c.pos;
+    if (wk.nblocks && g0 + wk.nblocks >= total) *last_bit = (unsigned long long)i0 * SUBSEQ_BITS + c.pos;
 }
 
 // ---- DC differences -> absolute values, per component (pre_DC, ref :611-614); component q owns blocks [cstart[q], cstart[q] + ccount[q]) of
@@ -368,12 +410,28 @@ __global__ __launch_bounds__(256) void dc_totals_kernel(int* totals, DcGeom g, u
         __syncthreads();
     }
 }
+// SELF_SUM (round 4, up to DC_SELF_SUM_MAX workgroups per component): the workgroup adds up the raw totals in front of it itself -- a few hundred
+// values out of the L2 -- and the launch that scanned them is gone (a dependent launch costs ~5 us)
+constexpr unsigned DC_SELF_SUM_MAX = 1024;
+template <bool SELF_SUM>
 __global__ __launch_bounds__(256) void dc_add_kernel(int16_t* coeffs, DcGeom g, const int* totals, unsigned wg_per_comp)
 {
+    __shared__ int red[4];
     const unsigned comp = blockIdx.y;
     const size_t nd = (size_t)g.nmcu * g.ccount[comp], j0 = (size_t)blockIdx.x * DC_PER_WG + (size_t)threadIdx.x * 8;
     if (blockIdx.x == 0 || (size_t)blockIdx.x * DC_PER_WG >= nd) return;   // (nothing comes before the first workgroup)
-    const int before = totals[(size_t)comp * wg_per_comp + blockIdx.x];
+    int before;
+    if (SELF_SUM) {
+        int sum = 0;
+        for (unsigned k = threadIdx.x; k < blockIdx.x; k += 256) sum += totals[(size_t)comp * wg_per_comp + k];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d, 64);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sum;
+        __syncthreads();
+        before = red[0] + red[1] + red[2] + red[3];
+    } else {
+        before = totals[(size_t)comp * wg_per_comp + blockIdx.x];
+    }
 #pragma unroll
     for (int q = 0; q < 8; ++q)
         if (j0 + q < nd) {
@@ -396,51 +454,96 @@ __global__ void scan_state_init_kernel(ScanState* st)
         *st = z;
     }
 }
+// Round 4: a thread fetches its 64 bytes with four 16-byte loads and walks them in registers (round 3: 64 single-byte loads per thread --
+// 17 us for a 5 MB scan), and the copy launch compacts into LDS and stores whole words (round 3: a byte store per byte, 35 us).  The
+// buffers are 64 bytes longer than the data (jpezy_read_jpeg_gpu), so the last chunk's loads stay inside them.
+__device__ __forceinline__ void load_chunk(const uint8_t* S, size_t b0, uint32_t* w)
+{
+    const uint4* p = reinterpret_cast<const uint4*>(S + b0);
+#pragma unroll
+    for (int k = 0; k < CHUNK / 16; ++k) {
+        const uint4 v = p[k];
+        w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w;
+    }
+}
 __global__ __launch_bounds__(256) void unstuff_count_kernel(const uint8_t* S, size_t n_max, uint32_t* counts, unsigned long long* first_marker)
 {
     const size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t b0 = c * CHUNK;
     if (b0 >= n_max) return;
+    uint32_t w[CHUNK / 4];
+    load_chunk(S, b0, w);
     unsigned cnt = 0;
     uint8_t prev = b0 ? S[b0 - 1] : 0;
-    const size_t e = b0 + CHUNK < n_max ? b0 + CHUNK : n_max;
-    unsigned long long marker = ~0ull;
-    for (size_t i = b0; i < e; ++i) {
-        const uint8_t v = S[i];
-        if (v == 0x00 && prev == 0xFF) { ++cnt; prev = 0x01; }                  // FF 00 00: only the first zero is stuffing
-        else {
-            if (prev == 0xFF && marker == ~0ull) marker = i - 1;
-            prev = v;
+    const unsigned e = (unsigned)(n_max - b0 < (size_t)CHUNK ? n_max - b0 : (size_t)CHUNK);
+    unsigned marker = ~0u;                           // offset inside the chunk's neighbourhood: b0 + marker (may be -1: the byte before the chunk)
+#pragma unroll
+    for (unsigned k = 0; k < (unsigned)CHUNK; ++k) {
+        const uint8_t v = (uint8_t)(w[k >> 2] >> ((k & 3u) * 8u));
+        if (k < e) {
+            if (v == 0x00 && prev == 0xFF) { ++cnt; prev = 0x01; }                  // FF 00 00: only the first zero is stuffing
+            else {
+                if (prev == 0xFF && marker == ~0u) marker = k;                       // (k: one more than the 0xFF's offset)
+                prev = v;
+            }
         }
     }
-    if (e == n_max && prev == 0xFF && marker == ~0ull) marker = n_max - 1;
+    unsigned long long mk = marker != ~0u ? (unsigned long long)b0 + marker - 1ull : ~0ull;
+    if (b0 + e == n_max && prev == 0xFF && marker == ~0u) mk = n_max - 1;
     // (counts of chunks behind the marker are never used: only prefix sums up to the marker's chunk are)
     counts[c] = cnt;
-    if (marker != ~0ull) atomicMin(first_marker, marker);
+    if (mk != ~0ull) atomicMin(first_marker, mk);
 }
-// totals[0] = stuffing bytes removed in front of the marker
+// A workgroup takes 256 consecutive chunks: their output is one contiguous byte range of U, assembled in LDS at the position it has there
+// (shifted so that LDS words line up with the words of U) and stored as whole words; the partial first and last word go out as bytes (the
+// neighbouring workgroups complete them).  The chunk that holds the segment's last byte leaves the totals in st.
 __global__ __launch_bounds__(256) void unstuff_copy_kernel(const uint8_t* S, size_t n_max, const unsigned long long* removed_before, uint8_t* U,
                                                            ScanState* st)
 {
-    const size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ uint32_t buf[256 * CHUNK / 4 + 4];
+    __shared__ unsigned end_sh;
+    uint8_t* const lb = reinterpret_cast<uint8_t*>(buf);
+    const size_t c0 = (size_t)blockIdx.x * 256, c = c0 + threadIdx.x;
     const size_t b0 = c * CHUNK;
     const unsigned long long fm = st->first_marker;
     const size_t n = fm < n_max ? (size_t)fm : n_max;
-    if (b0 >= n) return;
-    const unsigned long long rb = removed_before[c];
-    uint8_t* dst = U + b0 - rb;
-    uint8_t prev = b0 ? S[b0 - 1] : 0;
-    const size_t e = b0 + CHUNK < n ? b0 + CHUNK : n;
-    unsigned cnt = 0;
-    for (size_t i = b0; i < e; ++i) {
-        const uint8_t v = S[i];
-        if (v == 0x00 && prev == 0xFF) { prev = 0x01; ++cnt; continue; }
-        *dst++ = v;
-        prev = v;
+    if (c0 * CHUNK >= n) return;                                                     // workgroup-uniform
+    const unsigned long long rb0 = removed_before[c0];
+    uint8_t* const P = U + c0 * CHUNK - rb0;                                         // first output byte of the workgroup
+    const unsigned shift = (unsigned)(reinterpret_cast<uintptr_t>(P) & 3u);
+    if (b0 < n) {
+        const unsigned long long rb = removed_before[c];
+        uint32_t w[CHUNK / 4];
+        load_chunk(S, b0, w);
+        uint8_t prev = b0 ? S[b0 - 1] : 0;
+        const unsigned e = (unsigned)(n - b0 < (size_t)CHUNK ? n - b0 : (size_t)CHUNK);
+        uint8_t* dst = lb + shift + (b0 - c0 * CHUNK) - (size_t)(rb - rb0);
+        unsigned cnt = 0;
+#pragma unroll
+        for (unsigned k = 0; k < (unsigned)CHUNK; ++k) {
+            const uint8_t v = (uint8_t)(w[k >> 2] >> ((k & 3u) * 8u));
+            if (k < e) {
+                if (v == 0x00 && prev == 0xFF) { prev = 0x01; ++cnt; }
+                else { *dst++ = v; prev = v; }
+            }
+        }
+        const bool last = b0 + e == n;
+        if (last) {                                  // the chunk that holds the segment's last byte
+            st->removed = rb + cnt;
+            st->n_sub = (unsigned)((((unsigned long long)n - (rb + cnt)) * 8 + SUBSEQ_BITS - 1) / SUBSEQ_BITS);
+        }
+        if (last || threadIdx.x == 255) end_sh = (unsigned)(dst - lb);
     }
-    if (e == n) {                                    // the chunk that holds the segment's last byte
-        st->removed = rb + cnt;
-        st->n_sub = (unsigned)((((unsigned long long)n - (rb + cnt)) * 8 + SUBSEQ_BITS - 1) / SUBSEQ_BITS);
+    __syncthreads();
+    const unsigned end = end_sh, nwords = (end + 3) / 4;
+    uint32_t* const A = reinterpret_cast<uint32_t*>(P - shift);                      // 4-byte aligned
+    for (unsigned wd = threadIdx.x; wd < nwords; wd += 256) {
+        const unsigned lo = wd * 4, hi = lo + 4;
+        if (lo >= shift && hi <= end) {
+            A[wd] = buf[wd];
+        } else {
+            for (unsigned k = lo < shift ? shift : lo; k < (hi < end ? hi : end); ++k) reinterpret_cast<uint8_t*>(A)[k] = lb[k];
+        }
     }
 }
 
@@ -761,7 +864,7 @@ hipError_t launch_unstuff_copy(const uint8_t* S, size_t n_max, const unsigned lo
 {
     const size_t nc = (n_max + CHUNK - 1) / CHUNK;
     if (!nc) return hipSuccess;
-    hipLaunchKernelGGL(unstuff_copy_kernel, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, s, S, n_max, removed_before, U, st);
+    hipLaunchKernelGGL(unstuff_copy_kernel, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, s, S, n_max, removed_before, U, st);   // (a workgroup per 256 chunks, as before)
     return hipGetLastError();
 }
 hipError_t launch_speculate(const Setup* S, const uint32_t* U, size_t u_words, unsigned n_sub, const ScanState* st, unsigned long long* proposal,
@@ -777,17 +880,20 @@ hipError_t launch_speculate(const Setup* S, const uint32_t* U, size_t u_words, u
     hipLaunchKernelGGL(adopt_proposals_kernel, dim3((n_sub + 255) / 256), dim3(256), 0, s, proposal, n_sub, exit_state);
     return hipGetLastError();
 }
+unsigned emit_parts() { return EMIT_PARTS; }
 hipError_t launch_sync(const Setup* S, const uint32_t* U, size_t u_words, unsigned n_sub, const ScanState* st, uint32_t* exit_state, uint32_t* last_entry,
-                       unsigned* nblocks, unsigned* changed, const unsigned* prev, int max_inner, hipStream_t s)
+                       unsigned* nblocks, uint32_t* marks, unsigned* mark_blocks, unsigned* changed, const unsigned* prev, int max_inner, hipStream_t s)
 {
-    hipLaunchKernelGGL(sync_kernel, dim3((n_sub + WGS - 1) / WGS), dim3(WGS), 0, s, S, U, u_words, st, exit_state, last_entry, nblocks, changed, prev,
+    hipLaunchKernelGGL(sync_kernel, dim3((n_sub + WGS - 1) / WGS), dim3(WGS), 0, s, S, U, u_words, st, exit_state, last_entry, nblocks, marks, mark_blocks,
+                       changed, prev,
                        max_inner < 1 ? 1 : max_inner > WGS + 1 ? WGS + 1 : max_inner);
     return hipGetLastError();
 }
 hipError_t launch_emit(const Setup* S, const uint32_t* U, size_t u_words, unsigned n_sub, ScanState* st, const uint32_t* exit_state,
-                       const unsigned long long* blocks_before, int16_t* out, hipStream_t s)
+                       const uint32_t* marks, const unsigned* mark_blocks, const unsigned long long* blocks_before, int16_t* out, hipStream_t s)
 {
-    hipLaunchKernelGGL(emit_kernel, dim3((n_sub + WGS - 1) / WGS), dim3(WGS), 0, s, S, U, u_words, st, exit_state, blocks_before, out);
+    hipLaunchKernelGGL(emit_kernel, dim3((n_sub + EMIT_SUBS - 1) / EMIT_SUBS), dim3(WGS), 0, s, S, U, u_words, st, exit_state, marks, mark_blocks,
+                       blocks_before, out);
     return hipGetLastError();
 }
 size_t dc_prefix_scratch_ints(size_t nmcu, unsigned max_count) { return 3 * ((nmcu * max_count + DC_PER_WG - 1) / DC_PER_WG + 1); }
@@ -802,8 +908,16 @@ hipError_t launch_dc_prefix(int16_t* coeffs, unsigned bpm, unsigned ncomp, const
     if (!wgs || !ncomp) return hipSuccess;
     if (wgs > 0x7FFFFFFFull) return hipErrorInvalidValue;
     hipLaunchKernelGGL(dc_local_kernel, dim3((unsigned)wgs, ncomp), dim3(256), 0, s, coeffs, g, scratch, (unsigned)wgs + 1);
-    hipLaunchKernelGGL(dc_totals_kernel, dim3(ncomp), dim3(256), 0, s, scratch, g, (unsigned)wgs + 1);
-    hipLaunchKernelGGL(dc_add_kernel, dim3((unsigned)wgs, ncomp), dim3(256), 0, s, coeffs, g, (const int*)scratch, (unsigned)wgs + 1);
+    static const size_t self_sum_max = [] {
+        const char* e = std::getenv("JPEZY_DC_SELF_SUM_MAX");        // development / test knob: 0 forces the three-launch form
+        return e ? (size_t)std::atoll(e) : (size_t)DC_SELF_SUM_MAX;
+    }();
+    if (wgs <= self_sum_max) {
+        hipLaunchKernelGGL(dc_add_kernel<true>, dim3((unsigned)wgs, ncomp), dim3(256), 0, s, coeffs, g, (const int*)scratch, (unsigned)wgs + 1);
+    } else {
+        hipLaunchKernelGGL(dc_totals_kernel, dim3(ncomp), dim3(256), 0, s, scratch, g, (unsigned)wgs + 1);
+        hipLaunchKernelGGL(dc_add_kernel<false>, dim3((unsigned)wgs, ncomp), dim3(256), 0, s, coeffs, g, (const int*)scratch, (unsigned)wgs + 1);
+    }
     return hipGetLastError();
 }
 

@@ -480,3 +480,30 @@ def test_long_tail_behind_the_scan_is_not_decoded_or_uploaded(J, ctx, oracle):
     for info2, rr, gg, bb in ctx.decode_jpeg_batch([jpg + tail, jpg, jpg + second], gray=False):
         for a, e in zip((rr, gg, bb), want_planes[-3:]):
             assert np.array_equal(a, np.asarray(e).reshape(-1)[: W * H])
+
+
+def test_dc_predictors_three_launch_form(tmp_path):
+    """Round 4 folds the scan of the DC workgroup totals into the add launch for up to 1,024 workgroups per component; beyond that
+    (frames of more than ~2 M blocks per component) the three-launch form of round 3 runs.  JPEZY_DC_SELF_SUM_MAX=0 forces it: a
+    1920x1080 random-pixel scan decoded on the device in a subprocess equals the host decoder's coefficients."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    script = tmp_path / "dc_three.py"
+    script.write_text(
+        "import sys, numpy as np\n"
+        f"sys.path.insert(0, {str(root)!r})\n"
+        "import jpezy_amd as J\n"
+        "ctx = J.Context(0); ctx.set_huffdec_min_bytes(0)\n"
+        "rng = np.random.default_rng(11); W, H = 1920, 1080\n"
+        "data = ctx.encode_jpeg(*[rng.integers(0, 256, W * H, dtype=np.uint8) for _ in range(3)], W, H)\n"
+        "info, want = J.read_jpeg(data)\n"
+        "ginfo, got = ctx.read_jpeg_gpu(data)\n"
+        "assert ctx.last_huffdec_passes() >= 1, 'host decoder used'\n"
+        "assert np.array_equal(got.cpu().numpy(), want)\n"
+        "print('OK')\n")
+    env = dict(os.environ, JPEZY_DC_SELF_SUM_MAX="0")
+    p = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and "OK" in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]

@@ -142,18 +142,33 @@ __device__ __forceinline__ void run_subsequence(const uint16_t* tabs, unsigned b
 // completed before it): the coefficient pass starts a lane at each mark, so its serial walks are EMIT_PARTS times shorter (round 4; a lane
 // decodes ~24 bits per microsecond whatever else the chip is doing, and a single file fills a quarter of its lanes).
 constexpr int EMIT_PARTS = 4, PART_BITS = SUBSEQ_BITS / EMIT_PARTS;
-__device__ __forceinline__ void run_subsequence_marks(const uint16_t* tabs, unsigned bpm, unsigned tdmask, Cursor& c, Walk& s, unsigned base,
-                                                      uint32_t* mark, unsigned* mark_blocks)
+// have_old: mark / mark_blocks hold the lane's previous walk of the same subsequence (from another entry state).  A walk that reaches a mark in
+// the state the previous walk had there is the previous walk from then on: it stops, and the caller keeps the old exit state (returns the
+// number of blocks to add to the old count: new blocks in front of the mark minus old ones; the marks behind it move by as much).  A
+// corrected entry state usually falls into step within a few hundred bits, so most re-walks are a quarter or two long.
+__device__ __forceinline__ bool run_subsequence_marks(const uint16_t* tabs, unsigned bpm, unsigned tdmask, Cursor& c, Walk& s, unsigned base,
+                                                      uint32_t* mark, unsigned* mark_blocks, bool have_old, int* rejoin_delta)
 {
+    bool rejoined = false;
 #pragma unroll
     for (int q = 1; q <= EMIT_PARTS; ++q) {               // (unrolled: mark[] stays in registers)
         const unsigned lim = base + (unsigned)q * PART_BITS;
-        while (c.pos < lim) decode_step<false>(tabs, bpm, tdmask, c, s, 0, 0, nullptr);
-        if (q < EMIT_PARTS) {
-            mark[q - 1] = pack_state(c.pos - lim, s.b, s.k);
-            mark_blocks[q - 1] = s.nblocks;
+        if (!rejoined) {
+            while (c.pos < lim) decode_step<false>(tabs, bpm, tdmask, c, s, 0, 0, nullptr);
+            if (q < EMIT_PARTS) {
+                const uint32_t now = pack_state(c.pos - lim, s.b, s.k);
+                if (have_old && now == mark[q - 1]) {
+                    rejoined = true;
+                    *rejoin_delta = (int)s.nblocks - (int)mark_blocks[q - 1];
+                }
+                mark[q - 1] = now;
+                mark_blocks[q - 1] = s.nblocks;
+            }
+        } else if (q < EMIT_PARTS) {
+            mark_blocks[q - 1] += (unsigned)*rejoin_delta;
         }
     }
+    return rejoined;
 }
 
 // Speculation: lane i decodes from the guess (0, 0, 0) at the start of its subsequence through OVERFLOW + 1
@@ -239,6 +254,16 @@ __global__ __launch_bounds__(WGS) void sync_kernel(const Setup* gS, const uint32
         bool redo = live && entry != my_last;
         __syncthreads();                                   // everybody has read its entry before anybody publishes
         if (redo) {
+            // a lane that has walked before (this launch or an earlier one) and did not end in the error state has marks to fall back into
+            bool have_old = my_last != 0xFFFFFFFFu && !(my_exit & 0x40000000u) && !(my_last & 0x40000000u);
+            if (have_old && !walked) {
+#pragma unroll
+                for (int q = 0; q < EMIT_PARTS - 1; ++q) {
+                    mk[q] = marks[(size_t)i * (EMIT_PARTS - 1) + q];
+                    mkb[q] = mark_blocks[(size_t)i * (EMIT_PARTS - 1) + q];
+                }
+            }
+            const unsigned nb_old = nb;
             my_last = entry;
             nb = 0;
             walked = true;
@@ -252,9 +277,13 @@ __global__ __launch_bounds__(WGS) void sync_kernel(const Setup* gS, const uint32
                 Walk wk;
                 wk.init((entry >> 8) & 0xFFu, entry & 0xFFu, tdmask);
                 const unsigned end = (t + 1) * SUBSEQ_BITS;
-                run_subsequence_marks(tabs, bpm, tdmask, c, wk, t * SUBSEQ_BITS, mk, mkb);     // (the lane's last walk is the one that counts)
-                nb = wk.nblocks;
-                my_exit = pack_state(c.pos - end, wk.b, wk.k);
+                int delta = 0;
+                if (run_subsequence_marks(tabs, bpm, tdmask, c, wk, t * SUBSEQ_BITS, mk, mkb, have_old, &delta)) {
+                    nb = nb_old + (unsigned)delta;         // the previous walk from the mark on: same exit state
+                } else {
+                    nb = wk.nblocks;
+                    my_exit = pack_state(c.pos - end, wk.b, wk.k);
+                }
             }
             redo = sh_exit[t + 1] != my_exit;
             sh_exit[t + 1] = my_exit;

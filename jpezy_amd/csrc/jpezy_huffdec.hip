@@ -55,31 +55,26 @@ __device__ __forceinline__ unsigned pad_index(unsigned i) { return i + (i >> 5);
 struct Cursor {
     const uint32_t* w;
     unsigned pos;
-    uint32_t w0, w1, w2;
+    unsigned long long ww;        // the word that holds the bit at pos (high half) and the one after it
+    uint32_t w2;
     unsigned nxt;                 // window index of the word after w2
     __device__ __forceinline__ void init(const uint32_t* win, unsigned rel)
     {
         w = win;
         pos = rel;
         const unsigned i = rel >> 5;
-        w0 = w[pad_index(i)];
-        w1 = w[pad_index(i + 1)];
+        ww = ((unsigned long long)w[pad_index(i)] << 32) | w[pad_index(i + 1)];
         w2 = w[pad_index(i + 2)];
         nxt = i + 3;
     }
-    // the 32 bits at pos: (w0 << sh) | (w1 >> (32 - sh)), written so that sh = 0 needs no special case (and no branch)
-    __device__ __forceinline__ uint32_t peek32() const
-    {
-        const unsigned sh = pos & 31u;
-        return (w0 << sh) | ((w1 >> 1) >> (31u - sh));
-    }
+    // the 32 bits at pos: one 64-bit shift (round 3 formed them from two 32-bit words in four instructions)
+    __device__ __forceinline__ uint32_t peek32() const { return (uint32_t)((ww << (pos & 31u)) >> 32); }
     __device__ __forceinline__ uint32_t prefetch() const { return w[pad_index(nxt)]; }     // issued at the top of a step, used at its bottom
     __device__ __forceinline__ void advance(unsigned np, uint32_t ahead)               // np - pos <= 32: at most one word further
     {
         const bool adv = ((np ^ pos) >> 5) != 0u;
         pos = np;
-        w0 = adv ? w1 : w0;
-        w1 = adv ? w2 : w1;
+        ww = adv ? (ww << 32) | w2 : ww;
         w2 = adv ? ahead : w2;
         nxt += adv ? 1u : 0u;
     }

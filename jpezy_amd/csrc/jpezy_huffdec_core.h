@@ -23,9 +23,10 @@ namespace huffdec {
 // a handful of prefixes -- five for the Annex K tables; a table that needs more than MAX_SUB of them is left to the host decoder).
 // An entry says everything the decoder's state machine needs: E_VALID | E_EOB (AC symbol 0x00) | run << 9 | s << 4 | (length - 1), with s
 // the number of value bits that follow the code (AC: low nibble of the symbol; DC: the symbol, a category above 16 has no entry).  An unused
-// slot is 0: not a code.
+// slot is E_NOT_A_CODE: no E_VALID, and otherwise an end-of-block of one bit -- what a synchronisation walk does with bits that are no
+// code (abandon the block, move one bit on) then needs no test of its own (round 4); the coefficient pass tests E_VALID.
 constexpr int L1_BITS = 10, L2_BITS = 6, MAX_SUB = 16;
-constexpr unsigned E_VALID = 0x8000u, E_LONG = 0x4000u, E_EOB = 0x2000u;
+constexpr unsigned E_VALID = 0x8000u, E_LONG = 0x4000u, E_EOB = 0x2000u, E_NOT_A_CODE = E_EOB;
 struct alignas(16) Table {
     uint16_t l1[1 << L1_BITS];
     uint16_t l2[MAX_SUB << L2_BITS];
@@ -50,7 +51,8 @@ static_assert(sizeof(Table) == 4096 && sizeof(Setup) % 16 == 0, "table layout th
 // defines what it means.
 inline bool build_dev_table(Table& t, const uint8_t bits[16], const uint8_t* vals, int n, bool dc)
 {
-    memset(&t, 0, sizeof t);
+    for (uint16_t& e : t.l1) e = (uint16_t)E_NOT_A_CODE;
+    for (uint16_t& e : t.l2) e = (uint16_t)E_NOT_A_CODE;
     (void)n;
     unsigned code = 0;
     int p = 0, subs = 0;
@@ -132,14 +134,14 @@ JPEZY_HD bool decode_step(const uint16_t* tabs, unsigned bpm, unsigned tdmask, C
     const unsigned e = lng ? e2 : e1;
     const unsigned len = (e & 15u) + 1u, sz = (e >> 4) & 31u, run = (e >> 9) & 15u;
     const unsigned kk = s.k + run + 1u;                               // zig-zag index after this symbol
-    const bool bad = !(e & E_VALID) || kk > 64u;
     if (EMIT) {
-        if (bad) return false;
+        if (!(e & E_VALID) || kk > 64u) return false;
         if (sz && gidx + s.nblocks < total)
             out[(gidx + s.nblocks) * 64 + kk - 1u] = (int16_t)extend((int)((bits << len) >> (32u - sz)), (int)sz);
     }
-    const unsigned skip = bad ? 1u : len + sz;
-    const unsigned kn = (bad || (e & E_EOB)) ? 64u : kk;
+    // bits that are no code come out of the table as a one-bit end-of-block (E_NOT_A_CODE), a run past the end of the block ends it too
+    const unsigned skip = len + sz;
+    const unsigned kn = (e & E_EOB) ? 64u : kk;
     const bool endb = kn >= 64u;
     s.k = endb ? 0u : kn;
     s.nblocks += endb ? 1u : 0u;

@@ -17,19 +17,22 @@
 namespace jpezy_dev {
 namespace huffdec {
 
-// Decoding tables (round 3): two 16-bit lookups and no loop, no compare chain.  l1 is indexed by the next L1_BITS bits of the stream; a
-// code of at most L1_BITS bits is decoded by that entry alone, a longer one has E_LONG set and the entry's low 14 bits say where, in l2,
-// the 64 entries for the six bits after its 10-bit prefix start (canonical codes: the long codes sit at the top of the code space and share
-// a handful of prefixes -- five for the Annex K tables; a table that needs more than MAX_SUB of them is left to the host decoder).
+// Decoding tables: two 16-bit lookups, no loop, no compare chain -- and since round 4 the two are INDEPENDENT, so a step waits for one LDS round
+// trip, not two.  l1 is indexed by the next L1_BITS bits of the stream and decodes every code of at most L1_BITS bits.  Canonical codes ascend
+// with their length, so the longer ones sit at the top of the code space: hi is indexed by the low HI_BITS of the next 16 bits and is the
+// complete decode for every 16-bit window whose first 16 - HI_BITS bits are all ones (long codes, and the short codes that reach up there,
+// repeated).  A table with a code longer than L1_BITS bits below that region is left to the host decoder (the same capacity as round 3's
+// sixteen 64-entry second-level tables, which were reached through the first lookup's result: a dependent read).
 // An entry says everything the decoder's state machine needs: E_VALID | E_EOB (AC symbol 0x00) | run << 9 | s << 4 | (length - 1), with s
 // the number of value bits that follow the code (AC: low nibble of the symbol; DC: the symbol, a category above 16 has no entry).  An unused
 // slot is E_NOT_A_CODE: no E_VALID, and otherwise an end-of-block of one bit -- what a synchronisation walk does with bits that are no
 // code (abandon the block, move one bit on) then needs no test of its own (round 4); the coefficient pass tests E_VALID.
-constexpr int L1_BITS = 10, L2_BITS = 6, MAX_SUB = 16;
-constexpr unsigned E_VALID = 0x8000u, E_LONG = 0x4000u, E_EOB = 0x2000u, E_NOT_A_CODE = E_EOB;
+constexpr int L1_BITS = 10, HI_BITS = 10;
+constexpr unsigned E_VALID = 0x8000u, E_EOB = 0x2000u, E_NOT_A_CODE = E_EOB;
+constexpr unsigned HI_FIRST = 0x10000u - (1u << HI_BITS);        // the first 16-bit window the hi table answers for
 struct alignas(16) Table {
     uint16_t l1[1 << L1_BITS];
-    uint16_t l2[MAX_SUB << L2_BITS];
+    uint16_t hi[1 << HI_BITS];
 };
 constexpr unsigned TABLE_U16 = sizeof(Table) / 2;
 
@@ -45,43 +48,35 @@ static_assert(sizeof(Table) == 4096 && sizeof(Setup) % 16 == 0, "table layout th
 
 
 // ---- host: building the tables ----
-// The device decoder's two-level table of one Huffman table (jpezy_huffdec.h).  dc: the symbol is the number of value bits.
-// false: the counts do not describe a prefix code (more codes of some length than the code space has left), or the long codes
-// spread over more 10-bit prefixes than the table has room for -- such a table is left to the host decoder, whose canonical loop
-// defines what it means.
+// The device decoder's tables of one Huffman table (jpezy_huffdec.h).  dc: the symbol is the number of value bits.
+// false: the counts do not describe a prefix code (more codes of some length than the code space has left), or a code longer than
+// L1_BITS bits lies below the region the hi table covers -- such a table is left to the host decoder, whose canonical loop defines
+// what it means.
 inline bool build_dev_table(Table& t, const uint8_t bits[16], const uint8_t* vals, int n, bool dc)
 {
     for (uint16_t& e : t.l1) e = (uint16_t)E_NOT_A_CODE;
-    for (uint16_t& e : t.l2) e = (uint16_t)E_NOT_A_CODE;
+    for (uint16_t& e : t.hi) e = (uint16_t)E_NOT_A_CODE;
     (void)n;
     unsigned code = 0;
-    int p = 0, subs = 0;
-    long last_prefix = -1;
+    int p = 0;
     for (int l = 1; l <= 16; ++l) {
         for (int c = 0; c < bits[l - 1]; ++c, ++p, ++code) {
             if (code >= (1u << l)) return false;                     // more codes of this length than the code space has left
             const unsigned sym = vals[p];
-            unsigned e = 0;
+            unsigned e = E_NOT_A_CODE;
             if (dc) {
-                if (sym <= 16) e = E_VALID | (sym << 4) | (unsigned)(l - 1);           // a category above 16 is no symbol (entry 0)
+                if (sym <= 16) e = E_VALID | (sym << 4) | (unsigned)(l - 1);           // a category above 16 is no symbol
             } else {
                 e = E_VALID | (sym == 0 ? E_EOB : 0u) | ((sym >> 4) << 9) | ((sym & 15u) << 4) | (unsigned)(l - 1);
             }
+            const unsigned first = code << (16 - l), last = first + (1u << (16 - l)) - 1u;     // the 16-bit windows that start with this code
             if (l <= L1_BITS) {
                 const unsigned lo = code << (L1_BITS - l);
                 for (unsigned f = 0; f < (1u << (L1_BITS - l)); ++f) t.l1[lo + f] = (uint16_t)e;
-            } else {
-                const long prefix = (long)(code >> (l - L1_BITS));
-                if (prefix != last_prefix) {                         // canonical codes ascend: so do the prefixes
-                    if (subs == MAX_SUB) return false;
-                    t.l1[prefix] = (uint16_t)(E_VALID | E_LONG | (unsigned)(subs << L2_BITS));
-                    last_prefix = prefix;
-                    ++subs;
-                }
-                const int rest = L1_BITS + L2_BITS - l;      // free bits behind the code inside the 16-bit index
-                const unsigned lo = ((code << rest) & ((1u << L2_BITS) - 1u)) + (unsigned)((subs - 1) << L2_BITS);
-                for (unsigned f = 0; f < (1u << rest); ++f) t.l2[lo + f] = (uint16_t)e;
+            } else if (first < HI_FIRST) {
+                return false;                                        // a long code outside the hi table's region
             }
+            for (unsigned w = first < HI_FIRST ? HI_FIRST : first; w <= last; ++w) t.hi[w - HI_FIRST] = (uint16_t)e;
         }
         if (code > (1u << l)) return false;
         code <<= 1;
@@ -128,10 +123,8 @@ JPEZY_HD bool decode_step(const uint16_t* tabs, unsigned bpm, unsigned tdmask, C
     const uint32_t bits = c.peek32();
     const unsigned tb = s.tdoff + (s.k ? 3u * TABLE_U16 : 0u);         // dc[td] or ac[td]
     const unsigned e1 = tabs[tb + (bits >> (32 - L1_BITS))];
-    const bool lng = (e1 & E_LONG) != 0;
-    const unsigned i2 = lng ? (e1 & 0x3FFFu) + ((bits >> (32 - L1_BITS - L2_BITS)) & ((1u << L2_BITS) - 1u)) : 0u;
-    const unsigned e2 = tabs[tb + (1u << L1_BITS) + i2];
-    const unsigned e = lng ? e2 : e1;
+    const unsigned e2 = tabs[tb + (1u << L1_BITS) + ((bits >> 16) & ((1u << HI_BITS) - 1u))];      // (independent of e1: both reads are in flight together)
+    const unsigned e = bits >= (HI_FIRST << 16) ? e2 : e1;
     const unsigned len = (e & 15u) + 1u, sz = (e >> 4) & 31u, run = (e >> 9) & 15u;
     const unsigned kk = s.k + run + 1u;                               // zig-zag index after this symbol
     if (EMIT) {

@@ -151,7 +151,7 @@ __device__ __forceinline__ bool run_subsequence_marks(const uint16_t* tabs, unsi
         if (!rejoined) {
             while (c.pos < lim) decode_step<false>(tabs, bpm, tdmask, c, s, 0, 0, nullptr);
             if (q < EMIT_PARTS) {
-                const uint32_t now = pack_state(c.pos - lim, s.b, s.k);
+                const uint32_t now = pack_state(c.pos - lim, s.b(), s.k);
                 if (have_old && now == mark[q - 1]) {
                     rejoined = true;
                     *rejoin_delta = (int)s.nblocks - (int)mark_blocks[q - 1];
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(WGS) void spec_kernel(const Setup* gS, const uint32
         const unsigned end = (threadIdx.x + r + 1) * SUBSEQ_BITS;      // relative to the window's first bit, like c.pos
         run_subsequence(tabs, bpm, tdmask, c, wk, end);
         const unsigned long long rank = i == 0 ? 0xFFFFull : r;
-        atomicMax(proposal + i + r, (rank << 32) | pack_state(c.pos - end, wk.b, wk.k));
+        atomicMax(proposal + i + r, (rank << 32) | pack_state(c.pos - end, wk.b(), wk.k));
     }
 }
 
@@ -277,7 +277,7 @@ __global__ __launch_bounds__(WGS) void sync_kernel(const Setup* gS, const uint32
                     nb = nb_old + (unsigned)delta;         // the previous walk from the mark on: same exit state
                 } else {
                     nb = wk.nblocks;
-                    my_exit = pack_state(c.pos - end, wk.b, wk.k);
+                    my_exit = pack_state(c.pos - end, wk.b(), wk.k);
                 }
             }
             redo = sh_exit[t + 1] != my_exit;
@@ -671,7 +671,7 @@ __global__ __launch_bounds__(WGS) void spec_batch_kernel(const Setup* setups, co
         const unsigned end = (threadIdx.x + r + 1) * SUBSEQ_BITS;
         run_subsequence(tabs, bpm, tdmask, c, wk, end);
         const unsigned long long rank = i == 0 ? 0xFFFFull : r;
-        atomicMax(prop + i + r, (rank << 32) | pack_state(c.pos - end, wk.b, wk.k));
+        atomicMax(prop + i + r, (rank << 32) | pack_state(c.pos - end, wk.b(), wk.k));
     }
 }
 
@@ -719,7 +719,7 @@ __global__ __launch_bounds__(WGS) void sync_batch_kernel(const Setup* setups, co
                 const unsigned end = (t + 1) * SUBSEQ_BITS;
                 run_subsequence(tabs, bpm, tdmask, c, wk, end);
                 nb = wk.nblocks;
-                my_exit = pack_state(c.pos - end, wk.b, wk.k);
+                my_exit = pack_state(c.pos - end, wk.b(), wk.k);
             }
             redo = sh_exit[t + 1] != my_exit;
             sh_exit[t + 1] = my_exit;

@@ -23,12 +23,17 @@ namespace huffdec {
 // complete decode for every 16-bit window whose first 16 - HI_BITS bits are all ones (long codes, and the short codes that reach up there,
 // repeated).  A table with a code longer than L1_BITS bits below that region is left to the host decoder (the same capacity as round 3's
 // sixteen 64-entry second-level tables, which were reached through the first lookup's result: a dependent read).
-// An entry says everything the decoder's state machine needs: E_VALID | E_EOB (AC symbol 0x00) | run << 9 | s << 4 | (length - 1), with s
-// the number of value bits that follow the code (AC: low nibble of the symbol; DC: the symbol, a category above 16 has no entry).  An unused
-// slot is E_NOT_A_CODE: no E_VALID, and otherwise an end-of-block of one bit -- what a synchronisation walk does with bits that are no
-// code (abandon the block, move one bit on) then needs no test of its own (round 4); the coefficient pass tests E_VALID.
+// An entry says everything the decoder's state machine needs, laid out so that a walk takes it apart with two instructions (round 4):
+//   bits 4..0   len + s - 1   bits to move on, minus one (len: code length, s: value bits that follow -- AC: low nibble of the symbol; DC: the
+//                             symbol, a category above 16 has no entry)
+//   bits 9..5   s             (31: not a code -- only the coefficient pass looks)
+//   bits 15..10 run           zig-zag positions skipped in front of the coefficient; 63 for the end-of-block symbol and for bits that are
+//                             no code, which therefore ends the block at any position: what a synchronisation walk does with garbage
+//                             (abandon the block, move one bit on) needs no test of its own
 constexpr int L1_BITS = 10, HI_BITS = 10;
-constexpr unsigned E_VALID = 0x8000u, E_EOB = 0x2000u, E_NOT_A_CODE = E_EOB;
+constexpr unsigned E_RUN_END = 63u, E_S_NONE = 31u;
+constexpr unsigned E_NOT_A_CODE = (E_RUN_END << 10) | (E_S_NONE << 5);       // one bit on, block ended
+constexpr unsigned make_entry(unsigned len, unsigned s, unsigned run) { return (run << 10) | (s << 5) | (len + s - 1u); }
 constexpr unsigned HI_FIRST = 0x10000u - (1u << HI_BITS);        // the first 16-bit window the hi table answers for
 struct alignas(16) Table {
     uint16_t l1[1 << L1_BITS];
@@ -65,9 +70,9 @@ inline bool build_dev_table(Table& t, const uint8_t bits[16], const uint8_t* val
             const unsigned sym = vals[p];
             unsigned e = E_NOT_A_CODE;
             if (dc) {
-                if (sym <= 16) e = E_VALID | (sym << 4) | (unsigned)(l - 1);           // a category above 16 is no symbol
+                if (sym <= 16) e = make_entry((unsigned)l, sym, 0u);                   // a category above 16 is no symbol
             } else {
-                e = E_VALID | (sym == 0 ? E_EOB : 0u) | ((sym >> 4) << 9) | ((sym & 15u) << 4) | (unsigned)(l - 1);
+                e = make_entry((unsigned)l, sym & 15u, sym == 0 ? E_RUN_END : sym >> 4);
             }
             const unsigned first = code << (16 - l), last = first + (1u << (16 - l)) - 1u;     // the 16-bit windows that start with this code
             if (l <= L1_BITS) {
@@ -98,50 +103,58 @@ inline bool pack_td_sequence(const int* seq, int period, unsigned* mask)
 // ---- the decode step (device and host) ----
 JPEZY_HD int extend(int v, int cat) { return (v & (1 << (cat - 1))) ? v : v - ((1 << cat) - 1); }
 
-// The decoder's state besides the cursor: block inside the table period, zig-zag index (0: a DC symbol comes next), and the
-// offset of the block's table pair inside the Setup (in uint16 units).
+// The decoder's state besides the cursor: block inside the table period (doubled: the shift that finds its table selector), zig-zag
+// index (0: a DC symbol comes next), the offsets (uint16 units) of the block's table pair and of the AC half inside it.
 struct Walk {
-    unsigned b, k, tdoff, nblocks;
+    unsigned b2, k, tdoff, kb, nblocks;
+    unsigned long long tdm;              // table offset of block b of a period in bits [2 b + 12 : 2 b + 11]
     JPEZY_HD void init(unsigned b_, unsigned k_, unsigned tdmask)
     {
-        b = b_; k = k_; nblocks = 0;
-        tdoff = ((tdmask >> (2u * b)) & 3u) * TABLE_U16;
+        b2 = 2u * b_; k = k_; nblocks = 0;
+        kb = k_ ? 3u * TABLE_U16 : 0u;
+        tdm = 0;
+        for (unsigned q = 0; q < (unsigned)MAX_PERIOD; ++q) tdm |= (unsigned long long)((tdmask >> (2u * q)) & 3u) << (2u * q + 11u);
+        tdoff = (unsigned)(tdm >> b2) & 0x1800u;
     }
+    JPEZY_HD unsigned b() const { return b2 >> 1; }
 };
+static_assert(TABLE_U16 == 2048u, "Walk::tdm places the table selector at the bits of TABLE_U16");
 
 // One symbol.  DC and AC symbols run through the same instructions (the lanes of a wave are at unrelated places of their blocks): a DC
-// symbol is a (run 0, size = category) symbol at k = 0 from the DC table.  Straight-line code: every decision is a select.
-// An invalid code, or a run past the end of the block: EMIT returns false (the true decode hit it: the stream is bad); a
-// synchronisation pass -- which may well be decoding from a wrong guess, i.e. garbage -- abandons the block, moves one bit on and
-// carries on, so that it can still fall into step further down.
+// symbol is a (run 0, size = category) symbol at k = 0 from the DC table.  Straight-line code: every decision is a select; the two table
+// reads do not depend on each other.  Bits that are no code, or a run past the end of the block: EMIT returns false (the true decode hit
+// it: the stream is bad); a synchronisation pass -- which may well be decoding from a wrong guess, i.e. garbage -- abandons the block
+// (one bit on for a non-code) and carries on, so that it can still fall into step further down.
 // EMIT: coefficients of blocks gidx + nblocks < total go to out (DC: the difference, made absolute by the DC pass).
 template <bool EMIT, class CursorT>
 JPEZY_HD bool decode_step(const uint16_t* tabs, unsigned bpm, unsigned tdmask, CursorT& c, Walk& s,
                                             unsigned long long gidx, unsigned total, int16_t* out)
 {
+    (void)tdmask;
     const uint32_t ahead = c.prefetch();                               // used only when this symbol crosses a word boundary
     const uint32_t bits = c.peek32();
-    const unsigned tb = s.tdoff + (s.k ? 3u * TABLE_U16 : 0u);         // dc[td] or ac[td]
+    const unsigned tb = s.tdoff + s.kb;                                // dc[td] or ac[td]
     const unsigned e1 = tabs[tb + (bits >> (32 - L1_BITS))];
     const unsigned e2 = tabs[tb + (1u << L1_BITS) + ((bits >> 16) & ((1u << HI_BITS) - 1u))];      // (independent of e1: both reads are in flight together)
     const unsigned e = bits >= (HI_FIRST << 16) ? e2 : e1;
-    const unsigned len = (e & 15u) + 1u, sz = (e >> 4) & 31u, run = (e >> 9) & 15u;
-    const unsigned kk = s.k + run + 1u;                               // zig-zag index after this symbol
+    const unsigned skipm1 = e & 31u, run = e >> 10;
+    const unsigned kk = s.k + run + 1u;                               // zig-zag index after this symbol (beyond 63: the block is over)
     if (EMIT) {
-        if (!(e & E_VALID) || kk > 64u) return false;
-        if (sz && gidx + s.nblocks < total)
+        const unsigned sz = (e >> 5) & 31u;
+        if (sz == E_S_NONE || (run != E_RUN_END && kk > 64u)) return false;
+        if (sz && gidx + s.nblocks < total) {
+            const unsigned len = skipm1 + 1u - sz;
             out[(gidx + s.nblocks) * 64 + kk - 1u] = (int16_t)extend((int)((bits << len) >> (32u - sz)), (int)sz);
+        }
     }
-    // bits that are no code come out of the table as a one-bit end-of-block (E_NOT_A_CODE), a run past the end of the block ends it too
-    const unsigned skip = len + sz;
-    const unsigned kn = (e & E_EOB) ? 64u : kk;
-    const bool endb = kn >= 64u;
-    s.k = endb ? 0u : kn;
+    const bool endb = kk > 63u;
+    s.k = endb ? 0u : kk;
+    s.kb = endb ? 0u : 3u * TABLE_U16;
     s.nblocks += endb ? 1u : 0u;
-    const unsigned b1 = s.b + 1u == bpm ? 0u : s.b + 1u;
-    s.b = endb ? b1 : s.b;
-    s.tdoff = ((tdmask >> (2u * s.b)) & 3u) * TABLE_U16;
-    c.advance(c.pos + skip, ahead);
+    const unsigned n2 = s.b2 + 2u == 2u * bpm ? 0u : s.b2 + 2u;
+    s.b2 = endb ? n2 : s.b2;
+    s.tdoff = (unsigned)(s.tdm >> s.b2) & 0x1800u;
+    c.advance(c.pos + skipm1 + 1u, ahead);
     return true;
 }
 

@@ -1,4 +1,4 @@
-// CPU harness for the core of the GPU Huffman decoder (jpezy_amd/csrc/jpezy_huffdec_core.h: the two-level tables, their builder and
+// CPU harness for the core of the GPU Huffman decoder (jpezy_amd/csrc/jpezy_huffdec_core.h: the two lookup tables, their builder and
 // the one-symbol decode step the kernels run) -- built by g++ with AddressSanitizer + UBSan and driven by tests/fuzz/run_host_fuzz.py;
 // no HIP involved.  Every file named on the command line (or listed in @file) that the host parser accepts and that has no restart
 // intervals is decoded TWICE: by the host decoder (jpezy_host::read_jpeg, the authoritative one) and by walking the unstuffed scan
@@ -39,6 +39,44 @@ struct HostCursor {
     void advance(unsigned np, uint32_t) { pos = np; }
 };
 
+// Every 16-bit window of the stream against the canonical code itself (the loop of ITU T.81 F.2.2.3 over bits / vals): the entry the
+// step would pick -- l1 by the first L1_BITS bits, hi by the last HI_BITS when the window starts with 16 - HI_BITS ones -- must carry the
+// code's length, value-bit count and run, and E_NOT_A_CODE where no code matches.  A table the builder declines must have a code longer
+// than L1_BITS bits below the hi region (or counts that are no prefix code).  Returns false on any mismatch.
+static bool check_table(const HD::Table& t, bool built, const uint8_t bits[16], const uint8_t* vals, bool dc, const char* what)
+{
+    unsigned first[17], code = 0, at[17];
+    int p = 0;
+    bool prefix_code = true, long_low = false;
+    for (int l = 1; l <= 16; ++l) {
+        first[l] = code; at[l] = (unsigned)p;
+        if (code + bits[l - 1] > (1u << l)) prefix_code = false;
+        if (l > HD::L1_BITS && bits[l - 1] && (code << (16 - l)) < HD::HI_FIRST) long_low = true;
+        code = (code + bits[l - 1]) << 1;
+        p += bits[l - 1];
+    }
+    if (!built) {
+        if (prefix_code && !long_low) { std::fprintf(stderr, "%s: the builder declined a table it can express\n", what); return false; }
+        return true;
+    }
+    if (!prefix_code || long_low) { std::fprintf(stderr, "%s: the builder accepted a table it cannot express\n", what); return false; }
+    for (unsigned w = 0; w < 0x10000u; ++w) {
+        unsigned want = HD::E_NOT_A_CODE;
+        for (int l = 1; l <= 16; ++l) {
+            const unsigned c = w >> (16 - l);
+            if (c >= first[l] && c < first[l] + bits[l - 1]) {
+                const unsigned sym = vals[at[l] + (c - first[l])];
+                if (dc) { if (sym <= 16) want = HD::make_entry((unsigned)l, sym, 0u); }
+                else want = HD::make_entry((unsigned)l, sym & 15u, sym == 0 ? HD::E_RUN_END : sym >> 4);
+                break;
+            }
+        }
+        const unsigned got = w >= HD::HI_FIRST ? t.hi[w - HD::HI_FIRST] : t.l1[w >> (16 - HD::L1_BITS)];
+        if (got != want) { std::fprintf(stderr, "%s: window %04x decodes to %04x, the canonical code says %04x\n", what, w, got, want); return false; }
+    }
+    return true;
+}
+
 int main(int argc, char** argv)
 {
     std::vector<std::string> files;
@@ -48,7 +86,7 @@ int main(int argc, char** argv)
             for (std::string s; std::getline(l, s);) if (!s.empty()) files.push_back(s);
         } else files.push_back(argv[i]);
     }
-    size_t walked = 0, declined = 0, skipped = 0, host_rejected_after_decline = 0;
+    size_t walked = 0, declined = 0, skipped = 0, host_rejected_after_decline = 0, tables_checked = 0;
     for (const std::string& path : files) {
         const std::vector<unsigned char> d = slurp(path.c_str());
         const bool is_seed = path.find("/seed") != std::string::npos;
@@ -71,8 +109,17 @@ int main(int argc, char** argv)
         std::memset(&S, 0, sizeof S);
         bool tables = true;
         for (int td = 0; td < 3; ++td) {
-            if (setup.present[td]) tables = HD::build_dev_table(S.dc[td], setup.bits[td], setup.vals[td], setup.nvals[td], true) && tables;
-            if (setup.present[4 + td]) tables = HD::build_dev_table(S.ac[td], setup.bits[4 + td], setup.vals[4 + td], setup.nvals[4 + td], false) && tables;
+            if (setup.present[td]) {
+                const bool b = HD::build_dev_table(S.dc[td], setup.bits[td], setup.vals[td], setup.nvals[td], true);
+                if (!check_table(S.dc[td], b, setup.bits[td], setup.vals[td], true, path.c_str())) return 1;
+                tables = b && tables;
+            }
+            if (setup.present[4 + td]) {
+                const bool b = HD::build_dev_table(S.ac[td], setup.bits[4 + td], setup.vals[4 + td], setup.nvals[4 + td], false);
+                if (!check_table(S.ac[td], b, setup.bits[4 + td], setup.vals[4 + td], false, path.c_str())) return 1;
+                tables = b && tables;
+            }
+            tables_checked += (setup.present[td] ? 1 : 0) + (setup.present[4 + td] ? 1 : 0);
         }
         int seq[48], nb = 0;
         for (int q = 0; q < info.ncomp; ++q)
@@ -135,7 +182,34 @@ int main(int argc, char** argv)
         }
         ++walked;
     }
-    std::printf("decode step on the CPU: %zu files walked and equal to the host decoder, %zu declined (%zu of them rejected by the host decoder too), %zu not for this path\n",
-                walked, declined, host_rejected_after_decline, skipped);
+    // random canonical codes (not only the ones files carry): counts per length drawn so that they stay a prefix code, random symbols
+    size_t random_tables = 0, random_declined = 0;
+    {
+        uint64_t rs = 0x6A70657A79ull;
+        auto rnd = [&rs](unsigned n) { rs = rs * 6364136223846793005ull + 1442695040888963407ull; return (unsigned)((rs >> 33) % n); };
+        for (int it = 0; it < 3000; ++it) {
+            uint8_t bits[16], vals[256];
+            unsigned space = 0x10000u - 1u, total = 0;                      // (the all-ones code stays free, as JPEG asks)
+            const int lmin = 1 + (int)rnd(4);
+            for (int l = 1; l <= 16; ++l) {
+                const unsigned unit = 1u << (16 - l), room = space / unit;
+                unsigned n = 0;
+                if (l >= lmin && room) n = rnd(room < 24 ? room + 1 : 24);
+                if (l == 16) n = room < 255u - total ? room : 255u - total;  // fill what is left at the bottom
+                if (total + n > 255) n = 255 - total;
+                bits[l - 1] = (uint8_t)n; total += n; space -= n * unit;
+            }
+            const bool dc = (it & 3) == 0;
+            for (unsigned k = 0; k < total; ++k) vals[k] = (uint8_t)(dc ? rnd(20) : rnd(256));
+            HD::Table t;
+            const bool b = HD::build_dev_table(t, bits, vals, (int)total, dc);
+            if (!check_table(t, b, bits, vals, dc, "random table")) return 1;
+            ++random_tables;
+            random_declined += b ? 0 : 1;
+        }
+    }
+    std::printf("decode step on the CPU: %zu files walked and equal to the host decoder, %zu declined (%zu of them rejected by the host decoder too), %zu not for this path; "
+                "%zu tables of files and %zu random ones (%zu declined by the builder) checked window by window against their canonical codes\n",
+                walked, declined, host_rejected_after_decline, skipped, tables_checked, random_tables, random_declined);
     return 0;
 }

@@ -219,6 +219,10 @@ def test_host_codec_under_asan_ubsan_on_mutated_files():
     # decodes, and no encoder's file is declined
     m = re.search(r"decode step on the CPU: (\d+) files walked and equal to the host decoder", r.stdout)
     assert m and int(m.group(1)) >= 100, r.stdout
+    # ... and every table of those files, and 3,000 random canonical codes, decode each of the 65,536 16-bit windows as the canonical
+    # code says, through the two independent lookups of round 4; what the builder declines it cannot express
+    m = re.search(r"(\d+) tables of files and (\d+) random ones \((\d+) declined", r.stdout)
+    assert m and int(m.group(1)) >= 400 and int(m.group(2)) == 3000 and 0 < int(m.group(3)) < 3000, r.stdout
 
 
 def test_scan_that_selects_an_undefined_table_is_an_error(golden_dir):

@@ -410,10 +410,12 @@ try {
     // ScanState on the device; launches are sized for the upper bound n_sub_max and their workgroups leave when they lie beyond the data.  A second
     // synchronisation launch is enqueued blindly behind the first: it leaves at once when the first one settled everything (or found a stream
     // that does not synchronise).  The tables go up only when they differ from the ones the context already holds (profiles/r04_huffdec_*).
-    if (c->h_setup_host.size() != sizeof S || std::memcmp(c->h_setup_host.data(), &S, sizeof S) != 0) {
+    if (c->h_setup_dev != c->h_setup.p || c->h_setup_host.size() != sizeof S || std::memcmp(c->h_setup_host.data(), &S, sizeof S) != 0) {
+        c->h_setup_dev = nullptr;            // (stays null if the upload fails: the next call uploads again)
         c->h_setup_host.assign(reinterpret_cast<const uint8_t*>(&S), reinterpret_cast<const uint8_t*>(&S) + sizeof S);
         // (from the context's own copy: it outlives the asynchronous upload)
         HIP_TRY(hipMemcpyAsync(c->h_setup.p, c->h_setup_host.data(), sizeof S, hipMemcpyHostToDevice, s));
+        c->h_setup_dev = c->h_setup.p;
     }
     HIP_TRY(hipMemcpyAsync(c->h_scan.p, scan, n, hipMemcpyHostToDevice, s));
 

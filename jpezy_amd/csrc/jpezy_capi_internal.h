@@ -153,6 +153,7 @@ struct jpezy_ctx {
     size_t e_pinned_cap = 0;
     DevBuf h_scan, h_U, h_cnt, h_off, h_state, h_setup, h_small, h_dc;   // GPU Huffman decoder (jpezy_huffdec.hip)
     std::vector<uint8_t> h_setup_host;  // the device tables h_setup holds (jpezy_read_jpeg_gpu uploads them only when they change)
+    const void* h_setup_dev = nullptr;  // ... and the allocation they were uploaded to
     int h_last_passes = 0;         // synchronisation passes of the last jpezy_read_jpeg_gpu (0: the host decoder was used)
     size_t h_min_bytes = 64 << 10;    // scans shorter than this are decoded on the host: the GPU path has ~0.6 ms of fixed cost, the host decoder
                                       // takes ~11 us per KiB of a dense scan (tools/huffdec_threshold.py: they cross at 56 KiB; round 2: 3 ms, 256 KiB)

@@ -65,6 +65,18 @@ struct ScanState {
     unsigned pad1[3];
 };
 static_assert(sizeof(ScanState) == 80, "ScanState is read back in one copy");
+// Did the two synchronisation launches enqueued blindly settle the scan?  changed: the first launch's counters, changed2: the second's (which
+// left at once unless the first one left something for it).  The host and the guarded coefficient / DC launches ask the same function.
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline bool scan_settled(const unsigned* changed, const unsigned* changed2, unsigned n_sub)
+{
+    if (n_sub == 0u) return false;
+    if (changed[1] == 0u && changed[2] == 0u) return true;                       // nothing pending after the first launch
+    if (changed[3] > n_sub / 2u + 16u) return false;                             // a stream that does not synchronise: the second launch left at once
+    return changed2[1] == 0u && changed2[2] == 0u;
+}
 hipError_t launch_scan_state_init(ScanState* st, hipStream_t s);
 // S: the file from the first byte of the scan on (n_max bytes).  The count launch also finds where the entropy-coded segment ends
 // (st->first_marker: offset of the first 0xFF that is followed by anything but 0x00 or is the last byte; still all ones when there is none);
@@ -88,13 +100,16 @@ hipError_t launch_speculate(const Setup* S, const uint32_t* U, size_t u_words, u
 unsigned emit_parts();
 hipError_t launch_sync(const Setup* S, const uint32_t* U, size_t u_words, unsigned n_sub_max, const ScanState* st, uint32_t* exit_state, uint32_t* last_entry,
                        unsigned* nblocks, uint32_t* marks, unsigned* mark_blocks, unsigned* changed, const unsigned* prev, int max_inner, hipStream_t s);
+// guarded: the launch is enqueued before anybody has looked at the synchronisation launches' counters and leaves at once unless scan_settled()
 hipError_t launch_emit(const Setup* S, const uint32_t* U, size_t u_words, unsigned n_sub_max, ScanState* st, const uint32_t* exit_state,
-                       const uint32_t* marks, const unsigned* mark_blocks, const unsigned long long* blocks_before, int16_t* out, hipStream_t s);
+                       const uint32_t* marks, const unsigned* mark_blocks, const unsigned long long* blocks_before, int16_t* out, bool guarded,
+                       hipStream_t s);
 // DC differences -> values for all components of one scan in three launches (component q owns blocks [cstart[q], cstart[q] + ccount[q]) of
 // every MCU); scratch: dc_prefix_scratch_ints(nmcu, largest ccount) ints
 size_t dc_prefix_scratch_ints(size_t nmcu, unsigned max_count);
+// guard (may be null): leave at once unless scan_settled(guard)
 hipError_t launch_dc_prefix(int16_t* coeffs, unsigned bpm, unsigned ncomp, const unsigned cstart[3], const unsigned ccount[3], size_t nmcu, int* scratch,
-                            hipStream_t s);
+                            const ScanState* guard, hipStream_t s);
 
 }  // namespace huffdec
 }  // namespace jpezy_dev

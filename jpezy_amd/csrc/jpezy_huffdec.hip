@@ -319,11 +319,12 @@ constexpr int EMIT_WINDOW_LINEAR = (EMIT_SUBS + 1) * SUBSEQ_BITS / 32 + 16;     
 static_assert(EMIT_WINDOW_LINEAR <= WINDOW_LINEAR && WGS % EMIT_PARTS == 0 && SUBSEQ_BITS % EMIT_PARTS == 0, "emit geometry");
 __global__ __launch_bounds__(WGS) void emit_kernel(const Setup* gS, const uint32_t* U, size_t u_words, ScanState* st, const uint32_t* exit_state,
                                                    const uint32_t* marks, const unsigned* mark_blocks, const unsigned long long* blocks_before,
-                                                   int16_t* out)
+                                                   int16_t* out, int guarded)
 {
     __shared__ Setup S;
     __shared__ uint32_t win[EMIT_WINDOW_LINEAR + EMIT_WINDOW_LINEAR / 32 + 1];
     const unsigned n_sub = st->n_sub;
+    if (guarded && !scan_settled(st->changed, st->changed2, n_sub)) return;     // (workgroup-uniform)
     unsigned* const error = &st->error;
     unsigned long long* const last_bit = &st->last_bit;
     const unsigned i0 = blockIdx.x * EMIT_SUBS, ts = threadIdx.x / EMIT_PARTS, q = threadIdx.x % EMIT_PARTS, i = i0 + ts;
@@ -367,9 +368,10 @@ __device__ __forceinline__ size_t dc_slot(const DcGeom& g, unsigned comp, size_t
     const size_t mcu = j / count, t = j - mcu * count;
     return (mcu * g.bpm + g.cstart[comp] + t) * 64;
 }
-__global__ __launch_bounds__(256) void dc_local_kernel(int16_t* coeffs, DcGeom g, int* totals, unsigned wg_per_comp)
+__global__ __launch_bounds__(256) void dc_local_kernel(int16_t* coeffs, DcGeom g, int* totals, unsigned wg_per_comp, const ScanState* guard)
 {
     __shared__ int wsum[4];
+    if (guard && !scan_settled(guard->changed, guard->changed2, guard->n_sub)) return;
     const unsigned comp = blockIdx.y;
     const size_t nd = (size_t)g.nmcu * g.ccount[comp], j0 = (size_t)blockIdx.x * DC_PER_WG + (size_t)threadIdx.x * 8;
     if ((size_t)blockIdx.x * DC_PER_WG >= nd) return;                        // workgroup-uniform
@@ -403,9 +405,10 @@ __global__ __launch_bounds__(256) void dc_local_kernel(int16_t* coeffs, DcGeom g
     if (threadIdx.x == 0) totals[(size_t)comp * wg_per_comp + blockIdx.x] = tot;
 }
 // totals -> what came before each workgroup (exclusive), one workgroup per component, 256 totals per step with a running carry
-__global__ __launch_bounds__(256) void dc_totals_kernel(int* totals, DcGeom g, unsigned wg_per_comp)
+__global__ __launch_bounds__(256) void dc_totals_kernel(int* totals, DcGeom g, unsigned wg_per_comp, const ScanState* guard)
 {
     __shared__ int wsum[4];
+    if (guard && !scan_settled(guard->changed, guard->changed2, guard->n_sub)) return;
     const unsigned comp = blockIdx.x;
     const size_t nd = (size_t)g.nmcu * g.ccount[comp];
     const unsigned n = (unsigned)((nd + DC_PER_WG - 1) / DC_PER_WG);
@@ -438,9 +441,10 @@ __global__ __launch_bounds__(256) void dc_totals_kernel(int* totals, DcGeom g, u
 // values out of the L2 -- and the launch that scanned them is gone (a dependent launch costs ~5 us)
 constexpr unsigned DC_SELF_SUM_MAX = 1024;
 template <bool SELF_SUM>
-__global__ __launch_bounds__(256) void dc_add_kernel(int16_t* coeffs, DcGeom g, const int* totals, unsigned wg_per_comp)
+__global__ __launch_bounds__(256) void dc_add_kernel(int16_t* coeffs, DcGeom g, const int* totals, unsigned wg_per_comp, const ScanState* guard)
 {
     __shared__ int red[4];
+    if (guard && !scan_settled(guard->changed, guard->changed2, guard->n_sub)) return;
     const unsigned comp = blockIdx.y;
     const size_t nd = (size_t)g.nmcu * g.ccount[comp], j0 = (size_t)blockIdx.x * DC_PER_WG + (size_t)threadIdx.x * 8;
     if (blockIdx.x == 0 || (size_t)blockIdx.x * DC_PER_WG >= nd) return;   // (nothing comes before the first workgroup)
@@ -914,15 +918,16 @@ hipError_t launch_sync(const Setup* S, const uint32_t* U, size_t u_words, unsign
     return hipGetLastError();
 }
 hipError_t launch_emit(const Setup* S, const uint32_t* U, size_t u_words, unsigned n_sub, ScanState* st, const uint32_t* exit_state,
-                       const uint32_t* marks, const unsigned* mark_blocks, const unsigned long long* blocks_before, int16_t* out, hipStream_t s)
+                       const uint32_t* marks, const unsigned* mark_blocks, const unsigned long long* blocks_before, int16_t* out, bool guarded,
+                       hipStream_t s)
 {
     hipLaunchKernelGGL(emit_kernel, dim3((n_sub + EMIT_SUBS - 1) / EMIT_SUBS), dim3(WGS), 0, s, S, U, u_words, st, exit_state, marks, mark_blocks,
-                       blocks_before, out);
+                       blocks_before, out, guarded ? 1 : 0);
     return hipGetLastError();
 }
 size_t dc_prefix_scratch_ints(size_t nmcu, unsigned max_count) { return 3 * ((nmcu * max_count + DC_PER_WG - 1) / DC_PER_WG + 1); }
 hipError_t launch_dc_prefix(int16_t* coeffs, unsigned bpm, unsigned ncomp, const unsigned cstart[3], const unsigned ccount[3], size_t nmcu, int* scratch,
-                            hipStream_t s)
+                            const ScanState* guard, hipStream_t s)
 {
     DcGeom g;
     g.bpm = bpm; g.ncomp = ncomp; g.nmcu = nmcu;
@@ -931,16 +936,16 @@ hipError_t launch_dc_prefix(int16_t* coeffs, unsigned bpm, unsigned ncomp, const
     const size_t wgs = (nmcu * maxc + DC_PER_WG - 1) / DC_PER_WG;
     if (!wgs || !ncomp) return hipSuccess;
     if (wgs > 0x7FFFFFFFull) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(dc_local_kernel, dim3((unsigned)wgs, ncomp), dim3(256), 0, s, coeffs, g, scratch, (unsigned)wgs + 1);
+    hipLaunchKernelGGL(dc_local_kernel, dim3((unsigned)wgs, ncomp), dim3(256), 0, s, coeffs, g, scratch, (unsigned)wgs + 1, guard);
     static const size_t self_sum_max = [] {
         const char* e = std::getenv("JPEZY_DC_SELF_SUM_MAX");        // development / test knob: 0 forces the three-launch form
         return e ? (size_t)std::atoll(e) : (size_t)DC_SELF_SUM_MAX;
     }();
     if (wgs <= self_sum_max) {
-        hipLaunchKernelGGL(dc_add_kernel<true>, dim3((unsigned)wgs, ncomp), dim3(256), 0, s, coeffs, g, (const int*)scratch, (unsigned)wgs + 1);
+        hipLaunchKernelGGL(dc_add_kernel<true>, dim3((unsigned)wgs, ncomp), dim3(256), 0, s, coeffs, g, (const int*)scratch, (unsigned)wgs + 1, guard);
     } else {
-        hipLaunchKernelGGL(dc_totals_kernel, dim3(ncomp), dim3(256), 0, s, scratch, g, (unsigned)wgs + 1);
-        hipLaunchKernelGGL(dc_add_kernel<false>, dim3((unsigned)wgs, ncomp), dim3(256), 0, s, coeffs, g, (const int*)scratch, (unsigned)wgs + 1);
+        hipLaunchKernelGGL(dc_totals_kernel, dim3(ncomp), dim3(256), 0, s, scratch, g, (unsigned)wgs + 1, guard);
+        hipLaunchKernelGGL(dc_add_kernel<false>, dim3((unsigned)wgs, ncomp), dim3(256), 0, s, coeffs, g, (const int*)scratch, (unsigned)wgs + 1, guard);
     }
     return hipGetLastError();
 }

@@ -152,7 +152,7 @@ void jpezy_ctx_destroy(jpezy_ctx* c)
     for (DevBuf* b : { &c->b_scan, &c->b_U, &c->b_cnt, &c->b_rb, &c->b_state, &c->b_prop, &c->b_meta, &c->b_coef }) b->release();
     for (DevBuf& b : c->b_planes) b.release();
     for (DevBuf* b : { &c->e_tmp, &c->e_small, &c->e_U, &c->e_cnt, &c->e_out, &c->e_coef, &c->e_hdr, &c->e_status, &c->e_tt, &c->e_fft, &c->e_S, &c->e_base, &c->e_ft,
-                       &c->dump_t, &c->h_scan, &c->h_U, &c->h_cnt, &c->h_off, &c->h_state, &c->h_setup, &c->h_small, &c->h_dc }) b->release();
+                       &c->dump_t, &c->h_scan, &c->h_U, &c->h_cnt, &c->h_off, &c->h_state, &c->h_setup, &c->h_small, &c->h_dc, &c->h_dcbuf }) b->release();
     delete c;
 }
 

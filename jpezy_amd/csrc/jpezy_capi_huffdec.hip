@@ -377,6 +377,7 @@ try {
     if (int r2 = c->h_state.reserve((size_t)n_sub_max * (3 + 2 * (HD::emit_parts() - 1)) * sizeof(uint32_t))) return r2;
     if (int r2 = c->h_setup.reserve(sizeof(HD::Setup))) return r2;
     if (int r2 = c->h_small.reserve(sizeof(HD::ScanState))) return r2;
+    if (int r2 = c->h_dcbuf.reserve(total_blocks * sizeof(int16_t) + 64)) return r2;
     size_t max_dc = 0;
     for (int i = 0; i < info->ncomp; ++i) max_dc = std::max(max_dc, nmcu * (size_t)(info->H[i] * info->V[i]));
     if (int r2 = c->h_dc.reserve(std::max((2 * max_dc + 2), (size_t)n_sub) * sizeof(unsigned long long))) return r2;
@@ -465,10 +466,10 @@ try {
         HIP_TRY(E::launch_scan_u32((const uint32_t*)d_nblocks, (unsigned long long*)c->h_off.p, n_sub_max, (unsigned long long*)c->e_tmp.p, s));
         HIP_TRY(hipMemsetAsync(d_coeffs, 0, total * sizeof(int16_t), s));
         HIP_TRY(HD::launch_emit((const HD::Setup*)c->h_setup.p, (const uint32_t*)c->h_U.p, u_bytes / 4, n_sub_max, d_st, d_exit, d_marks, d_mark_blocks,
-                                (const unsigned long long*)c->h_off.p, d_coeffs, guarded, s));
+                                (const unsigned long long*)c->h_off.p, d_coeffs, (int16_t*)c->h_dcbuf.p, guarded, s));
         // DC differences -> values, all components in two launches (round 2: gather, two-launch scan, scatter per component = twelve)
         const StreamGeom g = jpezy_internal_stream_geom(*info);
-        HIP_TRY(HD::launch_dc_prefix(d_coeffs, g.bpm, g.ncomp, g.cstart, g.ccount, nmcu, (int*)c->h_dc.p, guarded ? d_st : nullptr, s));
+        HIP_TRY(HD::launch_dc_prefix(d_coeffs, (int16_t*)c->h_dcbuf.p, g.bpm, g.ncomp, g.cstart, g.ccount, nmcu, (int*)c->h_dc.p, guarded ? d_st : nullptr, s));
         return JPEZY_OK;
     };
     if (!dbg)

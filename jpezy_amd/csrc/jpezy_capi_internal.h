@@ -151,7 +151,7 @@ struct jpezy_ctx {
     DevBuf e_status;               // per-frame error flags of the device-resident entropy path: zero between calls (cleared by their consumer)
     uint8_t* e_pinned = nullptr;   // pinned host staging of the stuffed streams
     size_t e_pinned_cap = 0;
-    DevBuf h_scan, h_U, h_cnt, h_off, h_state, h_setup, h_small, h_dc;   // GPU Huffman decoder (jpezy_huffdec.hip)
+    DevBuf h_scan, h_U, h_cnt, h_off, h_state, h_setup, h_small, h_dc, h_dcbuf;   // GPU Huffman decoder (jpezy_huffdec.hip)
     std::vector<uint8_t> h_setup_host;  // the device tables h_setup holds (jpezy_read_jpeg_gpu uploads them only when they change)
     const void* h_setup_dev = nullptr;  // ... and the allocation they were uploaded to
     int h_last_passes = 0;         // synchronisation passes of the last jpezy_read_jpeg_gpu (0: the host decoder was used)

@@ -102,14 +102,15 @@ hipError_t launch_sync(const Setup* S, const uint32_t* U, size_t u_words, unsign
                        unsigned* nblocks, uint32_t* marks, unsigned* mark_blocks, unsigned* changed, const unsigned* prev, int max_inner, hipStream_t s);
 // guarded: the launch is enqueued before anybody has looked at the synchronisation launches' counters and leaves at once unless scan_settled()
 hipError_t launch_emit(const Setup* S, const uint32_t* U, size_t u_words, unsigned n_sub_max, ScanState* st, const uint32_t* exit_state,
-                       const uint32_t* marks, const unsigned* mark_blocks, const unsigned long long* blocks_before, int16_t* out, bool guarded,
-                       hipStream_t s);
+                       const uint32_t* marks, const unsigned* mark_blocks, const unsigned long long* blocks_before, int16_t* out, int16_t* dc_out,
+                       bool guarded, hipStream_t s);       // dc_out (may be null): the DC differences go to dc_out[block], every block's
 // DC differences -> values for all components of one scan in three launches (component q owns blocks [cstart[q], cstart[q] + ccount[q]) of
 // every MCU); scratch: dc_prefix_scratch_ints(nmcu, largest ccount) ints
 size_t dc_prefix_scratch_ints(size_t nmcu, unsigned max_count);
 // guard (may be null): leave at once unless scan_settled(guard)
-hipError_t launch_dc_prefix(int16_t* coeffs, unsigned bpm, unsigned ncomp, const unsigned cstart[3], const unsigned ccount[3], size_t nmcu, int* scratch,
-                            const ScanState* guard, hipStream_t s);
+// dc (may be null): the differences lie in dc[block] instead of the coefficients' DC slots (launch_emit's dc_out); the values go to the coefficients
+hipError_t launch_dc_prefix(int16_t* coeffs, int16_t* dc, unsigned bpm, unsigned ncomp, const unsigned cstart[3], const unsigned ccount[3], size_t nmcu,
+                            int* scratch, const ScanState* guard, hipStream_t s);
 
 }  // namespace huffdec
 }  // namespace jpezy_dev

@@ -319,7 +319,7 @@ constexpr int EMIT_WINDOW_LINEAR = (EMIT_SUBS + 1) * SUBSEQ_BITS / 32 + 16;     
 static_assert(EMIT_WINDOW_LINEAR <= WINDOW_LINEAR && WGS % EMIT_PARTS == 0 && SUBSEQ_BITS % EMIT_PARTS == 0, "emit geometry");
 __global__ __launch_bounds__(WGS) void emit_kernel(const Setup* gS, const uint32_t* U, size_t u_words, ScanState* st, const uint32_t* exit_state,
                                                    const uint32_t* marks, const unsigned* mark_blocks, const unsigned long long* blocks_before,
-                                                   int16_t* out, int guarded)
+                                                   int16_t* out, int16_t* dc_out, int guarded)
 {
     __shared__ Setup S;
     __shared__ uint32_t win[EMIT_WINDOW_LINEAR + EMIT_WINDOW_LINEAR / 32 + 1];
@@ -350,7 +350,7 @@ __global__ __launch_bounds__(WGS) void emit_kernel(const Setup* gS, const uint32
     const unsigned end = base + PART_BITS;
     // stop at the end of the last block: what follows are pad bits, not symbols
     while (c.pos < end && g0 + wk.nblocks < total) {
-        if (!decode_step<true>(tabs, bpm, tdmask, c, wk, g0, total, out)) { *error = 1u; return; }
+        if (!decode_step<true>(tabs, bpm, tdmask, c, wk, g0, total, out, dc_out)) { *error = 1u; return; }
     }
     // exactly one lane completes the last block; the bit behind it, counted from the start of the stream
     if (wk.nblocks && g0 + wk.nblocks >= total) *last_bit = (unsigned long long)i0 * SUBSEQ_BITS + c.pos;
@@ -368,7 +368,9 @@ __device__ __forceinline__ size_t dc_slot(const DcGeom& g, unsigned comp, size_t
     const size_t mcu = j / count, t = j - mcu * count;
     return (mcu * g.bpm + g.cstart[comp] + t) * 64;
 }
-__global__ __launch_bounds__(256) void dc_local_kernel(int16_t* coeffs, DcGeom g, int* totals, unsigned wg_per_comp, const ScanState* guard)
+// dc (may be null; round 4): the DC differences lie in an array of their own, dc[block] (the coefficient launch put them there): the first launch
+// sums in place THERE -- 2 bytes per block instead of a 128-byte line per block -- and the second one writes the values to the coefficients.
+__global__ __launch_bounds__(256) void dc_local_kernel(int16_t* coeffs, int16_t* dc, DcGeom g, int* totals, unsigned wg_per_comp, const ScanState* guard)
 {
     __shared__ int wsum[4];
     if (guard && !scan_settled(guard->changed, guard->changed2, guard->n_sub)) return;
@@ -379,7 +381,7 @@ __global__ __launch_bounds__(256) void dc_local_kernel(int16_t* coeffs, DcGeom g
     int v[8], sum = 0;
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-        v[q] = j0 + q < nd ? (int)coeffs[dc_slot(g, comp, j0 + q)] : 0;
+        v[q] = j0 + q < nd ? (int)(dc ? dc[dc_slot(g, comp, j0 + q) >> 6] : coeffs[dc_slot(g, comp, j0 + q)]) : 0;
         sum += v[q];
     }
     int inc = sum;
@@ -400,7 +402,10 @@ __global__ __launch_bounds__(256) void dc_local_kernel(int16_t* coeffs, DcGeom g
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
         run += v[q];
-        if (j0 + q < nd) coeffs[dc_slot(g, comp, j0 + q)] = (int16_t)run;
+        if (j0 + q < nd) {
+            if (dc) dc[dc_slot(g, comp, j0 + q) >> 6] = (int16_t)run;
+            else coeffs[dc_slot(g, comp, j0 + q)] = (int16_t)run;
+        }
     }
     if (threadIdx.x == 0) totals[(size_t)comp * wg_per_comp + blockIdx.x] = tot;
 }
@@ -441,13 +446,15 @@ __global__ __launch_bounds__(256) void dc_totals_kernel(int* totals, DcGeom g, u
 // values out of the L2 -- and the launch that scanned them is gone (a dependent launch costs ~5 us)
 constexpr unsigned DC_SELF_SUM_MAX = 1024;
 template <bool SELF_SUM>
-__global__ __launch_bounds__(256) void dc_add_kernel(int16_t* coeffs, DcGeom g, const int* totals, unsigned wg_per_comp, const ScanState* guard)
+__global__ __launch_bounds__(256) void dc_add_kernel(int16_t* coeffs, const int16_t* dc, DcGeom g, const int* totals, unsigned wg_per_comp,
+                                                     const ScanState* guard)
 {
     __shared__ int red[4];
     if (guard && !scan_settled(guard->changed, guard->changed2, guard->n_sub)) return;
     const unsigned comp = blockIdx.y;
     const size_t nd = (size_t)g.nmcu * g.ccount[comp], j0 = (size_t)blockIdx.x * DC_PER_WG + (size_t)threadIdx.x * 8;
-    if (blockIdx.x == 0 || (size_t)blockIdx.x * DC_PER_WG >= nd) return;   // (nothing comes before the first workgroup)
+    if ((size_t)blockIdx.x * DC_PER_WG >= nd) return;
+    if (blockIdx.x == 0 && !dc) return;                                     // (nothing comes before the first workgroup; with dc it still has to deliver)
     int before;
     if (SELF_SUM) {
         int sum = 0;
@@ -463,8 +470,8 @@ __global__ __launch_bounds__(256) void dc_add_kernel(int16_t* coeffs, DcGeom g, 
 #pragma unroll
     for (int q = 0; q < 8; ++q)
         if (j0 + q < nd) {
-            int16_t* z = coeffs + dc_slot(g, comp, j0 + q);
-            *z = (int16_t)((int)*z + before);
+            const size_t slot = dc_slot(g, comp, j0 + q);
+            coeffs[slot] = (int16_t)((int)(dc ? dc[slot >> 6] : coeffs[slot]) + before);
         }
 }
 
@@ -918,16 +925,16 @@ hipError_t launch_sync(const Setup* S, const uint32_t* U, size_t u_words, unsign
     return hipGetLastError();
 }
 hipError_t launch_emit(const Setup* S, const uint32_t* U, size_t u_words, unsigned n_sub, ScanState* st, const uint32_t* exit_state,
-                       const uint32_t* marks, const unsigned* mark_blocks, const unsigned long long* blocks_before, int16_t* out, bool guarded,
-                       hipStream_t s)
+                       const uint32_t* marks, const unsigned* mark_blocks, const unsigned long long* blocks_before, int16_t* out, int16_t* dc_out,
+                       bool guarded, hipStream_t s)
 {
     hipLaunchKernelGGL(emit_kernel, dim3((n_sub + EMIT_SUBS - 1) / EMIT_SUBS), dim3(WGS), 0, s, S, U, u_words, st, exit_state, marks, mark_blocks,
-                       blocks_before, out, guarded ? 1 : 0);
+                       blocks_before, out, dc_out, guarded ? 1 : 0);
     return hipGetLastError();
 }
 size_t dc_prefix_scratch_ints(size_t nmcu, unsigned max_count) { return 3 * ((nmcu * max_count + DC_PER_WG - 1) / DC_PER_WG + 1); }
-hipError_t launch_dc_prefix(int16_t* coeffs, unsigned bpm, unsigned ncomp, const unsigned cstart[3], const unsigned ccount[3], size_t nmcu, int* scratch,
-                            const ScanState* guard, hipStream_t s)
+hipError_t launch_dc_prefix(int16_t* coeffs, int16_t* dc, unsigned bpm, unsigned ncomp, const unsigned cstart[3], const unsigned ccount[3], size_t nmcu,
+                            int* scratch, const ScanState* guard, hipStream_t s)
 {
     DcGeom g;
     g.bpm = bpm; g.ncomp = ncomp; g.nmcu = nmcu;
@@ -936,16 +943,16 @@ hipError_t launch_dc_prefix(int16_t* coeffs, unsigned bpm, unsigned ncomp, const
     const size_t wgs = (nmcu * maxc + DC_PER_WG - 1) / DC_PER_WG;
     if (!wgs || !ncomp) return hipSuccess;
     if (wgs > 0x7FFFFFFFull) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(dc_local_kernel, dim3((unsigned)wgs, ncomp), dim3(256), 0, s, coeffs, g, scratch, (unsigned)wgs + 1, guard);
+    hipLaunchKernelGGL(dc_local_kernel, dim3((unsigned)wgs, ncomp), dim3(256), 0, s, coeffs, dc, g, scratch, (unsigned)wgs + 1, guard);
     static const size_t self_sum_max = [] {
         const char* e = std::getenv("JPEZY_DC_SELF_SUM_MAX");        // development / test knob: 0 forces the three-launch form
         return e ? (size_t)std::atoll(e) : (size_t)DC_SELF_SUM_MAX;
     }();
     if (wgs <= self_sum_max) {
-        hipLaunchKernelGGL(dc_add_kernel<true>, dim3((unsigned)wgs, ncomp), dim3(256), 0, s, coeffs, g, (const int*)scratch, (unsigned)wgs + 1, guard);
+        hipLaunchKernelGGL(dc_add_kernel<true>, dim3((unsigned)wgs, ncomp), dim3(256), 0, s, coeffs, (const int16_t*)dc, g, (const int*)scratch, (unsigned)wgs + 1, guard);
     } else {
         hipLaunchKernelGGL(dc_totals_kernel, dim3(ncomp), dim3(256), 0, s, scratch, g, (unsigned)wgs + 1, guard);
-        hipLaunchKernelGGL(dc_add_kernel<false>, dim3((unsigned)wgs, ncomp), dim3(256), 0, s, coeffs, g, (const int*)scratch, (unsigned)wgs + 1, guard);
+        hipLaunchKernelGGL(dc_add_kernel<false>, dim3((unsigned)wgs, ncomp), dim3(256), 0, s, coeffs, (const int16_t*)dc, g, (const int*)scratch, (unsigned)wgs + 1, guard);
     }
     return hipGetLastError();
 }

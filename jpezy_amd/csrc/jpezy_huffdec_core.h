@@ -125,10 +125,10 @@ static_assert(TABLE_U16 == 2048u, "Walk::tdm places the table selector at the bi
 // reads do not depend on each other.  Bits that are no code, or a run past the end of the block: EMIT returns false (the true decode hit
 // it: the stream is bad); a synchronisation pass -- which may well be decoding from a wrong guess, i.e. garbage -- abandons the block
 // (one bit on for a non-code) and carries on, so that it can still fall into step further down.
-// EMIT: coefficients of blocks gidx + nblocks < total go to out (DC: the difference, made absolute by the DC pass).
+// EMIT: coefficients of blocks gidx + nblocks < total go to out (DC: the difference, made absolute by the DC pass; to dc_out[block] if given).
 template <bool EMIT, class CursorT>
 JPEZY_HD bool decode_step(const uint16_t* tabs, unsigned bpm, unsigned tdmask, CursorT& c, Walk& s,
-                                            unsigned long long gidx, unsigned total, int16_t* out)
+                                            unsigned long long gidx, unsigned total, int16_t* out, int16_t* dc_out = nullptr)
 {
     (void)tdmask;
     const uint32_t ahead = c.prefetch();                               // used only when this symbol crosses a word boundary
@@ -142,9 +142,14 @@ JPEZY_HD bool decode_step(const uint16_t* tabs, unsigned bpm, unsigned tdmask, C
     if (EMIT) {
         const unsigned sz = (e >> 5) & 31u;
         if (sz == E_S_NONE || (run != E_RUN_END && kk > 64u)) return false;
-        if (sz && gidx + s.nblocks < total) {
+        const bool dc_sym = dc_out && s.k == 0u;                      // (a DC difference of zero has no value bits but is written all the same:
+        if ((sz || dc_sym) && gidx + s.nblocks < total) {             //  dc_out is not zeroed beforehand)
             const unsigned len = skipm1 + 1u - sz;
-            out[(gidx + s.nblocks) * 64 + kk - 1u] = (int16_t)extend((int)((bits << len) >> (32u - sz)), (int)sz);
+            const int16_t v = sz ? (int16_t)extend((int)((bits << len) >> (32u - sz)), (int)sz) : (int16_t)0;
+            // dc_out (may be null): the DC differences go to an array of their own, one per block -- the prefix sums then run over 2 bytes per
+            // block instead of one 128-byte line per block
+            if (dc_sym) dc_out[gidx + s.nblocks] = v;
+            else out[(gidx + s.nblocks) * 64 + kk - 1u] = v;
         }
     }
     const bool endb = kk > 63u;

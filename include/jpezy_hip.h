@@ -285,7 +285,7 @@ int jpezy_decode_jpeg_batch(jpezy_ctx* ctx, int n, const uint8_t* const* data, c
 int jpezy_ctx_last_huffdec_passes(jpezy_ctx* ctx);
 /* Files of the last jpezy_decode_jpeg_batch call that were decoded by the batch form of the kernels (test/diagnostic hook). */
 int jpezy_ctx_last_batch_fast_count(jpezy_ctx* ctx);
-/* Scans shorter than n bytes are decoded on the host (default 64 KiB: the GPU decoder has ~0.6 ms of fixed cost, which the host decoder spends on ~56 KiB of a dense scan); 0
+/* Scans shorter than n bytes are decoded on the host (default 32 KiB: the GPU decoder has ~0.32 ms of fixed cost, which the host decoder spends on ~30 KiB of scan); 0
  * sends every scan to the GPU decoder (tests). */
 void jpezy_ctx_set_huffdec_min_bytes(jpezy_ctx* ctx, size_t n);
 

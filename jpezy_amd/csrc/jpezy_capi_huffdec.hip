@@ -410,11 +410,12 @@ try {
         S.bpm = period;
         if (!jpezy_dev::huffdec::pack_td_sequence(seq, period, &S.tdmask)) return read_jpeg_host_to_device(c, data, len, info, d_coeffs, total);
     }
-    // Round 4: the whole chain below is enqueued with ONE look by the host before the coefficient pass (round 3: three -- after the unstuffing, after
-    // every synchronisation launch).  What the host used to fetch in between -- where the segment ends, how many subsequences hold data -- stays in a
+    // Round 4: the whole chain below is enqueued without the host looking in between (round 3: three synchronisations -- after the unstuffing,
+    // after every synchronisation launch).  What the host used to fetch -- where the segment ends, how many subsequences hold data -- stays in a
     // ScanState on the device; launches are sized for the upper bound n_sub_max and their workgroups leave when they lie beyond the data.  A second
-    // synchronisation launch is enqueued blindly behind the first: it leaves at once when the first one settled everything (or found a stream
-    // that does not synchronise).  The tables go up only when they differ from the ones the context already holds (profiles/r04_huffdec_*).
+    // synchronisation launch and the tail (block counts, coefficient pass, DC sums) are enqueued blindly: they leave at once when there is
+    // nothing for them (scan_settled in jpezy_huffdec.h).  The tables go up only when they differ from the ones the context already holds
+    // (profiles/r04_huffdec_*).
     if (c->h_setup_dev != c->h_setup.p || c->h_setup_host.size() != sizeof S || std::memcmp(c->h_setup_host.data(), &S, sizeof S) != 0) {
         c->h_setup_dev = nullptr;            // (stays null if the upload fails: the next call uploads again)
         c->h_setup_host.assign(reinterpret_cast<const uint8_t*>(&S), reinterpret_cast<const uint8_t*>(&S) + sizeof S);

@@ -435,15 +435,15 @@ try {
     HIP_TRY(E::launch_scan_u32((const uint32_t*)c->h_cnt.p, (unsigned long long*)c->h_off.p, nc, (unsigned long long*)c->e_tmp.p, s));
     HIP_TRY(HD::launch_unstuff_copy((const uint8_t*)c->h_scan.p, n, (const unsigned long long*)c->h_off.p, (uint8_t*)c->h_U.p, d_st, s));
 
-    // 2. speculation: every lane decodes through its own and the next subsequences from a guess; the farthest-travelled proposal for every
-    // boundary becomes the initial exit state (h_dc doubles as the proposal scratch).  Then synchronisation passes until no exit state changes.
+    // 2. speculation: every lane walks from a guess three subsequences in front of its own through its own and leaves entry state, exit state,
+    // blocks and marks of its own (jpezy_huffdec.hip).  Then synchronisation passes until no lane's entry state differs from its predecessor's exit.
     uint32_t* d_exit = (uint32_t*)c->h_state.p;
     uint32_t* d_last = d_exit + n_sub_max;
     unsigned* d_nblocks = (unsigned*)(d_last + n_sub_max);
     uint32_t* d_marks = (uint32_t*)(d_nblocks + n_sub_max);
     unsigned* d_mark_blocks = (unsigned*)(d_marks + (size_t)n_sub_max * (HD::emit_parts() - 1));
-    HIP_TRY(HD::launch_speculate((const HD::Setup*)c->h_setup.p, (const uint32_t*)c->h_U.p, u_bytes / 4, n_sub_max, d_st,
-                                 (unsigned long long*)c->h_dc.p, d_exit, d_last, d_nblocks, s));
+    HIP_TRY(HD::launch_speculate((const HD::Setup*)c->h_setup.p, (const uint32_t*)c->h_U.p, u_bytes / 4, n_sub_max, d_st, d_exit, d_last, d_nblocks,
+                                 d_marks, d_mark_blocks, s));
     HD::ScanState st;
     std::vector<uint32_t> dbg_spec;
     std::vector<unsigned> dbg_moved;

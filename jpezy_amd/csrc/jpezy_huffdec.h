@@ -83,11 +83,12 @@ hipError_t launch_scan_state_init(ScanState* st, hipStream_t s);
 // the copy launch stops there and leaves the stuffing bytes it removed and the number of subsequences in st.
 hipError_t launch_unstuff_count(const uint8_t* S, size_t n_max, uint32_t* counts, ScanState* st, hipStream_t s);
 hipError_t launch_unstuff_copy(const uint8_t* S, size_t n_max, const unsigned long long* removed_before, uint8_t* U, ScanState* st, hipStream_t s);
-// speculation pass: fills exit_state with the best available guess of every subsequence's true exit state
-// (proposal: n_sub_max uint64 of scratch); also puts last_entry and nblocks into their state before the first synchronisation launch.
-// n_sub_max sizes the launches, st->n_sub says which lanes have data.
-hipError_t launch_speculate(const Setup* S, const uint32_t* U, size_t u_words, unsigned n_sub_max, const ScanState* st, unsigned long long* proposal,
-                            uint32_t* exit_state, uint32_t* last_entry, unsigned* nblocks, hipStream_t s);
+// speculation pass: every lane walks from a guess `overflow` subsequences in front of its own through its own and leaves, for its own
+// subsequence, the entry state it arrived in (last_entry), the exit state, the blocks completed and the marks -- the state of the
+// synchronisation phase as if every lane had already confirmed its predecessor's exit state, true wherever the guesses have fallen into step.
+// n_sub_max sizes the launch, st->n_sub says which lanes have data.
+hipError_t launch_speculate(const Setup* S, const uint32_t* U, size_t u_words, unsigned n_sub_max, const ScanState* st, uint32_t* exit_state,
+                            uint32_t* last_entry, unsigned* nblocks, uint32_t* marks, unsigned* mark_blocks, hipStream_t s);
 // u_words: 32-bit words of U that may be read (the rest of a workgroup's window reads as zero)
 // changed[0] += number of lanes whose exit state moved, changed[1] += lanes left pending by the max_inner cut-off, changed[2] += moved lanes that
 // are a workgroup's last (the next workgroup may not have seen the new value), changed[3] += lanes whose first decode of the launch moved their state.  changed[1] == 0 && changed[2] == 0 after a launch: the states are

@@ -166,45 +166,54 @@ __device__ __forceinline__ bool run_subsequence_marks(const uint16_t* tabs, unsi
     return rejoined;
 }
 
-// Speculation: lane i decodes from the guess (0, 0, 0) at the start of its subsequence through OVERFLOW + 1
-// subsequences.  A decoder started at a wrong place is in step with the true one after a few hundred bits -- bit
-// position, zig-zag index and, after some more MCUs, the block phase -- so the state it holds at the end of subsequence
-// i + r is, for growing r, more and more likely the true one.  Every boundary j keeps the proposal of the lane that has
-// come the longest way (largest r; lane 0, whose entry state is the true one, outranks everybody), via atomicMax on
-// (r << 32 | state).  The refinement launches below then only have to confirm these states.
-__global__ __launch_bounds__(WGS) void spec_kernel(const Setup* gS, const uint32_t* U, size_t u_words, const ScanState* st,
-                                                   unsigned long long* proposal, unsigned overflow)
+// Speculation, round 4 form: lane i starts `overflow` subsequences BEFORE its own, from the guess (0, 0, 0) -- from the true state when that is
+// the start of the scan --, walks up to its own subsequence and through it.  A decoder started at a wrong place is in step with the true one
+// after a few hundred bits -- bit position, zig-zag index and, after some more MCUs, the block phase --, so the state it holds at the start of
+// its own subsequence is very likely the true one (92 % after one subsequence of warm-up, 99.5 % after three), and its walk through its own
+// subsequence -- entry state, exit state, blocks, marks -- is then already what the synchronisation phase would compute from its
+// predecessor's exit state: the confirmation walk of every lane (round 3: speculation forwards from the lane's own start, proposals by
+// atomicMax, then every lane once more from the adopted proposal) costs nothing any more.  The synchronisation launches only re-walk where a
+// lane's entry state is not its predecessor's exit state.
+__global__ __launch_bounds__(WGS) void spec_kernel(const Setup* gS, const uint32_t* U, size_t u_words, const ScanState* st, uint32_t* exit_state,
+                                                   uint32_t* last_entry, unsigned* nblocks_out, uint32_t* marks, unsigned* mark_blocks,
+                                                   unsigned overflow)
 {
     __shared__ Setup S;
     __shared__ uint32_t win[WINDOW_WORDS];
     const unsigned n_sub = st->n_sub;
     const unsigned i0 = blockIdx.x * WGS, i = i0 + threadIdx.x;
     if (i0 >= n_sub) return;                                         // (workgroup-uniform: the launch is sized before the stuffing is counted)
+    const unsigned wbase = i0 >= overflow ? i0 - overflow : 0u;       // the window starts `overflow` subsequences in front of the workgroup's first
     load_setup(S, gS);
-    load_window(win, U, i0, u_words);
+    load_window(win, U, wbase, u_words);
     __syncthreads();
     if (i >= n_sub) return;
     const uint16_t* tabs = reinterpret_cast<const uint16_t*>(&S);
     const unsigned bpm = (unsigned)S.bpm, tdmask = S.tdmask;
+    const unsigned start = i >= overflow ? i - overflow : 0u;         // (start == 0: the scan's own start state, no guess)
     Cursor c;
-    c.init(win, threadIdx.x * SUBSEQ_BITS);
+    c.init(win, (start - wbase) * SUBSEQ_BITS);
     Walk wk;
     wk.init(0, 0, tdmask);
-    for (unsigned r = 0; r <= overflow && i + r < n_sub; ++r) {
-        const unsigned end = (threadIdx.x + r + 1) * SUBSEQ_BITS;      // relative to the window's first bit, like c.pos
-        run_subsequence(tabs, bpm, tdmask, c, wk, end);
-        const unsigned long long rank = i == 0 ? 0xFFFFull : r;
-        atomicMax(proposal + i + r, (rank << 32) | pack_state(c.pos - end, wk.b(), wk.k));
+    const unsigned own = (i - wbase) * SUBSEQ_BITS;                   // relative to the window's first bit, like c.pos
+    run_subsequence(tabs, bpm, tdmask, c, wk, own);                   // the warm-up: up to the start of the lane's own subsequence
+    const uint32_t entry = pack_state(c.pos - own, wk.b(), wk.k);
+    wk.nblocks = 0;
+    uint32_t mk[EMIT_PARTS - 1];
+    unsigned mkb[EMIT_PARTS - 1];
+    int delta = 0;
+    (void)run_subsequence_marks(tabs, bpm, tdmask, c, wk, own, mk, mkb, false, &delta);
+    last_entry[i] = entry;
+    exit_state[i] = pack_state(c.pos - (own + SUBSEQ_BITS), wk.b(), wk.k);
+    nblocks_out[i] = wk.nblocks;
+#pragma unroll
+    for (int q = 0; q < EMIT_PARTS - 1; ++q) {
+        marks[(size_t)i * (EMIT_PARTS - 1) + q] = mk[q];
+        mark_blocks[(size_t)i * (EMIT_PARTS - 1) + q] = mkb[q];
     }
 }
 
-// state of the synchronisation phase before its first launch: no proposals, every lane still to decode, no blocks counted
-__global__ void init_state_kernel(unsigned long long* proposal, uint32_t* last_entry, unsigned* nblocks, unsigned n)
-{
-    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) { proposal[i] = 0ull; last_entry[i] = 0xFFFFFFFFu; nblocks[i] = 0u; }
-}
-
+// (batch form) the proposals that won become the initial exit states
 __global__ void adopt_proposals_kernel(const unsigned long long* proposal, unsigned n_sub, uint32_t* exit_state)
 {
     const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -902,17 +911,16 @@ hipError_t launch_unstuff_copy(const uint8_t* S, size_t n_max, const unsigned lo
     hipLaunchKernelGGL(unstuff_copy_kernel, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, s, S, n_max, removed_before, U, st);   // (a workgroup per 256 chunks, as before)
     return hipGetLastError();
 }
-hipError_t launch_speculate(const Setup* S, const uint32_t* U, size_t u_words, unsigned n_sub, const ScanState* st, unsigned long long* proposal,
-                            uint32_t* exit_state, uint32_t* last_entry, unsigned* nblocks, hipStream_t s)
+hipError_t launch_speculate(const Setup* S, const uint32_t* U, size_t u_words, unsigned n_sub, const ScanState* st, uint32_t* exit_state,
+                            uint32_t* last_entry, unsigned* nblocks, uint32_t* marks, unsigned* mark_blocks, hipStream_t s)
 {
-    hipLaunchKernelGGL(init_state_kernel, dim3((n_sub + 255) / 256), dim3(256), 0, s, proposal, last_entry, nblocks, n_sub);
     static const unsigned overflow = [] {
         const char* e = std::getenv("JPEZY_HUFFDEC_OVERFLOW");      // development knob; the default covers what was measured
         const int v = e ? std::atoi(e) : OVERFLOW_DEFAULT;
         return (unsigned)(v < 0 ? 0 : v > OVERFLOW ? OVERFLOW : v);
     }();
-    hipLaunchKernelGGL(spec_kernel, dim3((n_sub + WGS - 1) / WGS), dim3(WGS), 0, s, S, U, u_words, st, proposal, overflow);
-    hipLaunchKernelGGL(adopt_proposals_kernel, dim3((n_sub + 255) / 256), dim3(256), 0, s, proposal, n_sub, exit_state);
+    hipLaunchKernelGGL(spec_kernel, dim3((n_sub + WGS - 1) / WGS), dim3(WGS), 0, s, S, U, u_words, st, exit_state, last_entry, nblocks, marks, mark_blocks,
+                       overflow);
     return hipGetLastError();
 }
 unsigned emit_parts() { return EMIT_PARTS; }

@@ -17,8 +17,12 @@
 //
 // Anything irregular -- an invalid code, a run past the end of a block, a scan that ends early, restart markers that are
 // not exactly where they belong -- makes the caller (jpezy_capi.hip) fall back to the host decoder, whose verdict is
-// authoritative.  Round 3: two-level lookup tables and a branch-free decode step (jpezy_huffdec.h, decode_step below), one
-// confirmation + refinement launch with a fixed-point test, the end of the entropy-coded segment found by the stuffing count.
+// authoritative.  Round 3: lookup tables and a branch-free decode step (jpezy_huffdec_core.h), one confirmation + refinement
+// launch with a fixed-point test, the end of the entropy-coded segment found by the stuffing count.  Round 4, single scan: the chain
+// runs without the host looking in between (ScanState, guarded launches), speculation runs backwards (a lane's last walk is its
+// confirmation walk), marks at every quarter of a subsequence (shorter coefficient walks, re-walks that stop where they rejoin),
+// two independent table lookups per symbol, unstuffing with wide loads and LDS-staged stores, DC differences in an array of their
+// own.  The batch form keeps round 3's schedule (forward speculation with proposals): its calls are bound by PCIe.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <cstdlib>

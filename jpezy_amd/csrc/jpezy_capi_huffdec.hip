@@ -423,14 +423,18 @@ try {
         HIP_TRY(hipMemcpyAsync(c->h_setup.p, c->h_setup_host.data(), sizeof S, hipMemcpyHostToDevice, s));
         c->h_setup_dev = c->h_setup.p;
     }
+    // what does not depend on the scan goes first: the zeroing of the unstuffed stream's buffer and of the coefficients (50 MB for a 4096^2
+    // frame: 10 us) and the state record.  (They do not overlap the upload -- one stream; a side stream for them measured no gain against the
+    // event calls it needs.  The upload from pageable memory blocks the host for ~100 us before anything behind it can be enqueued.)
+    HD::ScanState* d_st = (HD::ScanState*)c->h_small.p;
+    HIP_TRY(hipMemsetAsync(c->h_U.p, 0, u_bytes, s));
+    HIP_TRY(hipMemsetAsync(d_coeffs, 0, total * sizeof(int16_t), s));
+    HIP_TRY(HD::launch_scan_state_init(d_st, s));
     const double tp2 = tnow();
     HIP_TRY(hipMemcpyAsync(c->h_scan.p, scan, n, hipMemcpyHostToDevice, s));
     const double tp3 = tnow();
 
     // 1. find the end of the segment, remove the byte stuffing
-    HD::ScanState* d_st = (HD::ScanState*)c->h_small.p;
-    HIP_TRY(hipMemsetAsync(c->h_U.p, 0, u_bytes, s));
-    HIP_TRY(HD::launch_scan_state_init(d_st, s));
     HIP_TRY(HD::launch_unstuff_count((const uint8_t*)c->h_scan.p, n, (uint32_t*)c->h_cnt.p, d_st, s));
     HIP_TRY(E::launch_scan_u32((const uint32_t*)c->h_cnt.p, (unsigned long long*)c->h_off.p, nc, (unsigned long long*)c->e_tmp.p, s));
     HIP_TRY(HD::launch_unstuff_copy((const uint8_t*)c->h_scan.p, n, (const unsigned long long*)c->h_off.p, (uint8_t*)c->h_U.p, d_st, s));
@@ -465,7 +469,7 @@ try {
     // goes on with refinement launches and enqueues this tail again, unguarded) -- the usual file is decoded without the host looking once.
     auto enqueue_tail = [&](bool guarded) -> int {
         HIP_TRY(E::launch_scan_u32((const uint32_t*)d_nblocks, (unsigned long long*)c->h_off.p, n_sub_max, (unsigned long long*)c->e_tmp.p, s));
-        HIP_TRY(hipMemsetAsync(d_coeffs, 0, total * sizeof(int16_t), s));
+        // (the coefficients were zeroed at the start of the call; a guarded coefficient launch that left at once has written nothing)
         HIP_TRY(HD::launch_emit((const HD::Setup*)c->h_setup.p, (const uint32_t*)c->h_U.p, u_bytes / 4, n_sub_max, d_st, d_exit, d_marks, d_mark_blocks,
                                 (const unsigned long long*)c->h_off.p, d_coeffs, (int16_t*)c->h_dcbuf.p, guarded, s));
         // DC differences -> values, all components in two launches (round 2: gather, two-launch scan, scatter per component = twelve)

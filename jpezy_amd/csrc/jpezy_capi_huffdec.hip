@@ -424,8 +424,8 @@ try {
         c->h_setup_dev = c->h_setup.p;
     }
     // what does not depend on the scan goes first: the zeroing of the unstuffed stream's buffer and of the coefficients (50 MB for a 4096^2
-    // frame: 10 us) and the state record.  (They do not overlap the upload -- one stream; a side stream for them measured no gain against the
-    // event calls it needs.  The upload from pageable memory blocks the host for ~100 us before anything behind it can be enqueued.)
+    // frame: 10 us) and the state record.  (They do not overlap the upload -- one stream; a side stream would hide their ~20 us behind it at the price
+    // of four event calls.  The upload from pageable memory blocks the host for ~100 us before anything behind it can be enqueued.)
     HD::ScanState* d_st = (HD::ScanState*)c->h_small.p;
     HIP_TRY(hipMemsetAsync(c->h_U.p, 0, u_bytes, s));
     HIP_TRY(hipMemsetAsync(d_coeffs, 0, total * sizeof(int16_t), s));

@@ -32,6 +32,11 @@
 namespace jpezy_dev {
 namespace huffdec {
 
+// 1,024 bits.  512 was measured once more on the final round-4 decoder (profiles/r04_huffdec_s512.txt): the same 0.61 ms on 4096^2 noise,
+// 10-20 % less on everything shorter or smoother (smooth 4096^2 0.39 -> 0.32 ms, 1080p 0.47 -> 0.43, small files 0.32 -> 0.26, 256-file
+// batches -4 %) -- but dense high-quality noise (blocks longer than a subsequence) leaves fewer lanes in step after the speculation, the
+// "more than half of the lanes wrong at the first step" cut hands such files to the host decoder (one of the test suite's libjpeg files,
+// and about twice as many files of the fuzz corpus), and relaxing the cut costs flat images milliseconds of futile refinement.
 #ifndef JPEZY_SUBSEQ_BITS
 #define JPEZY_SUBSEQ_BITS 1024
 #endif

@@ -568,6 +568,33 @@ __global__ __launch_bounds__(64 * EWPB, JPEZY_F32_WAVES) void fdct_quant_f32_ker
     const unsigned long long tr_t1 = __builtin_amdgcn_s_memrealtime();
 #endif
     PHASE_STAMP(1);
+#ifdef JPEZY_ABL_LIGHT_TAIL
+    // TIMING PROBE (wrong results; jpezy_experiment.h): the workgroups of the launch's last JPEZY_ABL_LIGHT_TAIL groups do their loads and their
+    // stores and nothing in between -- the shortest waves a tail of any finer-grained design (half quads) could have.
+    // What the launch gains from that is the upper bound of what such a design can gain.
+    if (blockIdx.x + (unsigned)JPEZY_ABL_LIGHT_TAIL >= gridDim.x) {
+        char* st0 = reinterpret_cast<char*>(lds) + CT_BYTES;
+        uint32_t* w = reinterpret_cast<uint32_t*>(st0) + lane * 12;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { w[k] = R[k]; w[4 + k] = G[k]; w[8 + k] = B[k]; }
+        wave_sync();
+        if (has_quad) {
+            const int valid_chunks = min(4, p.mcu_cols - quad_x * 4) * BPM * 8;
+            int16_t* gbase = p.coeffs + (size_t)frame * p.coeffs_per_frame + ((size_t)mcu_y * p.mcu_cols + (size_t)quad_x * 4) * (BPM * 64);
+            uint4* g4 = reinterpret_cast<uint4*>(gbase);
+#pragma unroll
+            for (int k = 0; k < BPM * 128 * 4 / 1024; ++k) {
+                const int c = k * 64 + lane;
+                if (c < valid_chunks) {
+                    const uint4 v = *reinterpret_cast<const uint4*>(st0 + (c >> 3) * STG_BLK + (c & 7) * 16);
+                    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+                    __builtin_nontemporal_store(v4u{v.x, v.y, v.z, v.w}, reinterpret_cast<v4u*>(g4 + c));
+                }
+            }
+        }
+        return;
+    }
+#endif
     PkCos kc = pk_cos();
 #if JPEZY_PIN_CONSTANTS
     // ten SGPRs for the whole kernel: left alone, hipcc rebuilds every constant pair with s_mov_b32 in front of the packed

@@ -148,6 +148,7 @@ void jpezy_ctx_destroy(jpezy_ctx* c)
     if (c->d_codes) (void)hipFree(c->d_codes);
     if (c->e_pinned) (void)hipHostFree(c->e_pinned);
     if (c->b_pin) (void)hipHostFree(c->b_pin);
+    if (c->h_fb_pin) (void)hipHostFree(c->h_fb_pin);
     for (uint8_t* q : c->b_stage) if (q) (void)hipHostFree(q);
     for (DevBuf* b : { &c->b_scan, &c->b_U, &c->b_cnt, &c->b_rb, &c->b_state, &c->b_prop, &c->b_meta, &c->b_coef }) b->release();
     for (DevBuf& b : c->b_planes) b.release();

@@ -10,11 +10,26 @@ namespace {
 int read_jpeg_host_to_device(jpezy_ctx* c, const uint8_t* data, size_t len, jpezy_frame_info* info, int16_t* d_coeffs, size_t total)
 {
     if (total / 64 > 4 * len) return set_err(JPEZY_E_FORMAT, "scan too short for the declared dimensions");
-    std::vector<int16_t> tmp(total);
     std::string err;
+    // The host decoder writes every coefficient, so its output needs no zeroing: up to 256 MB it goes to a pinned buffer the context keeps
+    // (round 4: a fresh 50 MB vector per 4096^2 frame cost 8 ms of page faults and a pageable upload -- 14.6 ms around a 5 ms decode)
+    const size_t bytes = total * sizeof(int16_t);
+    if (bytes <= ((size_t)256 << 20)) {
+        if (c->h_fb_cap < bytes) {
+            if (c->h_fb_pin) (void)hipHostFree(c->h_fb_pin);
+            c->h_fb_pin = nullptr; c->h_fb_cap = 0;
+            HIP_TRY(hipHostMalloc((void**)&c->h_fb_pin, bytes, hipHostMallocDefault));
+            c->h_fb_cap = bytes;
+        }
+        const int rc = jpezy_host::read_jpeg(data, len, info, (int16_t*)c->h_fb_pin, total, &err);
+        if (rc < 0) { g_err = err; return rc; }
+        HIP_TRY(hipMemcpy(d_coeffs, c->h_fb_pin, bytes, hipMemcpyHostToDevice));
+        return JPEZY_OK;
+    }
+    std::vector<int16_t> tmp(total);
     const int rc = jpezy_host::read_jpeg(data, len, info, tmp.data(), tmp.size(), &err);
     if (rc < 0) { g_err = err; return rc; }
-    HIP_TRY(hipMemcpy(d_coeffs, tmp.data(), total * sizeof(int16_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_coeffs, tmp.data(), bytes, hipMemcpyHostToDevice));
     return JPEZY_OK;
 }
 
@@ -27,7 +42,8 @@ int read_jpeg_host_to_device(jpezy_ctx* c, const uint8_t* data, size_t len, jpez
 //   first launch: every lane decodes once from its predecessor's proposed exit state (the confirmation) and the corrections travel up to seven
 //     lanes on -- isolated wrong proposals, the usual case, settle here and the file is done after one launch and one look by the host
 //     (round 2: confirmation, a 24-step launch and a launch that found nothing to do, with a host synchronisation after each).  More than half
-//     of the proposals wrong at that first step: the stream does not synchronise (periodic data: flat areas) -- host decoder.
+//     of the lanes moved at that first step and more than a quarter still pending after it (scan_hopeless, jpezy_huffdec.h): the stream does
+//     not synchronise (periodic data: flat areas) -- host decoder.
 //   refinement launches of 64 steps for longer wrong runs (up to ~100 subsequences in the fuzzer's files), which decode such a stretch lane
 //     after lane -- at a fraction of the host decoder's rate, so it only pays while the stretches are short.  They go on while they make
 //     progress (round 2: a fixed six launches of 24 steps): two always run; from the third on the lanes that moved must be down to a
@@ -40,6 +56,7 @@ struct RefineBudget {
     static constexpr int MAX_LAUNCHES = 12;
     int first_steps, steps;
     unsigned residue;
+    int max_launches = MAX_LAUNCHES;
     explicit RefineBudget(unsigned subseq_bits)
     {
         const int k = subseq_bits >= 1024u ? 1 : (int)(1024u / subseq_bits);
@@ -47,10 +64,20 @@ struct RefineBudget {
         steps = 64 * k > 256 ? 256 : 64 * k;
         residue = 64u * (unsigned)k;
     }
+    // A periodic stream (flat areas) can hold the decoder in a wrong parse for ever: the speculative lanes, all at the same phase of the period,
+    // agree with one another, nothing looks wrong at the first step, and the true state creeps down the scan one lane per step -- ~33 bits per
+    // microsecond where the host decoder walks ~780.  The speculation counts the lanes that leave their subsequence in the state they entered it
+    // (ScanState::periodic; chance says one in ten thousand); a scan in which most lanes do gets the launch that is enqueued blindly and no
+    // further one.  (A flat 4080 x 4096 colour frame was refined for 50 ms, 64 lanes per launch, before the twelfth launch gave up:
+    // profiles/r04_huffdec_periodic.txt.)
+    RefineBudget(unsigned subseq_bits, unsigned n_sub, unsigned periodic) : RefineBudget(subseq_bits)
+    {
+        if ((unsigned long long)periodic * 5u > (unsigned long long)n_sub * 3u) max_launches = 1;
+    }
     // may refinement launch `launch` (1-based, after the first launch) run, given the lanes that moved in the two launches before it?
     bool go_on(int launch, unsigned moved_before, unsigned moved_last) const
     {
-        if (launch > MAX_LAUNCHES) return false;
+        if (launch > max_launches) return false;
         if (launch <= 2 || moved_last <= residue) return true;
         return (unsigned long long)moved_last * 4u <= (unsigned long long)moved_before * 3u;
     }
@@ -197,7 +224,7 @@ int jpezy_internal_huffdec_streams(jpezy_ctx* c, const std::vector<DevStream>& s
             if (pending == 0) { active[k] = 0; converged[k] = 1; continue; }
             // many proposals moved at the first look (periodic data never falls into step), or the refinement launches have
             // stopped paying for this stream (RefineBudget): the caller's other path
-            if (pass == 0 ? F[k].changed[3] > F[k].n_sub / 2 + 16 : !budget.go_on(pass + 1, prev_moved[k], moved)) { active[k] = 0; dead[k] = 1; }
+            if (pass == 0 ? HD::scan_hopeless(F[k].changed, F[k].n_sub) : !budget.go_on(pass + 1, prev_moved[k], moved)) { active[k] = 0; dead[k] = 1; }
             prev_moved[k] = moved;
         }
         // reset the per-pass counters of the streams that go on (one launch: there may be tens of thousands of streams)
@@ -497,7 +524,6 @@ try {
         bool pending = st.changed[1] != 0 || st.changed[2] != 0;        // lanes left with a stale entry state, or a moved workgroup boundary: not the fixed point yet
         if (dbg) dbg_moved.push_back(moved);
         converged = !pending;
-        const unsigned wrong = st.changed[3];            // proposals the confirmation step did not bear out
         const bool patient = dbg && std::getenv("JPEZY_HUFFDEC_PATIENT") != nullptr;      // diagnostic: show where the launches would have led
         auto pass = [&](int max_inner) -> int {          // further launches, one look each (rare: 1 % of the fuzz corpus)
             unsigned mv[4] = { 0, 0, 0, 0 };
@@ -511,7 +537,7 @@ try {
             if (dbg) dbg_moved.push_back(moved);
             return JPEZY_OK;
         };
-        if (!converged && wrong <= n_sub / 2 + 16) {
+        if (!converged && !HD::scan_hopeless(st.changed, n_sub)) {
             // the blind launch was refinement launch 1
             unsigned prev = moved;
             moved = st.changed2[0];
@@ -519,7 +545,8 @@ try {
             ++passes;
             if (dbg) dbg_moved.push_back(moved);
             converged = !pending;
-            for (int it = 2; !converged && (patient ? it <= 40 : budget.go_on(it, prev, moved)); ++it) {
+            const RefineBudget sized(L, n_sub, st.periodic);
+            for (int it = 2; !converged && (patient ? it <= 40 : sized.go_on(it, prev, moved)); ++it) {
                 prev = moved;
                 if (int r2 = pass(budget.steps)) return r2;
                 converged = !pending;

@@ -154,6 +154,8 @@ struct jpezy_ctx {
     DevBuf h_scan, h_U, h_cnt, h_off, h_state, h_setup, h_small, h_dc, h_dcbuf;   // GPU Huffman decoder (jpezy_huffdec.hip)
     std::vector<uint8_t> h_setup_host;  // the device tables h_setup holds (jpezy_read_jpeg_gpu uploads them only when they change)
     const void* h_setup_dev = nullptr;  // ... and the allocation they were uploaded to
+    uint8_t* h_fb_pin = nullptr;        // pinned buffer for the host decoder's coefficients (read_jpeg_host_to_device)
+    size_t h_fb_cap = 0;
     int h_last_passes = 0;         // synchronisation passes of the last jpezy_read_jpeg_gpu (0: the host decoder was used)
     size_t h_min_bytes = 32 << 10;    // scans shorter than this are decoded on the host: the GPU path has ~0.32 ms of fixed cost, the host decoder
                                       // takes ~10.5 us per KiB of scan (tools/huffdec_threshold.py, profiles/r04_huffdec_threshold.txt: they cross at

@@ -62,9 +62,19 @@ struct ScanState {
     unsigned long long removed;         // stuffing bytes removed in front of it
     unsigned changed2[4];               // second synchronisation launch
     unsigned n_sub;                     // subsequences that hold data
-    unsigned pad1[3];
+    unsigned periodic;                  // lanes that left their subsequence in the state they entered it (speculation): a periodic stream
+    unsigned pad1[2];
 };
 static_assert(sizeof(ScanState) == 80, "ScanState is read back in one copy");
+// A stream that does not synchronise (periodic data: flat areas) is the host decoder's: refinement would walk it lane after lane.  After the
+// first synchronisation launch (counters `changed`, see launch_sync): more than half of the lanes moved at its first step AND more than a
+// quarter are still pending after its propagation steps.  (Round 3 and most of round 4 judged by the first half alone, which also sent dense
+// high-quality noise away -- blocks longer than a subsequence leave few lanes in step after the speculation, but the corrections then settle
+// within a few steps: most of the wrong runs are short.)
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline bool scan_hopeless(const unsigned* changed, unsigned n_sub) { return changed[3] > n_sub / 2u + 16u && changed[1] > n_sub / 4u; }
 // Did the two synchronisation launches enqueued blindly settle the scan?  changed: the first launch's counters, changed2: the second's (which
 // left at once unless the first one left something for it).  The host and the guarded coefficient / DC launches ask the same function.
 #if defined(__HIPCC__)
@@ -74,7 +84,7 @@ inline bool scan_settled(const unsigned* changed, const unsigned* changed2, unsi
 {
     if (n_sub == 0u) return false;
     if (changed[1] == 0u && changed[2] == 0u) return true;                       // nothing pending after the first launch
-    if (changed[3] > n_sub / 2u + 16u) return false;                             // a stream that does not synchronise: the second launch left at once
+    if (scan_hopeless(changed, n_sub)) return false;                             // the second launch left at once
     return changed2[1] == 0u && changed2[2] == 0u;
 }
 hipError_t launch_scan_state_init(ScanState* st, hipStream_t s);

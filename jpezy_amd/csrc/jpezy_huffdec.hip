@@ -212,8 +212,13 @@ __global__ __launch_bounds__(WGS) void spec_kernel(const Setup* gS, const uint32
     unsigned mkb[EMIT_PARTS - 1];
     int delta = 0;
     (void)run_subsequence_marks(tabs, bpm, tdmask, c, wk, own, mk, mkb, false, &delta);
+    const uint32_t exit_now = pack_state(c.pos - (own + SUBSEQ_BITS), wk.b(), wk.k);
+    {   // lanes that leave in the state they entered (a stream with a period that divides the subsequence; one vote per wave)
+        const unsigned long long same = __builtin_amdgcn_ballot_w64(entry == exit_now);
+        if (same && (threadIdx.x & 63u) == (unsigned)__builtin_ctzll(same)) atomicAdd(const_cast<unsigned*>(&st->periodic), (unsigned)__builtin_popcountll(same));
+    }
     last_entry[i] = entry;
-    exit_state[i] = pack_state(c.pos - (own + SUBSEQ_BITS), wk.b(), wk.k);
+    exit_state[i] = exit_now;
     nblocks_out[i] = wk.nblocks;
 #pragma unroll
     for (int q = 0; q < EMIT_PARTS - 1; ++q) {
@@ -244,7 +249,7 @@ __global__ __launch_bounds__(WGS) void sync_kernel(const Setup* gS, const uint32
     const unsigned i0 = blockIdx.x * WGS, t = threadIdx.x, i = i0 + t;
     if (i0 >= n_sub) return;
     // enqueued blindly behind another launch: nothing left to do, or a stream that does not synchronise (RefineBudget in jpezy_capi_huffdec.hip)
-    if (prev && ((prev[1] == 0u && prev[2] == 0u) || prev[3] > n_sub / 2u + 16u)) return;
+    if (prev && ((prev[1] == 0u && prev[2] == 0u) || scan_hopeless(prev, n_sub))) return;
     const bool live = i < n_sub;
     uint32_t my_last = live ? last_entry[i] : 0u, my_exit = live ? exit_state[i] : 0u;
     const uint32_t exit_before = my_exit;

@@ -511,3 +511,23 @@ def test_dc_predictors_three_launch_form(tmp_path):
     env = dict(os.environ, JPEZY_DC_SELF_SUM_MAX="0")
     p = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=300)
     assert p.returncode == 0 and "OK" in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]
+
+
+def test_flat_colour_frame_is_not_refined_for_ever(J, ctx, oracle):
+    """A flat frame is a periodic stream.  When its period does not line up with the subsequences (any level but mid-gray: the first
+    MCU's DC codes shift the rest) a decoder started from the guess stays in a wrong parse for ever, and the speculative lanes --
+    all at the same phase of the period -- agree with one another: nothing looks wrong at the first step and the true state creeps
+    down the scan one lane per step.  Until round 4 such a scan was refined twelve launches long (50 ms for 4080 x 4096) before the
+    host decoder got it; now the speculation counts the lanes that leave their subsequence as they entered it and the scan gets one
+    refinement launch (profiles/r04_huffdec_periodic.txt).  The result is the host decoder's either way; the bound is generous."""
+    import time
+    W, H = 2032, 2048
+    planes = [np.full(W * H, v, np.uint8) for v in (77, 200, 77)]
+    data = ctx.encode_jpeg(*planes, W, H)
+    info, want = J.read_jpeg(data)
+    ctx.read_jpeg_gpu(data)
+    t0 = time.perf_counter()
+    ginfo, got = ctx.read_jpeg_gpu(data)
+    dt = time.perf_counter() - t0
+    assert np.array_equal(got.cpu().numpy().reshape(want.shape), want)
+    assert dt < 0.012, f"{dt * 1e3:.1f} ms"          # (4-5 ms measured, 1.7 of them the host decoder; twelve refinement launches take several times that)

@@ -224,7 +224,9 @@ int jpezy_internal_huffdec_streams(jpezy_ctx* c, const std::vector<DevStream>& s
             if (pending == 0) { active[k] = 0; converged[k] = 1; continue; }
             // many proposals moved at the first look (periodic data never falls into step), or the refinement launches have
             // stopped paying for this stream (RefineBudget): the caller's other path
-            if (pass == 0 ? HD::scan_hopeless(F[k].changed, F[k].n_sub) : !budget.go_on(pass + 1, prev_moved[k], moved)) { active[k] = 0; dead[k] = 1; }
+            // (a periodic stream that has not settled at once: its true state creeps down the scan one lane per step -- RefineBudget above)
+            const bool periodic = (unsigned long long)F[k].periodic * 5u > (unsigned long long)F[k].n_sub * 3u;
+            if (pass == 0 ? periodic || HD::scan_hopeless(F[k].changed, F[k].n_sub) : !budget.go_on(pass + 1, prev_moved[k], moved)) { active[k] = 0; dead[k] = 1; }
             prev_moved[k] = moved;
         }
         // reset the per-pass counters of the streams that go on (one launch: there may be tens of thousands of streams)

@@ -24,7 +24,7 @@ struct BatchFile {
     unsigned u_words;                   // 32-bit words of U the file may read
     unsigned removed;                   // stuffing bytes removed (device)
     unsigned first_marker;              // n_bytes may be an upper bound: offset of the first marker inside it (device, atomicMin; the host sets all ones)
-    unsigned pad2;
+    unsigned periodic;                  // lanes whose first walk left their subsequence in the state they entered it (device): a periodic stream
     unsigned long long coeff_off;       // int16 offset of the file's coefficients
     unsigned total_blocks, nmcu, bpm, ncomp;
     unsigned cstart[3], ccount[3];      // component c owns blocks [cstart, cstart + ccount) of every MCU

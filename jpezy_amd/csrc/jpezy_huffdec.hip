@@ -736,11 +736,13 @@ __global__ __launch_bounds__(WGS) void sync_batch_kernel(const Setup* setups, co
     const uint16_t* tabs = reinterpret_cast<const uint16_t*>(&S);
     const unsigned bpm = (unsigned)S.bpm, tdmask = S.tdmask;
     bool first_moved = false;                              // this lane's first decode of the launch left another state than it had
+    bool same_state = false;
     for (int inner = 0; inner < max_inner; ++inner) {
         const uint32_t entry = sh_exit[t];
         bool redo = live && entry != my_last;
         __syncthreads();
         if (redo) {
+            const bool first_walk = my_last == 0xFFFFFFFFu;
             my_last = entry;
             nb = 0;
             if (entry & 0x40000000u) {
@@ -754,12 +756,17 @@ __global__ __launch_bounds__(WGS) void sync_batch_kernel(const Setup* setups, co
                 run_subsequence(tabs, bpm, tdmask, c, wk, end);
                 nb = wk.nblocks;
                 my_exit = pack_state(c.pos - end, wk.b(), wk.k);
+                same_state = same_state || (first_walk && my_exit == entry);
             }
             redo = sh_exit[t + 1] != my_exit;
             sh_exit[t + 1] = my_exit;
             first_moved = first_moved || (inner == 0 && redo);
         }
         if (!__syncthreads_or(redo)) break;
+    }
+    {   // lanes whose very first walk left as it entered: a stream with a period that divides the subsequence (see RefineBudget)
+        const unsigned long long same = __builtin_amdgcn_ballot_w64(same_state);
+        if (same && (t & 63u) == (unsigned)__builtin_ctzll(same)) atomicAdd(&F[f].periodic, (unsigned)__builtin_popcountll(same));
     }
     if (live) {
         last_entry[i] = my_last;

@@ -246,6 +246,8 @@ def run_batch(args, torch, dist, J, ctx, dev, rank, world, multi, comm_cpu):
     """BASELINE configs[3]: `--batch-frames` 1920x1080 frames sharded over the ranks (strong scaling).  See the
     module docstring for what is reported.  comm_cpu: rehearsal on one GPU (gloo cannot move device tensors)."""
     from jpezy_amd import sharding
+    if os.environ.get("JPEZY_BENCH_FAIL_BATCH"):          # tests/test_gpu_parity.py: a failing batch leg must not cost the headline line
+        raise RuntimeError("injected failure (JPEZY_BENCH_FAIL_BATCH)")
     W, H, F, chunk = BATCH_W, BATCH_H, args.batch_frames, args.batch_chunk
     plane = W * H
     cpf = J.coeff_count(W, H, False)
@@ -433,6 +435,88 @@ def run_batch(args, torch, dist, J, ctx, dev, rank, world, multi, comm_cpu):
             res["rehearsal"] = "all ranks on GPU 0, gloo + host staging: control flow only, the numbers mean nothing"
     return res
 
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# The other single-GPU BASELINE configs on the driver's default line: configs[2] (decode 4096^2, bit-exact and tolerant) and
+# configs[4] (7680x4320 --gray encode and decode), a few replays each AFTER the timed region, reported beside `value`, never in it
+# ------------------------------------------------------------------------------------------------------------------
+OTHER_KERNELS = {"encode": "f32::fdct_quant_f32_kernel", "decode": "dequant_idct_kernel"}
+
+
+def measure_other_workloads(torch, J, ctx, dev, steps=40, replays=3):
+    """Every entry: the same protocol as the headline in small -- a ring of distinct frames larger than the Infinity Cache,
+    `steps` launches captured as one hipGraph, the median of `replays` replays timed with HIP events on the launch stream."""
+    traffic = {}
+    tfile = ROOT / "profiles" / "traffic.json"
+    if tfile.exists():
+        try:
+            traffic = json.loads(tfile.read_text())
+        except Exception:
+            traffic = {}
+    out = {}
+    stream = torch.cuda.Stream(dev)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(0x6A70657A7A)
+    for name, tolerant in (("decode4096", False), ("decode4096", True), ("gray8k", False), ("gray8k_decode", False)):
+        key = name + ("_tolerant" if tolerant else "")
+        try:
+            W, H, gray, fps, direction, desc = WORKLOADS[name]
+            plane = W * H
+            ncoef = J.coeff_count(W, H, gray if direction == "encode" else False)
+            step_bytes = algorithmic_bytes(W, H, gray, direction) * fps
+            ring = max(2, -(-(512 << 20) // step_bytes))
+            pr, pg, pb = (torch.randint(0, 256, (ring, plane), dtype=torch.uint8, device=dev, generator=gen) for _ in range(3))
+            co = torch.empty((ring, ncoef), dtype=torch.int16, device=dev)
+            with torch.cuda.stream(stream):
+                if direction == "decode":      # real coefficients: the random frames encoded once (6-block layout)
+                    for k in range(ring):
+                        ctx.fdct_quant_dev(pr[k], pg[k], pb[k], W, H, co[k], gray=False, stream=stream.cuda_stream)
+
+                    def step(i):
+                        k = i % ring
+                        ctx.dequant_idct_dev(co[k], W, H, pr[k], pg[k], pb[k], gray=gray, stream=stream.cuda_stream)
+                else:
+                    def step(i):
+                        k = i % ring
+                        ctx.fdct_quant_dev(pr[k], pg[k], pb[k], W, H, co[k], gray=gray, stream=stream.cuda_stream)
+                ctx.set_decode_tolerance(1 if tolerant else 0)
+                for i in range(4):
+                    step(i)
+                stream.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=stream):
+                    for i in range(steps):
+                        step(i)
+                stream.synchronize()
+                g.replay()
+                stream.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ms = []
+                for _ in range(replays):
+                    e0.record(stream)
+                    g.replay()
+                    e1.record(stream)
+                    stream.synchronize()
+                    ms.append(e0.elapsed_time(e1) / steps)
+            m = statistics.median(ms)
+            gbs = step_bytes / (m * 1e-3) / 1e9
+            tj = traffic.get(name, {}) if not tolerant else {}
+            out[key] = {"workload": desc + (" -- opt-in tolerance mode (within 1 LSB)" if tolerant else ""),
+                        "ms_per_step": round(m, 5), "value": round(plane * fps / (m * 1e-3) / 1e6, 2), "unit": "Mpixels/s",
+                        "steps": steps, "replays": replays, "kernel": OTHER_KERNELS[direction],
+                        "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                     "frac": round(gbs / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": step_bytes,
+                                     "traffic": tj.get("bytes_per_launch"), "traffic_source": tj.get("source")}}
+            del g, pr, pg, pb, co
+        except Exception as e:          # never at the cost of the headline line
+            out[key] = {"error": f"{type(e).__name__}: {e}"[:300]}
+        finally:
+            ctx.set_decode_tolerance(0)
+    ctx.fallback_count()
+    torch.cuda.synchronize(dev)
+    torch.cuda.empty_cache()
+    return out
 
 # ------------------------------------------------------------------------------------------------------------------
 def run_rank(args):
@@ -805,6 +889,13 @@ def run_rank(args):
             batch = {"error": f"{type(e).__name__}: {e}"[:400]} if rank == 0 else None
             print(f"bench.py rank {rank}: batch measurement failed: {e}", file=sys.stderr)
 
+    others = None
+    if rank == 0 and world == 1 and args.workload == "encode4096" and not args.no_others and args.variant in (None, 1) and not args.tolerant:
+        try:
+            others = measure_other_workloads(torch, J, ctx, dev)
+        except Exception as e:
+            others = {"error": f"{type(e).__name__}: {e}"[:300]}
+
     if rank == 0:
         px_per_step = plane * fps
         total_px = px_per_step * args.steps * world
@@ -878,16 +969,24 @@ def run_rank(args):
             out["decode_tolerant"] = dec_tol
         if batch:
             out["batch"] = batch
+        if batch and "error" not in batch:
             # north_star's 8-GPU target is STRONG scaling of this batch (configs[3]); `value` above is weak scaling of configs[1].
             # Top-level copies so that a 1 -> 8 curve of the target can be read off the lines without opening the object.
-            out["batch_strong_scaling"] = {
-                "metric": "Mpixels/s, batch of %d 1920x1080 frames end to end in .jpg on rank 0 (strong scaling)" % batch["frames"],
-                "value": batch["end_to_end_jpg"]["Mpixels_per_s"],
-                "value_coefficients_gathered": batch["end_to_end"]["Mpixels_per_s"],
-                "value_kernels_only": batch["kernel_only"]["Mpixels_per_s"],
-                "one_gpu_same_pipeline": batch["one_gpu_same_pipeline_jpg"]["Mpixels_per_s"],
-                "speedup_vs_one_gpu": batch["speedup_end_to_end_jpg"],
-                "n_gpus": world}
+            try:
+                out["batch_strong_scaling"] = {
+                    "metric": "Mpixels/s, batch of %d 1920x1080 frames end to end in .jpg on rank 0 (strong scaling)" % batch["frames"],
+                    "value": batch["end_to_end_jpg"]["Mpixels_per_s"],
+                    "value_coefficients_gathered": batch["end_to_end"]["Mpixels_per_s"],
+                    "value_kernels_only": batch["kernel_only"]["Mpixels_per_s"],
+                    "one_gpu_same_pipeline": batch["one_gpu_same_pipeline_jpg"]["Mpixels_per_s"],
+                    "speedup_vs_one_gpu": batch["speedup_end_to_end_jpg"],
+                    "n_gpus": world}
+            except (KeyError, TypeError) as e:      # a partial batch object must not cost the job its headline line either
+                out["batch_strong_scaling"] = {"error": f"{type(e).__name__}: {e}"}
+        if others:
+            # BASELINE configs[2] and [4] (and the decoder's opt-in tolerance mode) as this same run measured them after the timed
+            # region: objects of their own, never part of `value`
+            out["other_workloads"] = others
         if not args.no_cpu:          # rank 0 only, after every timed region (the other ranks idle at the closing barrier)
             out["cpu_baseline"] = cpu_baseline(W, H, gray, direction)
         print(json.dumps(out), flush=True)
@@ -909,6 +1008,8 @@ def parse_args(argv=None):
     ap.add_argument("--ring", type=int, default=0, help="distinct batches in the ring (0 = enough to exceed 512 MiB)")
     ap.add_argument("--variant", type=int, default=None, help="encode kernel variant (0 FP64 butterflies, 1 packed-FP32 first level [default])")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-others", action="store_true",
+                    help="default workload at N = 1: skip the other_workloads object (configs[2] and [4] measured after the timed region)")
     ap.add_argument("--batch", action="store_true", help="measure the configs[3] batch pipeline also at N = 1")
     ap.add_argument("--no-batch", action="store_true", help="N > 1: skip the configs[3] batch measurement")
     ap.add_argument("--batch-frames", type=int, default=None,

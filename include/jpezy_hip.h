@@ -158,8 +158,10 @@ int jpezy_dequant_idct_generic_batch_dev(jpezy_ctx* ctx, const int16_t* d_coeffs
  * parity tests. */
 void jpezy_ctx_set_force_exact(jpezy_ctx* ctx, int on);
 /* Encode kernel variant: 0 = FP64 butterflies (round-1 kernel), 1 = packed-FP32 first level + FP64 second level +
- * reference-order third level (default).  Two independently written kernels with proven error bounds that must agree bit
- * for bit (tests/test_gpu_parity.py runs every case through both). */
+ * reference-order third level, one quad of four MCUs per wave.  Two independently written kernels with proven error
+ * bounds that must agree bit for bit (tests/test_gpu_parity.py runs every case through both).  2 = variant 1's arithmetic
+ * in persistent workgroups whose loader waves stream the pixels into an LDS ring by LDS-DMA (frames whose rows divide into
+ * groups of 16 MCUs and 16-byte aligned planes; anything else is handed to variant 1's launch).  tests/test_gpu_persistent.py. */
 int jpezy_ctx_set_variant(jpezy_ctx* ctx, int variant);
 /*
  * Decode tolerance (opt-in; default 0).  BASELINE.json's north_star asks of the decoder "PPM output within +-1 LSB per

@@ -48,6 +48,11 @@ jpezy_ctx* jpezy_ctx_create(int device)
         return nullptr;
     }
     c->device = device;
+    if (hipDeviceGetAttribute(&c->n_cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || c->n_cus <= 0) c->n_cus = 256;
+    if (const char* v = getenv("JPEZY_ENC_VARIANT")) {   // development: the default encode kernel of every context (A/B runs of tools/ab_run.sh)
+        const int k = atoi(v);
+        if (k >= 0 && k <= 3) c->variant = k;
+    }
     std::vector<DeviceTables> hbuf(1); // 33 KB: off the stack, and private to this call (contexts may be created concurrently)
     DeviceTables& h = hbuf[0];
     const double S = JPEZY_INV_SQRT2;
@@ -184,7 +189,7 @@ int jpezy_ctx_set_decode_tolerance(jpezy_ctx* c, int on)
 int jpezy_ctx_set_variant(jpezy_ctx* c, int variant)
 {
     if (!c) return set_err(JPEZY_E_BADARG, "null context");
-    if (variant < 0 || variant > 1) return set_err(JPEZY_E_BADARG, "unknown kernel variant");
+    if (variant < 0 || variant > 3) return set_err(JPEZY_E_BADARG, "unknown kernel variant");
     c->variant = variant;
     return JPEZY_OK;
 }
@@ -250,7 +255,11 @@ int jpezy_fdct_quant_dev(jpezy_ctx* c, const uint8_t* d_r, const uint8_t* d_g, c
         q.n_frames = n_frames - f0 < kMaxFramesPerLaunch ? n_frames - f0 : kMaxFramesPerLaunch;
         q.r += (size_t)f0 * plane_stride; q.g += (size_t)f0 * plane_stride; q.b += (size_t)f0 * plane_stride;
         q.coeffs += (size_t)f0 * p.coeffs_per_frame;
-        if (c->variant == 1)
+        if (c->variant == 3)
+            HIP_TRY(launch_fdct_quant_f32_ps2(q, gray != 0, c->force_exact, c->n_cus, s));
+        else if (c->variant == 2)
+            HIP_TRY(launch_fdct_quant_f32_ps(q, gray != 0, c->force_exact, c->n_cus, s));
+        else if (c->variant == 1)
             HIP_TRY(launch_fdct_quant_f32(q, gray != 0, c->force_exact, s));
         else
             HIP_TRY(launch_fdct_quant(q, gray != 0, c->force_exact != 0, s));

@@ -137,7 +137,11 @@ struct jpezy_ctx {
     bool dq_valid = false;
     int force_exact = 0;           // 0 normal, 1 everything through the reference-order path, 2 (f32 variant) through level 2,
                                    // 3 (f32 variant) through the per-lane evaluator of the queue-overflow case
-    int variant = 1;               // encode kernel: 0 = FP64 butterflies, 1 = FP32 first level (default)
+#ifndef JPEZY_DEFAULT_VARIANT
+#define JPEZY_DEFAULT_VARIANT 1
+#endif
+    int variant = JPEZY_DEFAULT_VARIANT;   // encode kernel: 0 = FP64 butterflies, 1 = FP32 first level (default), 2 = variant 1's arithmetic in persistent workgroups
+    int n_cus = 0;                 // compute units of the device (grid of the persistent kernel)
 #ifdef JPEZY_TRACE
     unsigned long long* d_trace = nullptr;
 #endif

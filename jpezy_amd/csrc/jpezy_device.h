@@ -69,6 +69,10 @@ struct EncParams {
     unsigned qpr_magic, qpr_shift;   // fast_div by quads_per_row
     int groups_per_row;              // f32 kernel: workgroups per MCU row, and fast_div by it (set by its launcher)
     unsigned gpr_magic, gpr_shift;
+    // persistent f32 kernel (variant 2): groups of four quads over all frames of the launch, fast_div by the groups of one frame
+    unsigned ps_total_groups, ps_groups_per_frame, gpf_magic, gpf_shift;
+    // variant 3: quads over all frames of the launch, fast_div by the quads of one frame
+    unsigned ps_total_quads, ps_quads_per_frame, qpf_magic, qpf_shift;
 #ifdef JPEZY_TRACE
     unsigned long long* trace;       // development builds only (tools/wave_trace.py): 4 words per wave
 #endif
@@ -111,6 +115,13 @@ hipError_t launch_fdct_quant(const EncParams& p, bool gray, bool force_exact, hi
 // coefficient through the reference-order chain, 2 every coefficient through the FP64 second level, 3 every quad
 // through the per-lane evaluator of the queue-overflow case.
 hipError_t launch_fdct_quant_f32(const EncParams& p, bool gray, int force, hipStream_t stream);
+// variant 2: the same arithmetic in persistent workgroups with LDS-DMA loader waves (jpezy_kernels_f32.hip); frames whose rows do
+// not divide into groups of four quads, or unaligned planes, go to variant 1's launch.  n_cus: compute units of the device.
+hipError_t launch_fdct_quant_f32_ps(const EncParams& p, bool gray, int force, int n_cus, hipStream_t stream);
+bool fdct_quant_f32_ps_applies(const EncParams& p);
+// variant 3: persistent workgroups of 16 compute waves, every wave prefetching its next quad's pixels into registers; any frame
+// with W % 16 == 0 and 16-byte aligned planes, anything else goes to variant 1's launch
+hipError_t launch_fdct_quant_f32_ps2(const EncParams& p, bool gray, int force, int n_cus, hipStream_t stream);
 // tolerant: luma in FP32 without guard band (samples within one of the reference's, jpezy_kernels.hip); chroma stays exact
 hipError_t launch_dequant_idct(const DecParams& p, bool gray, bool force_exact, bool tolerant, hipStream_t stream);
 

@@ -4,6 +4,6 @@
 // Switches that keep the results right (JPEZY_DEC_LDS_R01, JPEZY_DEC_INTERLEAVE, JPEZY_ENT_NOFAST, JPEZY_TRACE,
 // JPEZY_DUMP_T, register / occupancy knobs) are not gated.
 #pragma once
-#if (defined(JPEZY_ABL_NOGUARD) || defined(JPEZY_ABL_NOCFLAG) || defined(JPEZY_ABL_LIGHT_TAIL) || defined(JPEZY_ENT_ABL)) && !defined(JPEZY_EXPERIMENT)
+#if (defined(JPEZY_ABL_PS_NOLOAD) || defined(JPEZY_ABL_NOSTORE) || defined(JPEZY_ABL_NOGUARD) || defined(JPEZY_ABL_NOCFLAG) || defined(JPEZY_ABL_LIGHT_TAIL) || defined(JPEZY_ENT_ABL)) && !defined(JPEZY_EXPERIMENT)
 #error "JPEZY_ABL_* / JPEZY_ENT_ABL produce wrong results: such a build must also define JPEZY_EXPERIMENT"
 #endif

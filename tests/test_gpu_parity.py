@@ -508,6 +508,31 @@ def test_bench_prints_one_contract_line():
     assert abs(d["value"] - 4096 * 4096 / (d["ms_per_step"] * 1e-3) / 1e6) / d["value"] < 0.01
 
 
+def test_bench_line_survives_a_failing_batch_leg_and_carries_the_other_workloads():
+    """ADVICE r04: when run_batch raises, the headline JSON line is still printed (batch = {"error": ...}, no batch_strong_scaling);
+    VERDICT r04 item 2: the default command's line carries configs[2] and [4] as `other_workloads`, measured after the timed region."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    env = dict(os.environ, JPEZY_BENCH_FAIL_BATCH="1")
+    r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "1", "--no-cpu", "--batch"],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert "injected failure" in d["batch"]["error"] and "batch_strong_scaling" not in d
+    assert d["value"] > 0 and d["roofline"]["frac"] > 0
+    ow = d["other_workloads"]
+    for k in ("decode4096", "decode4096_tolerant", "gray8k", "gray8k_decode"):
+        assert "error" not in ow[k], ow[k]
+        assert ow[k]["ms_per_step"] > 0 and 0 < ow[k]["roofline"]["frac"] < 1 and ow[k]["kernel"]
+        assert abs(ow[k]["roofline"]["frac"] - ow[k]["roofline"]["achieved"] / 8000.0) < 1e-3
+    assert ow["decode4096_tolerant"]["ms_per_step"] < ow["decode4096"]["ms_per_step"] * 1.05
+
+
 def test_bench_decode4096_jpg_line():
     """the workload that starts from .jpg bytes (GPU Huffman decoder + fused IDCT): one contract line whose roofline object prices
     jpezy_read_jpeg_gpu, the decoder really on the GPU (synchronisation launches > 0), value = pixels over the wall time of the K steps"""

@@ -530,6 +530,17 @@ __device__ __forceinline__ void encode_quad_compute(const EncParams& p, const ui
 #define DUMP_ARG
 #endif
     if (lane == 0) queue[0] = 0;
+#ifdef JPEZY_PROBE_SALU   // timing probe (results unchanged): JPEZY_PROBE_SALU extra scalar-ALU instructions per quad, in four places
+#define PROBE_SALU() do { int d_ = lane; d_ = __builtin_amdgcn_readfirstlane(d_); _Pragma("unroll") for (int k_ = 0; k_ < JPEZY_PROBE_SALU / 4; ++k_) asm volatile("s_add_u32 %0, %0, 1" : "+s"(d_)); asm volatile("" :: "s"(d_)); } while (0)
+#else
+#define PROBE_SALU() do { } while (0)
+#endif
+#ifdef JPEZY_PROBE_VALU   // the same with full-rate vector instructions
+#define PROBE_VALU() do { int d_ = lane; _Pragma("unroll") for (int k_ = 0; k_ < JPEZY_PROBE_VALU / 4; ++k_) asm volatile("v_add_u32 %0, %0, 1" : "+v"(d_)); asm volatile("" :: "v"(d_)); } while (0)
+#else
+#define PROBE_VALU() do { } while (0)
+#endif
+    PROBE_SALU(); PROBE_VALU();
     PkCos kc = pk_cos();
 #if JPEZY_PIN_CONSTANTS
     // ten SGPRs for the whole kernel: left alone, hipcc rebuilds every constant pair with s_mov_b32 in front of the packed
@@ -590,6 +601,7 @@ __device__ __forceinline__ void encode_quad_compute(const EncParams& p, const ui
     }
     PHASE_FENCE();
     after_pixels();
+    PROBE_SALU(); PROBE_VALU();
     PHASE_STAMP(3);
     wave_sync();
 
@@ -632,6 +644,7 @@ __device__ __forceinline__ void encode_quad_compute(const EncParams& p, const ui
     }
 
     PHASE_FENCE();
+    PROBE_SALU(); PROBE_VALU();
     PHASE_STAMP(5);
     // ---- 5. chroma row pass, transpose, column pass ----
     if (!GRAY) {
@@ -657,6 +670,7 @@ __device__ __forceinline__ void encode_quad_compute(const EncParams& p, const ui
         quant_block_column(Fc, ks, dd, PS ? pre->th_c : lcol[8].th, j, dc_c, live, sbase, zz_lo, zz_hi, 4 * STG_BLK, m * BPM + 4 + bx, queue, FORCE != 0 DUMP_ARG);
     }
     wave_sync();
+    PROBE_SALU(); PROBE_VALU();
     PHASE_STAMP(6);
 
     // ---- 5b. levels 2 and 3 for the queued coefficients (FORCE 1/2: every coefficient of the quad) ----
@@ -1234,7 +1248,7 @@ __global__ __launch_bounds__(64 * PS_WAVES, (JPEZY_PS_WG_PER_CU * PS_WAVES + 3) 
 // store instructions): loads and stores complete in issue order, so that wait covers the loads and leaves the stores in flight.
 // For that count to be exact the stores are unconditional (encode_quad_store<ALL_LANES>) and the loop holds no other
 // vector-memory instruction: quantiser records in registers, DC / cosine / quantiser tables in LDS as in variant 2.
-constexpr int PS2_WAVES = 16;
+constexpr int PS2_WAVES = 16;      // (quad_of below: runs of 16 quads)
 static_assert(PS2_WAVES * WAVE_LDS_DWORDS * 4 + (2 * 16385 + 15) / 16 * 16 + (int)sizeof(PsTables) <= 160 * 1024, "LDS per CU");
 
 template <bool GRAY, int FORCE>
@@ -1245,8 +1259,16 @@ __global__ __launch_bounds__(64 * PS2_WAVES) void fdct_quant_f32_ps2_kernel(EncP
     __shared__ __attribute__((aligned(16))) signed char dcq_s[DCQ_BYTES];
     __shared__ PsTables pst;
     const int lane0 = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const unsigned stride = gridDim.x * PS2_WAVES, total = p.ps_total_quads;
-    unsigned q = blockIdx.x * PS2_WAVES + (unsigned)wave;
+    // The workgroup owns the runs of 16 consecutive quads number w, w + gridDim.x, ... (w = blockIdx.x) and its waves DRAW quads from
+    // them through a counter in LDS: draw j is quad ((j / 16) * gridDim.x + w) * 16 + j % 16.  A fixed share per wave ends badly:
+    // the four waves of a SIMD are served oldest first, so the older ones run through their quads in 3 us each while the youngest
+    // takes up to 18 us for its first -- measured with four quads per wave: the waves finished after 19 us on average, the last one
+    // of a workgroup after 26 us, the launch after 30 (profiles/r05_ps2_timeline_static.txt).
+    __shared__ unsigned next_draw;
+    const unsigned nwg = gridDim.x, w = blockIdx.x, total = p.ps_total_quads;
+    auto quad_of = [&](unsigned j) -> unsigned { return ((j >> 4) * nwg + w) * 16u + (j & 15u); };   // increasing in j
+    unsigned q = quad_of((unsigned)wave);
+    if (threadIdx.x == 0) next_draw = PS2_WAVES;
 
     // quad q -> (frame, mcu_y, quad_x); scalar
     auto locate = [&](unsigned qq, unsigned& frame, int& mcu_y, int& quad_x) {
@@ -1308,20 +1330,51 @@ __global__ __launch_bounds__(64 * PS2_WAVES) void fdct_quant_f32_ps2_kernel(EncP
         unsigned frame; int mcu_y, quad_x;
         locate(q, frame, mcu_y, quad_x);
         const unsigned qidx = (unsigned)(mcu_y * p.quads_per_row + quad_x);
-        const unsigned qn = q + stride;
+        unsigned qn = 0;
 #ifdef JPEZY_TRACE
+        const unsigned long long tr_t0 = __builtin_amdgcn_s_memrealtime();
         QuadTrace tr;
+#if JPEZY_TRACE >= 3
+        unsigned long long* ph = tr.ph;
+        PHASE_STAMP(0);
 #endif
+        const unsigned long long tr_t1 = tr_t0;
+#endif
+        PHASE_STAMP(1);
         // steps 2-5b; between 2b and 3 the next quad's pixels are requested into R, G, B
         encode_quad_compute<GRAY, FORCE, true>(p, R, G, B, lds, lane, mcu_y, quad_x, (int)frame, qidx, &lc, dcq_s, &pst,
                                                 // (unconditional: behind a branch the loaded values would have to be merged with the old ones
                                                 // at once, and the wait for them would stand here; a wave's last round re-reads its last quad)
-                                                [&]() { request_pixels(qn < total ? qn : q, lane); } QUAD_TRACE_ARG);
+                                                [&]() {
+                                                    unsigned j = 0;
+                                                    if (lane == 0) j = __hip_atomic_fetch_add(&next_draw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                                    qn = quad_of((unsigned)__builtin_amdgcn_readfirstlane((int)j));
+                                                    request_pixels(qn < total ? qn : q, lane);
+                                                } QUAD_TRACE_ARG);
         encode_quad_store<GRAY, true>(p, lds, lane, mcu_y, quad_x, (int)frame);
         // the next quad's pixels: requested before the stores above, so this wait (placed by the compiler: vmcnt = the store
         // instructions issued since) does not include the stores
         asm volatile("" : "+v"(R[0]), "+v"(R[1]), "+v"(R[2]), "+v"(R[3]), "+v"(G[0]), "+v"(G[1]), "+v"(G[2]), "+v"(G[3]),
                           "+v"(B[0]), "+v"(B[1]), "+v"(B[2]), "+v"(B[3]));
+#ifdef JPEZY_TRACE
+        if (frame == 0 && qidx < 65536u) {      // "stores issued" here = stores + the wait for the next quad's pixels
+            const unsigned long long tr_t3 = __builtin_amdgcn_s_memrealtime();
+            const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+            if (lane == 0) {
+                p.trace[qidx * 4 + 0] = tr_t0;
+                p.trace[qidx * 4 + 1] = ((tr_t1 - tr_t0) << 32) | (tr.t2 - tr_t0);
+                p.trace[qidx * 4 + 2] = tr_t3 - tr_t0;
+                p.trace[qidx * 4 + 3] = ((unsigned long long)xcc << 32) | hw;
+#if JPEZY_TRACE >= 3
+                unsigned long long t_end;
+                asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_end) : : "memory");
+#pragma unroll
+                for (int k = 0; k < 8; ++k) p.trace[4 * 65536 + qidx * 9 + k] = ph[k];
+                p.trace[4 * 65536 + qidx * 9 + 8] = t_end;
+#endif
+            }
+        }
+#endif
         q = qn;
     }
 }

@@ -229,6 +229,41 @@ int jpezy_write_jpeg_gpu_dev(jpezy_ctx* ctx, const int16_t* d_coeffs, int W, int
 long jpezy_encode_jpeg(jpezy_ctx* ctx, const uint8_t* r, const uint8_t* g, const uint8_t* b, int W, int H, int gray,
                        const char* comment, uint8_t* out, size_t cap);
 
+/*
+ * MULTI-GPU, one host process (north_star: "host C++ ... partition the input batch and gather ... over xGMI").
+ *
+ * jpezy_shard_range: the partition rule of every batch entry point and of jpezy_amd/sharding.py -- shard k of n_shards owns the
+ * contiguous units [*first, *first + *count) of n_units; counts differ by at most one, the earlier shards take the extra.
+ *
+ * jpezy_encode_batch_multi: encoder::encode (encoder/jpezy_encoder.hpp:38-77) for n_frames independent frames of one size, i.e. the
+ * loop a caller of the reference runs over encoder objects, spread over the n_dev GPUs devices[0..n_dev) of this node; devices[0] is
+ * the ROOT (the calling thread drives it, one more host thread per further device).  r, g, b: host memory, n_frames consecutive W*H
+ * planes each.  Device k encodes shard k in chunks of chunk_frames (<= 0: 16) on two alternating streams with a context each, so that
+ * a chunk's results travel while the next chunk's kernels run.  out says what is wanted and where:
+ *   coeffs      NULL, or room for n_frames * jpezy_coeff_count(W, H, gray) int16 (the layout of jpezy_fdct_quant)
+ *   jpg         NULL, or n_frames * jpg_stride bytes: frame f's complete file at jpg + f * jpg_stride (MCU loop AND Huffman tail on
+ *               the frame's GPU, only the finished file travels, at its real length); jpg_sizes[f] (HOST memory, n_frames entries)
+ *               receives its length, JPEZY_E_FORMAT or JPEZY_E_NOSPACE (jpg_stride too small for it)
+ *   on_root_device  0: coeffs / jpg are HOST memory -- every device delivers its shard over its own PCIe link;
+ *                   1: they are memory of devices[0] (coeffs 16-byte aligned) -- the consumer runs on that GPU: the other devices'
+ *                      results are gathered into it chunk by chunk with hipMemcpyPeerAsync (xGMI between the GPUs of a node), the
+ *                      root's own chunks are written in place.
+ * An index may appear more than once in devices (several shards on one GPU, each with its own contexts and streams): that is how the
+ * multi-shard path is exercised on a one-GPU box (tests/test_gpu_multi.py).  Returns JPEZY_OK, or the first failing shard's code
+ * (message: which device and why); JPEZY_E_FORMAT when every shard ran but a frame was refused (see jpg_sizes).  Synchronous.
+ * Replaces, for a batch: the caller's loop over encoder objects; inside each frame encoder/jpezy_encoder.hpp:55-67 and :174-225.
+ */
+typedef struct jpezy_multi_out {
+    int16_t* coeffs;
+    uint8_t* jpg;
+    size_t jpg_stride;
+    long long* jpg_sizes;
+    int on_root_device;
+} jpezy_multi_out;
+void jpezy_shard_range(long n_units, int n_shards, int k, long* first, long* count);
+int jpezy_encode_batch_multi(const int* devices, int n_dev, const uint8_t* r, const uint8_t* g, const uint8_t* b, int W, int H, int gray,
+                             int n_frames, int chunk_frames, const char* comment, const jpezy_multi_out* out);
+
 typedef struct jpezy_frame_info {
     int width, height, ncomp, precision;
     int H[3], V[3], Tq[3];

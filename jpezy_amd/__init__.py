@@ -15,15 +15,17 @@ from .api import (  # noqa: F401
     FrameInfo,
     JpezyError,
     coeff_count,
+    encode_batch_multi,
     library_path,
     load_library,
     mcu_grid,
     read_jpeg,
+    shard_range,
     write_jpeg,
     write_jpeg_batch,
 )
 
 __all__ = [
-    "Context", "Decoder", "Encoder", "FrameInfo", "JpezyError", "coeff_count", "library_path",
-    "load_library", "mcu_grid", "read_jpeg", "write_jpeg", "write_jpeg_batch",
+    "Context", "Decoder", "Encoder", "FrameInfo", "JpezyError", "coeff_count", "encode_batch_multi", "library_path",
+    "load_library", "mcu_grid", "read_jpeg", "shard_range", "write_jpeg", "write_jpeg_batch",
 ]

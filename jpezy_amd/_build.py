@@ -23,7 +23,7 @@ DEVICE = ["--offload-arch=gfx950", "-fno-slp-vectorize"]
 
 LIB_SOURCES = [CSRC / "jpezy_kernels.hip", CSRC / "jpezy_kernels_f32.hip", CSRC / "jpezy_kernels_generic.hip",
                CSRC / "jpezy_entropy.hip", CSRC / "jpezy_huffdec.hip",
-               CSRC / "jpezy_capi.hip", CSRC / "jpezy_capi_entropy.hip", CSRC / "jpezy_capi_huffdec.hip", CSRC / "jpezy_capi_decode_batch.hip",
+               CSRC / "jpezy_capi.hip", CSRC / "jpezy_capi_entropy.hip", CSRC / "jpezy_capi_huffdec.hip", CSRC / "jpezy_capi_decode_batch.hip", CSRC / "jpezy_capi_multi.hip",
                CSRC / "jpezy_host_codec.cpp"]
 LIB_DEPS = LIB_SOURCES + [CSRC / "jpezy_device.h", CSRC / "jpezy_capi_internal.h", CSRC / "jpezy_experiment.h", CSRC / "jpezy_hostpipe.h", CSRC / "jpezy_host_codec.h", CSRC / "jpezy_entropy.h", CSRC / "jpezy_huffdec.h", CSRC / "jpezy_huffdec_core.h",
                           ROOT / "include" / "jpezy_hip.h", ROOT / "include" / "jpezy_constants.h"]

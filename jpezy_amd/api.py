@@ -34,6 +34,11 @@ class FrameInfo(C.Structure):
     ]
 
 
+class MultiOut(C.Structure):
+    _fields_ = [("coeffs", C.c_void_p), ("jpg", C.c_void_p), ("jpg_stride", C.c_size_t), ("jpg_sizes", C.POINTER(C.c_longlong)),
+                ("on_root_device", C.c_int)]
+
+
 # every symbol include/jpezy_hip.h declares: (name, restype, argtypes)
 _u8p, _i16p, _vp = C.POINTER(C.c_uint8), C.POINTER(C.c_int16), C.c_void_p
 _QT = C.POINTER((C.c_uint16 * 64) * 4)
@@ -70,6 +75,9 @@ ABI = [
     ("jpezy_write_jpeg_gpu_batch", C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, _vp, C.c_size_t, C.POINTER(C.c_long)]),
     ("jpezy_write_jpeg_gpu_dev", C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, _vp, C.c_size_t, _vp, _vp]),
     ("jpezy_encode_jpeg", C.c_long, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_char_p, _vp, C.c_size_t]),
+    ("jpezy_shard_range", None, [C.c_long, C.c_int, C.c_int, C.POINTER(C.c_long), C.POINTER(C.c_long)]),
+    ("jpezy_encode_batch_multi", C.c_int, [C.POINTER(C.c_int), C.c_int, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p,
+                                           C.POINTER(MultiOut)]),
     ("jpezy_read_jpeg", C.c_int, [_vp, C.c_size_t, C.POINTER(FrameInfo), _vp, C.c_size_t]),
     ("jpezy_read_jpeg_gpu", C.c_int, [_vp, _vp, C.c_size_t, C.POINTER(FrameInfo), _vp, C.c_size_t]),
     ("jpezy_decode_jpeg", C.c_int, [_vp, _vp, C.c_size_t, C.c_int, C.POINTER(FrameInfo), _vp, _vp, _vp, C.c_size_t]),
@@ -401,6 +409,59 @@ def write_jpeg_batch(coeffs, W, H, n_frames, gray=False, comment=None, threads=0
     sizes = (C.c_long * n_frames)()
     _check(lib.jpezy_write_jpeg_batch(_np_ptr(coeffs), W, H, int(gray), n_frames, comment, _np_ptr(buf), cap, sizes, threads))
     return [buf[f * cap: f * cap + sizes[f]].tobytes() for f in range(n_frames)]
+
+
+def shard_range(n_units, n_shards, k):
+    """[lo, hi) of shard k: the C entry jpezy_shard_range (the rule jpezy_encode_batch_multi partitions by)."""
+    lo, n = C.c_long(), C.c_long()
+    load_library().jpezy_shard_range(n_units, n_shards, k, C.byref(lo), C.byref(n))
+    return lo.value, lo.value + n.value
+
+
+def encode_batch_multi(devices, r, g, b, W, H, n_frames, gray=False, chunk_frames=0, comment=None, want_coeffs=False, want_jpg=True,
+                       on_root_device=False, jpg_stride=None):
+    """jpezy_encode_batch_multi: n_frames frames (host planes, n_frames * W * H bytes each) over the GPUs `devices` (devices[0] = root).
+    Returns (coeffs or None, list of .jpg bytes or None).  on_root_device: the results are gathered into the root GPU's memory (torch
+    tensors on that device) and copied to the host here only to be returned."""
+    lib = load_library()
+    planes = [np.ascontiguousarray(p, dtype=np.uint8).reshape(-1) for p in (r, g, b)]
+    for p in planes:
+        if p.size != W * H * n_frames:
+            raise JpezyError("plane size does not match W*H*n_frames")
+    if comment is None:
+        comment = b"Encoded by JPEZY" if gray else b"Encoded by jpezy"
+    cpf = lib.jpezy_coeff_count(W, H, int(gray))
+    stride = int(jpg_stride) if jpg_stride else lib.jpezy_jpeg_bound(W, H)
+    sizes = (C.c_longlong * n_frames)()
+    out = MultiOut()
+    out.on_root_device = int(bool(on_root_device))
+    out.jpg_stride = stride
+    out.jpg_sizes = sizes
+    keep = []
+    if on_root_device:
+        import torch
+        dev = torch.device("cuda", int(devices[0]))
+        if want_coeffs:
+            t = torch.empty(n_frames * cpf, dtype=torch.int16, device=dev); keep.append(t); out.coeffs = t.data_ptr()
+        if want_jpg:
+            t = torch.zeros(n_frames * stride, dtype=torch.uint8, device=dev); keep.append(t); out.jpg = t.data_ptr()
+    else:
+        if want_coeffs:
+            t = np.empty(n_frames * cpf, dtype=np.int16); keep.append(t); out.coeffs = t.ctypes.data
+        if want_jpg:
+            t = np.zeros(n_frames * stride, dtype=np.uint8); keep.append(t); out.jpg = t.ctypes.data
+    devs = (C.c_int * len(devices))(*[int(d) for d in devices])
+    rc = lib.jpezy_encode_batch_multi(devs, len(devices), _np_ptr(planes[0]), _np_ptr(planes[1]), _np_ptr(planes[2]), W, H, int(gray), n_frames,
+                                      int(chunk_frames), comment, C.byref(out))
+    if rc != 0 and not (rc == -5 and want_jpg):
+        _check(rc)
+    host = [k.cpu().numpy() if on_root_device else k for k in keep]
+    co = host.pop(0).reshape(n_frames, -1) if want_coeffs else None
+    jpg = None
+    if want_jpg:
+        buf = host.pop(0)
+        jpg = [buf[f * stride: f * stride + sizes[f]].tobytes() if sizes[f] > 0 else int(sizes[f]) for f in range(n_frames)]
+    return co, jpg
 
 
 def read_jpeg(data):

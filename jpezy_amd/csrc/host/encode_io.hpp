@@ -153,6 +153,19 @@ struct encode_io : pnm_stream {
         if (rgb_img.size() < width * height) initializing_succeed = false;   // the reference would read out of bounds
     }
 
+    // (extension, jpezy_encode --gpus: the batch form needs the planes of several files at once)
+    std::size_t image_width() const noexcept { return width; }
+    std::size_t image_height() const noexcept { return height; }
+    void append_planes(std::vector<std::uint8_t>& r, std::vector<std::uint8_t>& g, std::vector<std::uint8_t>& b) const
+    {
+        const std::size_t n = width * height;
+        for (std::size_t i = 0; i < n; ++i) {
+            r.push_back(std::to_integer<std::uint8_t>(rgb_img[i][0]));
+            g.push_back(std::to_integer<std::uint8_t>(rgb_img[i][1]));
+            b.push_back(std::to_integer<std::uint8_t>(rgb_img[i][2]));
+        }
+    }
+
 private:
     friend std::ostream& operator<<(std::ostream& os, const encode_io& pnm)   // Mode::PPM / --debug (:104-119)
     {

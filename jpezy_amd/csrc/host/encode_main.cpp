@@ -1,12 +1,18 @@
 // jpezy_encode <input.ppm> ( <output.(jpeg | jpg) [OPT: --gray]> | <output.ppm> | --debug )
 // Same argv rules, transcript and exit codes as the reference's src/encoder/main.cpp; the codec underneath is
 // the MI355X path (jpezy_encoder.hpp).
+// Extension (not in the reference):  jpezy_encode --gpus N [--gray] <in1.ppm> <out1.jpg> [<in2.ppm> <out2.jpg> ...]
+// encodes a list of files on up to N GPUs of this node through jpezy_encode_batch_multi: runs of consecutive inputs of one size
+// form a batch, a batch is sharded over the GPUs frame by frame.
 #include <cstdlib>
 #include <fstream>
 #include <iostream>
 #include <string_view>
 
 #include "encode_io.hpp"
+
+#include <cstdint>
+#include <vector>
 
 namespace {
 
@@ -24,10 +30,60 @@ bool has_ext(std::string_view s, std::string_view ext)
     return s.find(ext, s.find_first_of('.')) != std::string_view::npos;
 }
 
+// jpezy_encode --gpus N [--gray] in out [in out ...]
+int batch_main(const int argc, const char* argv[])
+{
+    const int want = std::atoi(argv[2]);
+    int a = 3;
+    bool gray = false;
+    if (a < argc && std::string_view(argv[a]) == "--gray") { gray = true; ++a; }
+    if (want <= 0 || a >= argc || (argc - a) % 2 != 0) {
+        std::cerr << "Usage: jpezy_encode --gpus N [--gray] <in1.ppm> <out1.jpg> [<in2.ppm> <out2.jpg> ...]" << std::endl;
+        return EXIT_FAILURE;
+    }
+    const int have = jpezy_hip_device_count();
+    if (have <= 0) { std::cerr << "jpezy_encode: no HIP device (the jpezy hot path has no CPU fallback)" << std::endl; return EXIT_FAILURE; }
+    std::vector<int> devices;
+    for (int d = 0; d < want && d < have; ++d) devices.push_back(d);
+    jpezy::disp_logo();
+    const int n_files = (argc - a) / 2;
+    int f = 0;
+    while (f < n_files) {
+        std::vector<std::uint8_t> r, g, b;
+        std::size_t W = 0, H = 0;
+        int n = 0;
+        for (; f + n < n_files; ++n) {                      // a run of consecutive inputs of one size
+            jpezy::encode_io pnm(argv[a + 2 * (f + n)]);
+            if (!pnm) { std::cerr << "The file is not found or the formatting error" << std::endl; return EXIT_FAILURE; }
+            if (n == 0) { W = pnm.image_width(); H = pnm.image_height(); }
+            else if (pnm.image_width() != W || pnm.image_height() != H) break;
+            pnm.append_planes(r, g, b);
+        }
+        const std::size_t stride = jpezy_jpeg_bound(static_cast<int>(W), static_cast<int>(H));
+        std::vector<std::uint8_t> jpg(stride * static_cast<std::size_t>(n));
+        std::vector<long long> sizes(static_cast<std::size_t>(n));
+        jpezy_multi_out out{ nullptr, jpg.data(), stride, sizes.data(), 0 };
+        const int rc = jpezy_encode_batch_multi(devices.data(), static_cast<int>(devices.size()), r.data(), g.data(), b.data(), static_cast<int>(W),
+                                                static_cast<int>(H), gray ? 1 : 0, n, 0, gray ? "Encoded by JPEZY" : "Encoded by jpezy", &out);
+        if (rc != JPEZY_OK) { std::cerr << "jpezy_encode_batch_multi: " << jpezy_hip_last_error() << std::endl; return EXIT_FAILURE; }
+        for (int i = 0; i < n; ++i) {
+            const char* name = argv[a + 2 * (f + i) + 1];
+            std::ofstream ofs(name, std::ios::binary);
+            ofs.write(reinterpret_cast<const char*>(jpg.data() + stride * static_cast<std::size_t>(i)), static_cast<std::streamsize>(sizes[static_cast<std::size_t>(i)]));
+            if (!ofs) { std::cerr << "output_file" << std::endl; return EXIT_FAILURE; }
+            std::cout << name << ": Output size: " << sizes[static_cast<std::size_t>(i)] << " byte" << std::endl;
+        }
+        f += n;
+    }
+    std::cout << "Encoded " << n_files << " file(s) on " << devices.size() << " GPU(s)" << std::endl;
+    return EXIT_SUCCESS;
+}
+
 }  // namespace
 
 int main(const int argc, const char* argv[])
 {
+    if (argc >= 3 && std::string_view(argv[1]) == "--gpus") return batch_main(argc, argv);
     if (argc < 3) return disp_error();
 
     Mode m1 = Mode::UD, m2 = Mode::UD;

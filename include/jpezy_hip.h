@@ -54,7 +54,7 @@ enum jpezy_status {
 
 const char* jpezy_hip_last_error(void);
 int jpezy_hip_device_count(void);
-/* 1 when the library was built with a timing-probe switch that gives wrong results (development builds of tools/ab_build.py,
+/* 1 when the library was built with a timing-probe switch that gives wrong results (development builds of tools/ab/ab_build.py,
  * jpezy_amd/csrc/jpezy_experiment.h); 0 for every build that may be shipped or tested. */
 int jpezy_hip_is_experimental_build(void);
 

@@ -12,7 +12,7 @@ from pathlib import Path
 import numpy as np
 
 _PKG = Path(__file__).resolve().parent
-# JPEZY_LIB: development aid (tools/ab.sh): load another build of the same library for A/B timing
+# JPEZY_LIB: development aid (tools/ab/ab_run.sh): load another build of the same library for A/B timing
 _LIBPATH = Path(os.environ["JPEZY_LIB"]) if os.environ.get("JPEZY_LIB") else _PKG / "libjpezy_hip.so"
 _LIB = None
 

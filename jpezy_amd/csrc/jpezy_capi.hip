@@ -49,7 +49,7 @@ jpezy_ctx* jpezy_ctx_create(int device)
     }
     c->device = device;
     if (hipDeviceGetAttribute(&c->n_cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || c->n_cus <= 0) c->n_cus = 256;
-    if (const char* v = getenv("JPEZY_ENC_VARIANT")) {   // development: the default encode kernel of every context (A/B runs of tools/ab_run.sh)
+    if (const char* v = getenv("JPEZY_ENC_VARIANT")) {   // development: the default encode kernel of every context (A/B runs of tools/ab/ab_run.sh)
         const int k = atoi(v);
         if (k >= 0 && k <= 3) c->variant = k;
     }

@@ -14,17 +14,23 @@ int read_jpeg_host_to_device(jpezy_ctx* c, const uint8_t* data, size_t len, jpez
     // The host decoder writes every coefficient, so its output needs no zeroing: up to 256 MB it goes to a pinned buffer the context keeps
     // (round 4: a fresh 50 MB vector per 4096^2 frame cost 8 ms of page faults and a pageable upload -- 14.6 ms around a 5 ms decode)
     const size_t bytes = total * sizeof(int16_t);
-    if (bytes <= ((size_t)256 << 20)) {
+    // A worker of jpezy_decode_jpeg_batch keeps at most 32 MB pinned (eight or more workers that each fell back once on a large file
+    // would otherwise hold gigabytes of page-locked memory for the life of their parent); a pinned allocation that fails is not an
+    // error: the pageable path below does the same work.
+    const size_t pin_limit = c->is_batch_child ? ((size_t)32 << 20) : ((size_t)256 << 20);
+    if (bytes <= pin_limit) {
         if (c->h_fb_cap < bytes) {
             if (c->h_fb_pin) (void)hipHostFree(c->h_fb_pin);
             c->h_fb_pin = nullptr; c->h_fb_cap = 0;
-            HIP_TRY(hipHostMalloc((void**)&c->h_fb_pin, bytes, hipHostMallocDefault));
-            c->h_fb_cap = bytes;
+            if (hipHostMalloc((void**)&c->h_fb_pin, bytes, hipHostMallocDefault) == hipSuccess) c->h_fb_cap = bytes;
+            else { c->h_fb_pin = nullptr; (void)hipGetLastError(); }
         }
-        const int rc = jpezy_host::read_jpeg(data, len, info, (int16_t*)c->h_fb_pin, total, &err);
-        if (rc < 0) { g_err = err; return rc; }
-        HIP_TRY(hipMemcpy(d_coeffs, c->h_fb_pin, bytes, hipMemcpyHostToDevice));
-        return JPEZY_OK;
+        if (c->h_fb_pin) {
+            const int rc = jpezy_host::read_jpeg(data, len, info, (int16_t*)c->h_fb_pin, total, &err);
+            if (rc < 0) { g_err = err; return rc; }
+            HIP_TRY(hipMemcpy(d_coeffs, c->h_fb_pin, bytes, hipMemcpyHostToDevice));
+            return JPEZY_OK;
+        }
     }
     std::vector<int16_t> tmp(total);
     const int rc = jpezy_host::read_jpeg(data, len, info, tmp.data(), tmp.size(), &err);
@@ -49,7 +55,7 @@ int read_jpeg_host_to_device(jpezy_ctx* c, const uint8_t* data, size_t len, jpez
 //     progress (round 2: a fixed six launches of 24 steps): two always run; from the third on the lanes that moved must be down to a
 //     residue (<= 64) or have fallen to 3/4 of the launch before; never more than MAX_LAUNCHES.
 // A file that drops out goes to the host decoder, whose result is the same.
-// (tools/fuzz_huffdec.py with JPEZY_HUFFDEC_DEBUG=1 prints the lanes moved per launch; JPEZY_HUFFDEC_PATIENT=1 lifts the budget.)
+// (tools/fuzz/fuzz_huffdec.py with JPEZY_HUFFDEC_DEBUG=1 prints the lanes moved per launch; JPEZY_HUFFDEC_PATIENT=1 lifts the budget.)
 // The numbers are in units of 1,024 bits of stream: with subsequences of L bits a step is 1024 / L times cheaper and a correction has that
 // many more lanes to cross.
 struct RefineBudget {
@@ -626,7 +632,7 @@ try {
     const size_t plane = (size_t)W * H, stride = (plane + 15) & ~(size_t)15;
     uint8_t* dst[3] = { r, g, b };
     // three plain copies into the caller's planes: measured against bands through the pinned ring of the host-buffer entry points
-    // (tools/measure_decode_single_raw.py, 4096 x 4096, planes the caller has touched before: 2.0 ms against 2.6 ms) -- the runtime's
+    // (tools/measure/measure_decode_single_raw.py, 4096 x 4096, planes the caller has touched before: 2.0 ms against 2.6 ms) -- the runtime's
     // pageable path moves 50 MB in 0.9 ms when the pages exist; what a caller pays for fresh pages is page faults, in either form
     for (int k = 0; k < 3; ++k)
         if (int rc2 = c->in[k].reserve(stride)) return rc2;

@@ -162,7 +162,7 @@ struct jpezy_ctx {
     size_t h_fb_cap = 0;
     int h_last_passes = 0;         // synchronisation passes of the last jpezy_read_jpeg_gpu (0: the host decoder was used)
     size_t h_min_bytes = 32 << 10;    // scans shorter than this are decoded on the host: the GPU path has ~0.32 ms of fixed cost, the host decoder
-                                      // takes ~10.5 us per KiB of scan (tools/huffdec_threshold.py, profiles/r04_huffdec_threshold.txt: they cross at
+                                      // takes ~10.5 us per KiB of scan (tools/measure/huffdec_threshold.py, profiles/r04_huffdec_threshold.txt: they cross at
                                       // ~30 KiB; round 3: 0.6 ms, 64 KiB; round 2: 3 ms, 256 KiB)
     static constexpr int B_DEPTH = 3;   // slices of jpezy_decode_jpeg_batch whose planes may be on their way to the host while the next one is decoded
     DevBuf b_scan, b_U, b_cnt, b_rb, b_state, b_prop, b_meta, b_coef, b_planes[B_DEPTH];   // jpezy_decode_jpeg_batch, batch form of the Huffman decoder

@@ -74,10 +74,10 @@ struct EncParams {
     // variant 3: quads over all frames of the launch, fast_div by the quads of one frame
     unsigned ps_total_quads, ps_quads_per_frame, qpf_magic, qpf_shift;
 #ifdef JPEZY_TRACE
-    unsigned long long* trace;       // development builds only (tools/wave_trace.py): 4 words per wave
+    unsigned long long* trace;       // development builds only (tools/profile/wave_trace.py): 4 words per wave
 #endif
 #ifdef JPEZY_DUMP_T
-    float* dump_t;                   // development builds only (tools/check_level1_bound.py): the f32 kernel's level-1
+    float* dump_t;                   // development builds only (tools/measure/check_level1_bound.py): the f32 kernel's level-1
                                      // t = F * ks of every coefficient, coefficient-buffer layout, NATURAL order in a block
 #endif
 };

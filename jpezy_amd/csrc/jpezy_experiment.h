@@ -1,4 +1,4 @@
-// jpezy_experiment.h -- one gate for every build switch that yields WRONG RESULTS (timing probes of tools/ab_build.py).
+// jpezy_experiment.h -- one gate for every build switch that yields WRONG RESULTS (timing probes of tools/ab/ab_build.py).
 // A library built with any of them must also be built with -DJPEZY_EXPERIMENT: it then says so through
 // jpezy_hip_is_experimental_build(), and the Python binding refuses to load it unless JPEZY_ALLOW_EXPERIMENT=1 is set.
 // Switches that keep the results right (JPEZY_DEC_LDS_R01, JPEZY_DEC_INTERLEAVE, JPEZY_ENT_NOFAST, JPEZY_TRACE,

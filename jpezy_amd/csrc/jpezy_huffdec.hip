@@ -932,16 +932,12 @@ hipError_t launch_unstuff_copy(const uint8_t* S, size_t n_max, const unsigned lo
     hipLaunchKernelGGL(unstuff_copy_kernel, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, s, S, n_max, removed_before, U, st);   // (a workgroup per 256 chunks, as before)
     return hipGetLastError();
 }
+static unsigned spec_overflow();
 hipError_t launch_speculate(const Setup* S, const uint32_t* U, size_t u_words, unsigned n_sub, const ScanState* st, uint32_t* exit_state,
                             uint32_t* last_entry, unsigned* nblocks, uint32_t* marks, unsigned* mark_blocks, hipStream_t s)
 {
-    static const unsigned overflow = [] {
-        const char* e = std::getenv("JPEZY_HUFFDEC_OVERFLOW");      // development knob; the default covers what was measured
-        const int v = e ? std::atoi(e) : OVERFLOW_DEFAULT;
-        return (unsigned)(v < 0 ? 0 : v > OVERFLOW ? OVERFLOW : v);
-    }();
     hipLaunchKernelGGL(spec_kernel, dim3((n_sub + WGS - 1) / WGS), dim3(WGS), 0, s, S, U, u_words, st, exit_state, last_entry, nblocks, marks, mark_blocks,
-                       overflow);
+                       spec_overflow());
     return hipGetLastError();
 }
 unsigned emit_parts() { return EMIT_PARTS; }
@@ -987,10 +983,10 @@ hipError_t launch_dc_prefix(int16_t* coeffs, int16_t* dc, unsigned bpm, unsigned
 }
 
 
-static unsigned spec_overflow()
+static unsigned spec_overflow()      // speculation distance in subsequences: one place for the single-scan and the batch form
 {
     static const unsigned overflow = [] {
-        const char* e = std::getenv("JPEZY_HUFFDEC_OVERFLOW");
+        const char* e = std::getenv("JPEZY_HUFFDEC_OVERFLOW");      // development knob; the default covers what was measured
         const int v = e ? std::atoi(e) : OVERFLOW_DEFAULT;
         return (unsigned)(v < 0 ? 0 : v > OVERFLOW ? OVERFLOW : v);
     }();

@@ -79,14 +79,14 @@ constexpr int WAVE_LDS_DWORDS = TILE_DWORDS + 64;   // 9728 B per wave, 38912 B 
 
 // Decode kernel LDS slice (dwords): the luma tile is exchanged in two halves (left blocks, then right blocks) so that
 // the slice is 5.4 KB instead of 9.5 KB and LDS no longer caps the kernel at 4 waves per SIMD.
-// Geometry from tools/lds_bank_model.py (the lane groups and bank functions of MI355X_MICROARCH.md): the coefficient
+// Geometry from tools/profile/lds_bank_model.py (the lane groups and bank functions of MI355X_MICROARCH.md): the coefficient
 // staging area has a 144-byte block pitch (the zig-zag-indexed 2-byte column reads of the four MCUs then start 24 banks
 // apart: 108 LDS cycles per wave instead of 192), the luma half tile an MCU stride == 8 (mod 32) dwords (conflict-free
 // ds_write_b64 columns; the ds_read_b128 rows become 2-way: 128 cycles for both instead of 160 -- no pitch makes both
 // directions conflict-free), the chroma tile unpadded rows (64 instead of 80).  Model: 456 -> 324 cycles per wave;
 // counters (profiles/r02e_ab_decode.txt): SQ_LDS_BANK_CONFLICT 219 -> 104, SQ_LDS_IDX_ACTIVE 487 -> 371 per wave -- and
 // 39.5 -> 39.3 us: the kernel is not bound by its LDS traffic.
-#ifdef JPEZY_DEC_LDS_R01     // round-1 geometry, kept for A/B counters (tools/ab_build.py)
+#ifdef JPEZY_DEC_LDS_R01     // round-1 geometry, kept for A/B counters (tools/ab/ab_build.py)
 constexpr int DH_PITCH = 20, DH_MCU = 16 * DH_PITCH + 16;                    // 336
 constexpr int DC_PITCH = 20, DC_COMP = 8 * DC_PITCH, DC_MCU = 2 * DC_COMP + 16;
 constexpr int DSTG_PITCH = 128;               // bytes per staged block
@@ -746,7 +746,7 @@ __global__ __launch_bounds__(64 * WPB, GRAY ? JPEZY_DEC_WAVES_GRAY : JPEZY_DEC_W
 #endif
     if constexpr (TOL) {
         // the whole luma tile as floats (pitch 16, MCU stride 264 dwords: the column stores are conflict-free, the 16-byte row
-        // reads 2-way -- tools/lds_bank_model.py); one exchange instead of two, no guard keys
+        // reads 2-way -- tools/profile/lds_bank_model.py); one exchange instead of two, no guard keys
         float* ldsf = reinterpret_cast<float*>(lds);
         {
             float* dst = ldsf + m * TF_MCU + cq;
@@ -955,8 +955,11 @@ __global__ __launch_bounds__(64 * WPB, GRAY ? JPEZY_DEC_WAVES_GRAY : JPEZY_DEC_W
     // Y, U = Cb - 128, V = Cr - 128 are integers, so each of r = Y + 1.402 V, g = Y - 0.3441 U - 0.7139 V, b = Y + 1.7718 U is Y plus a
     // term of the chroma sample alone, and revise_value(trunc(Y + t)) == clamp(Y + floor(t)) unless t is an integer whose double
     // evaluation may fall on either side (negative values clamp to 0 under both roundings).  1.402 V is a multiple of 0.002 and
-    // 1.7718 U of 0.0002 -- integral only at zero, where the products are exact --, and c = 0.3441 U + 0.7139 V is a multiple of
-    // 0.0001: integral for one pair in 10,000.  Round 4: three integer offsets per chroma sample from FP32 arithmetic (floor-
+    // 1.7718 U of 0.0002: inside the gate |U|, |V| <= 512 they are integral at zero, where the products are exact, and at
+    // V = +-500 (1.402 x 500 = 701), where BOTH the FP32 product 1.402f x 500 and the reference's double product 500 x 1.4020
+    // round to exactly 701.0 (asserted in tests/test_colour_offsets.py: a change of constant or gate that breaks either equality
+    // fails there), so floor and trunc agree on them; 1.7718 U is integral only for multiples of 5000.  c = 0.3441 U + 0.7139 V
+    // is a multiple of 0.0001: integral for one pair in 10,000.  Round 4: three integer offsets per chroma sample from FP32 arithmetic (floor-
     // converting v_cvt_flr_i32_f32: the FP32 error is below 3.4e-5 inside |U|, |V| <= 512, a third of the lattice spacing), three
     // integer additions per pixel; a chroma sample whose c is within 5e-5 of a NON-ZERO integer is one of those pairs (U = V = 0,
     // every gray pixel, has c = 0 exactly and the reference subtracts two zeros), and a wave that holds one -- or a chroma sample

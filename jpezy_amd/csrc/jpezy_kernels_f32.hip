@@ -243,7 +243,7 @@ __device__ __forceinline__ void luma8(const uint32_t* wr, const uint32_t* wg, co
     __builtin_amdgcn_sched_barrier(0);   // 4 pixels at a time: more in flight only costs registers
     luma_px2<2, 1>(wr[0], wg[0], wb[0], wr[1], wg[1], wb[1], A[2], e[2]);
     luma_px2<3, 0>(wr[0], wg[0], wb[0], wr[1], wg[1], wb[1], A[3], e[3]);
-#ifdef JPEZY_ABL_NOCFLAG    // timing probe (wrong results, tools/ab_build.py): what the colour guard tests and their rare path cost
+#ifdef JPEZY_ABL_NOCFLAG    // timing probe (wrong results, tools/ab/ab_build.py): what the colour guard tests and their rare path cost
     if (false) {
 #else
     if (wave_any(min8(e) < LUMA_TH)) {   // one pixel in 1000: the reference's FP64 rounding decides
@@ -448,7 +448,7 @@ __device__ __forceinline__ void lds_column(const float* src, f2* A)
 // natural-order view of a row of samples held as fdct8p wants them: x-th sample of A[k] = (s[k], s[7-k])
 __device__ __forceinline__ float pick(const f2* A, int x) { return x < 4 ? A[x].x : A[7 - x].y; }
 
-// development builds (-DJPEZY_TRACE=3, tools/wave_phases.py): the shader clock at the phase boundaries of every wave
+// development builds (-DJPEZY_TRACE=3, tools/profile/wave_phases.py): the shader clock at the phase boundaries of every wave
 #if defined(JPEZY_TRACE) && JPEZY_TRACE >= 3
 #define PHASE_STAMP(k)                                                                                        \
     do {                                                                                                      \

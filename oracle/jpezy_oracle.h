@@ -15,7 +15,7 @@
  * Both are taken as the binary64 sqrt of 2.0 (srook::sqrt is a constexpr template; an overload returning an
  * integer would make the decoder's DC gain 1 instead of 1/sqrt 2 and every decoded image far too bright, which
  * the README's round trip rules out).  Whether the int overload rounds differently in the last place is
- * unknowable here; the alternative-constants build (tools/gen_constants.py --variant alt1, make CONSTANTS=...)
+ * unknowable here; the alternative-constants build (tools/gen/gen_constants.py --variant alt1, make CONSTANTS=...)
  * exists so that a different value is a one-header change for oracle and product alike.
  *
  * All `ref` citations are into /root/reference/src/.

@@ -96,7 +96,7 @@ def test_traffic_json_is_what_the_cited_summaries_say():
     # the counters agree with the algorithmic bytes to within 2 % (no wasted re-reads): encode and decode 4096^2
     b = _bench()
     assert abs(have["encode4096"]["bytes_per_launch"] / b.algorithmic_bytes(4096, 4096, False, "encode") - 1) < 0.02
-    # decode: the coefficient reads are exact; the non-temporal half-line plane stores are COUNTED at ~1.3x (tools/make_traffic_json.py)
+    # decode: the coefficient reads are exact; the non-temporal half-line plane stores are COUNTED at ~1.3x (tools/gen/make_traffic_json.py)
     dec = have["decode4096"]
     assert abs(2 * dec["fetch_size_kib"] * 1024 / (b.algorithmic_bytes(4096, 4096, False, "decode") / 2) - 1) < 0.02
     assert 0.98 < dec["write_size_kib"] * 1024 / (3 * 4096 * 4096) < 1.40

@@ -47,7 +47,14 @@ def test_offsets_equal_the_integer_floors_and_the_flags_are_the_integral_chroma_
     u = np.arange(-GATE, GATE + 1, dtype=np.int64)
     U, V = np.meshgrid(u, u, indexing="ij")
     offR, offG, offB, flag = kernel_offsets(U, V)
-    assert np.array_equal(offR, (701 * V) // 500)                             # floor(1.402 V); integral only for V = 0
+    assert np.array_equal(offR, (701 * V) // 500)                             # floor(1.402 V)
+    # 1.402 V is integral at V = 0 and, inside the gate, at V = +-500 (= +-701): there the argument "floor of a non-integer" does
+    # not apply, and the offsets are right only because the FP32 product AND the reference's double product are both exactly 701
+    # (made explicit so that a change of constant or gate that breaks either equality fails here)
+    assert GATE >= 500 and float(f32(np.float64(K_R) * F(500.0))) == 701.0 and float(f32(np.float64(K_R) * F(-500.0))) == -701.0
+    assert 500.0 * 1.4020 == 701.0 and -500.0 * 1.4020 == -701.0
+    assert [int(v) for v in u if (701 * int(v)) % 500 == 0] == [-500, 0, 500]
+    assert [int(v) for v in u if (8859 * int(v)) % 5000 == 0] == [0]          # 1.7718 U: integral only at zero inside the gate
     assert np.array_equal(offB, (8859 * U) // 5000)
     N = 3441 * U + 7139 * V
     integral = (N % 10000 == 0) & (N != 0)

@@ -1,6 +1,6 @@
 """The unpinned constants (cos table, 1/sqrt 2, pad-bit polarity: SURVEY H1/H8) live in ONE header,
 include/jpezy_constants.h, and both the oracle and the product follow it: built against an alternative header
-(tools/gen_constants.py --variant alt1: cosines one ULP larger, 1/sqrt 2 one ULP larger, pad bits 1) the two still agree
+(tools/gen/gen_constants.py --variant alt1: cosines one ULP larger, 1/sqrt 2 one ULP larger, pad bits 1) the two still agree
 with each other bit for bit -- and disagree with the frozen build, so the test has teeth.  If the true SrookCppLibraries
 values are ever obtained, regenerating that header is the whole change."""
 import json

@@ -260,7 +260,7 @@ def test_decode_jpeg_batch(J, ctx, oracle):
 
 
 def test_differential_fuzz_small(J, ctx):
-    """a short run of tools/fuzz_huffdec.py: random sizes, contents, qualities, sampling factors, optimised tables"""
+    """a short run of tools/fuzz/fuzz_huffdec.py: random sizes, contents, qualities, sampling factors, optimised tables"""
     import subprocess
     import sys
     from pathlib import Path
@@ -526,8 +526,9 @@ def test_flat_colour_frame_is_not_refined_for_ever(J, ctx, oracle):
     data = ctx.encode_jpeg(*planes, W, H)
     info, want = J.read_jpeg(data)
     ctx.read_jpeg_gpu(data)
-    t0 = time.perf_counter()
     ginfo, got = ctx.read_jpeg_gpu(data)
-    dt = time.perf_counter() - t0
     assert np.array_equal(got.cpu().numpy().reshape(want.shape), want)
-    assert dt < 0.012, f"{dt * 1e3:.1f} ms"          # (4-5 ms measured, 1.7 of them the host decoder; twelve refinement launches take several times that)
+    # the mechanism, not the clock (a wall-clock bound fails on a loaded box with no regression in the code): the scan was
+    # handed to the host decoder after the first look, i.e. the call reports no synchronisation passes of its own.  The times
+    # (4-5 ms, 1.7 of them the host decoder; twelve refinement launches took 50 ms) are in profiles/r04_huffdec_periodic.txt.
+    assert ctx.last_huffdec_passes() == 0

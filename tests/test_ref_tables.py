@@ -1,6 +1,6 @@
 """The integer half of the path, pinned to the reference itself.
 
-tests/golden/ref_tables.json holds what tools/extract_ref_tables.py read out of the reference's source text (data only): `ZZ`,
+tests/golden/ref_tables.json holds what tools/gen/extract_ref_tables.py read out of the reference's source text (data only): `ZZ`,
 Tables K.1 / K.2, the MARKER values (src/jpezy.hpp:36-45, 131-152, 47-127), Tables K.3-K.6 as (size, code) arrays in the
 reference's own `run * 10 + s + (run == 15)` layout with the EOB / ZRL indices and the four DHT segments
 (src/encoder/huffman_table.hpp:26-282), and the bytes `jpezy_writer::write_header` / `write_eoi` emit

@@ -82,7 +82,7 @@ def test_gpus_n_without_a_launcher_spawns_the_ranks_itself():
 
 
 def test_traffic_json_is_what_the_cited_summaries_say():
-    spec = importlib.util.spec_from_file_location("make_traffic_json", ROOT / "tools" / "make_traffic_json.py")
+    spec = importlib.util.spec_from_file_location("make_traffic_json", ROOT / "tools" / "gen" / "make_traffic_json.py")
     m = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(m)
     have = json.loads((ROOT / "profiles" / "traffic.json").read_text())

@@ -18,7 +18,7 @@ sys.path.insert(0, str(ROOT))
 
 @pytest.fixture(scope="module")
 def alt():
-    from tools import build_alt
+    from tools.gen import build_alt
     lib, ora, hdr = build_alt.build_alt("alt1")     # a no-op when __graft_entry__.build() already made them
     return lib, ora, hdr
 

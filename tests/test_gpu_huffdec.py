@@ -265,7 +265,7 @@ def test_differential_fuzz_small(J, ctx):
     import sys
     from pathlib import Path
     root = Path(__file__).resolve().parent.parent
-    out = subprocess.run([sys.executable, str(root / "tools" / "fuzz_huffdec.py"), "30"], capture_output=True, text=True, timeout=600)
+    out = subprocess.run([sys.executable, str(root / "tools" / "fuzz" / "fuzz_huffdec.py"), "30"], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "files identical" in out.stdout, out.stdout + out.stderr
 
 

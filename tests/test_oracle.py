@@ -36,7 +36,7 @@ def test_quant_tables_are_annex_k(oracle):
 
 
 def test_cos_table_is_correctly_rounded(oracle):
-    sys.path.insert(0, str(ROOT / "tools"))
+    sys.path.insert(0, str(ROOT / "tools" / "gen"))
     import gen_constants
     want = gen_constants.cos_table()
     got = oracle.constants()["cos"]

@@ -20,7 +20,7 @@ ALT_DIR = B.PKG / "_alt"          # git-ignored *.so / *.h, regenerated here
 def build_alt(variant="alt1", force=False):
     """Returns (product .so, oracle .so, header)."""
     hdr = ALT_DIR / f"jpezy_constants_{variant}.h"
-    gen = ROOT / "tools" / "gen_constants.py"
+    gen = ROOT / "tools" / "gen" / "gen_constants.py"
     if force or B._stale(hdr, [gen]):
         ALT_DIR.mkdir(parents=True, exist_ok=True)
         B._run([sys.executable, gen, "--variant", variant, "--out", hdr])

@@ -540,7 +540,28 @@ __device__ __forceinline__ void encode_quad_compute(const EncParams& p, const ui
 #else
 #define PROBE_VALU() do { } while (0)
 #endif
-    PROBE_SALU(); PROBE_VALU();
+#ifdef JPEZY_PROBE_NOP    // s_nop 0
+#define PROBE_NOP() do { _Pragma("unroll") for (int k_ = 0; k_ < JPEZY_PROBE_NOP / 4; ++k_) asm volatile("s_nop 0"); } while (0)
+#else
+#define PROBE_NOP() do { } while (0)
+#endif
+#ifdef JPEZY_PROBE_HALF   // a second-class vector instruction (v_cvt_f32_ubyte0)
+#define PROBE_HALF() do { float d_ = __builtin_bit_cast(float, lane); _Pragma("unroll") for (int k_ = 0; k_ < JPEZY_PROBE_HALF / 4; ++k_) asm volatile("v_cvt_f32_ubyte0 %0, %0" : "+v"(d_)); asm volatile("" :: "v"(d_)); } while (0)
+#else
+#define PROBE_HALF() do { } while (0)
+#endif
+#ifdef JPEZY_PROBE_PK     // a packed FP32 instruction
+#define PROBE_PK() do { f2 d_ = { 1.f, 2.f }; _Pragma("unroll") for (int k_ = 0; k_ < JPEZY_PROBE_PK / 4; ++k_) asm volatile("v_pk_add_f32 %0, %0, %0" : "+v"(d_)); asm volatile("" :: "v"(d_)); } while (0)
+#else
+#define PROBE_PK() do { } while (0)
+#endif
+#ifdef JPEZY_PROBE_LDS    // a 2-byte LDS store into the (still unused) queue area of the wave's slice
+#define PROBE_LDS() do { _Pragma("unroll") for (int k_ = 0; k_ < JPEZY_PROBE_LDS / 4; ++k_) asm volatile("ds_write_b16 %0, %1 offset:%2" :: "v"((unsigned)(uintptr_t)(queue + 8) + 2u * (unsigned)lane), "v"(lane), "n"(0) : "memory"); } while (0)
+#else
+#define PROBE_LDS() do { } while (0)
+#endif
+#define PROBE_ALL() do { PROBE_SALU(); PROBE_VALU(); PROBE_NOP(); PROBE_HALF(); PROBE_PK(); PROBE_LDS(); } while (0)
+    PROBE_ALL();
     PkCos kc = pk_cos();
 #if JPEZY_PIN_CONSTANTS
     // ten SGPRs for the whole kernel: left alone, hipcc rebuilds every constant pair with s_mov_b32 in front of the packed
@@ -601,7 +622,7 @@ __device__ __forceinline__ void encode_quad_compute(const EncParams& p, const ui
     }
     PHASE_FENCE();
     after_pixels();
-    PROBE_SALU(); PROBE_VALU();
+    PROBE_ALL();
     PHASE_STAMP(3);
     wave_sync();
 
@@ -644,7 +665,7 @@ __device__ __forceinline__ void encode_quad_compute(const EncParams& p, const ui
     }
 
     PHASE_FENCE();
-    PROBE_SALU(); PROBE_VALU();
+    PROBE_ALL();
     PHASE_STAMP(5);
     // ---- 5. chroma row pass, transpose, column pass ----
     if (!GRAY) {
@@ -670,7 +691,7 @@ __device__ __forceinline__ void encode_quad_compute(const EncParams& p, const ui
         quant_block_column(Fc, ks, dd, PS ? pre->th_c : lcol[8].th, j, dc_c, live, sbase, zz_lo, zz_hi, 4 * STG_BLK, m * BPM + 4 + bx, queue, FORCE != 0 DUMP_ARG);
     }
     wave_sync();
-    PROBE_SALU(); PROBE_VALU();
+    PROBE_ALL();
     PHASE_STAMP(6);
 
     // ---- 5b. levels 2 and 3 for the queued coefficients (FORCE 1/2: every coefficient of the quad) ----

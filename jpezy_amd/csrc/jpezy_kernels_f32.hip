@@ -1269,7 +1269,10 @@ __global__ __launch_bounds__(64 * PS_WAVES, (JPEZY_PS_WG_PER_CU * PS_WAVES + 3) 
 // store instructions): loads and stores complete in issue order, so that wait covers the loads and leaves the stores in flight.
 // For that count to be exact the stores are unconditional (encode_quad_store<ALL_LANES>) and the loop holds no other
 // vector-memory instruction: quantiser records in registers, DC / cosine / quantiser tables in LDS as in variant 2.
-constexpr int PS2_WAVES = 16;      // (quad_of below: runs of 16 quads)
+#ifndef JPEZY_PS2_WAVES
+#define JPEZY_PS2_WAVES 16
+#endif
+constexpr int PS2_WAVES = JPEZY_PS2_WAVES;      // waves per workgroup = quads per run (quad_of below)
 static_assert(PS2_WAVES * WAVE_LDS_DWORDS * 4 + (2 * 16385 + 15) / 16 * 16 + (int)sizeof(PsTables) <= 160 * 1024, "LDS per CU");
 
 template <bool GRAY, int FORCE>
@@ -1287,7 +1290,7 @@ __global__ __launch_bounds__(64 * PS2_WAVES) void fdct_quant_f32_ps2_kernel(EncP
     // of a workgroup after 26 us, the launch after 30 (profiles/r05_ps2_timeline_static.txt).
     __shared__ unsigned next_draw;
     const unsigned nwg = gridDim.x, w = blockIdx.x, total = p.ps_total_quads;
-    auto quad_of = [&](unsigned j) -> unsigned { return ((j >> 4) * nwg + w) * 16u + (j & 15u); };   // increasing in j
+    auto quad_of = [&](unsigned j) -> unsigned { return ((j / PS2_WAVES) * nwg + w) * PS2_WAVES + (j % PS2_WAVES); };   // increasing in j
     unsigned q = quad_of((unsigned)wave);
     if (threadIdx.x == 0) next_draw = PS2_WAVES;
 

@@ -518,6 +518,40 @@ def measure_other_workloads(torch, J, ctx, dev, steps=40, replays=3):
     torch.cuda.empty_cache()
     return out
 
+
+# ------------------------------------------------------------------------------------------------------------------
+# The native multi-GPU entry of the C-ABI (jpezy_encode_batch_multi: ONE host process, a thread per device, gather by peer copies),
+# timed by rank 0 over the GPUs of the job after everything else.  Host planes in, .jpg files out in host memory: PCIe-inclusive,
+# reported beside `value`, never in it.  On a one-GPU run it also runs two shards on the one device (the multi-shard path).
+# ------------------------------------------------------------------------------------------------------------------
+def measure_native_multi(J, ctx, n_dev, frames_per_dev=16):
+    import numpy as np
+    W, H = BATCH_W, BATCH_H
+    rng = np.random.default_rng(0x6A70)
+    base = [rng.integers(0, 256, (4, W * H), dtype=np.uint8) for _ in range(3)]          # four distinct frames, repeated
+    res = {"workload": f"{W}x{H} frames, host planes -> .jpg files in host memory (PCIe inclusive), jpezy_encode_batch_multi",
+           "entry": "include/jpezy_hip.h: jpezy_encode_batch_multi (one host process, one thread + two contexts per device)"}
+    layouts = [("devices_%d" % n_dev, list(range(n_dev)))]
+    if n_dev == 1:
+        layouts.append(("two_shards_on_one_device", [0, 0]))
+    else:
+        layouts.insert(0, ("devices_1", [0]))
+    ref = ctx.encode_jpeg(base[0][1], base[1][1], base[2][1], W, H)
+    for name, devs in layouts:
+        F = frames_per_dev * len(devs)
+        planes = [np.ascontiguousarray(np.tile(b, (F // 4 + 1, 1))[:F]).reshape(-1) for b in base]
+        try:
+            J.encode_batch_multi(devs, *planes, W, H, F, chunk_frames=8)              # contexts, buffers, first-touch
+            t0 = time.perf_counter()
+            _, jpg = J.encode_batch_multi(devs, *planes, W, H, F, chunk_frames=8)
+            dt = time.perf_counter() - t0
+            ok = all(isinstance(j, bytes) for j in jpg) and jpg[1] == ref and jpg[F - 3] == ref     # frames 1 and F-3 are copies of base frame 1
+            res[name] = {"devices": devs, "frames": F, "ms": round(dt * 1e3, 2), "Mpixels_per_s": round(F * W * H / dt / 1e6, 1),
+                         "jpg_bytes": int(sum(len(j) for j in jpg)), "equal_to_single_frame_entry": bool(ok)}
+        except Exception as e:
+            res[name] = {"devices": devs, "error": f"{type(e).__name__}: {e}"[:300]}
+    return res
+
 # ------------------------------------------------------------------------------------------------------------------
 def run_rank(args):
     import torch
@@ -896,6 +930,13 @@ def run_rank(args):
         except Exception as e:
             others = {"error": f"{type(e).__name__}: {e}"[:300]}
 
+    native = None
+    if rank == 0 and not args.no_native_multi and args.workload == "encode4096" and not args.rehearse_on_one_gpu:
+        try:
+            native = measure_native_multi(J, ctx, min(world, torch.cuda.device_count()))
+        except Exception as e:
+            native = {"error": f"{type(e).__name__}: {e}"[:300]}
+
     if rank == 0:
         px_per_step = plane * fps
         total_px = px_per_step * args.steps * world
@@ -987,6 +1028,8 @@ def run_rank(args):
             # BASELINE configs[2] and [4] (and the decoder's opt-in tolerance mode) as this same run measured them after the timed
             # region: objects of their own, never part of `value`
             out["other_workloads"] = others
+        if native:
+            out["native_multi_gpu"] = native
         if not args.no_cpu:          # rank 0 only, after every timed region (the other ranks idle at the closing barrier)
             out["cpu_baseline"] = cpu_baseline(W, H, gray, direction)
         print(json.dumps(out), flush=True)
@@ -1008,6 +1051,8 @@ def parse_args(argv=None):
     ap.add_argument("--ring", type=int, default=0, help="distinct batches in the ring (0 = enough to exceed 512 MiB)")
     ap.add_argument("--variant", type=int, default=None, help="encode kernel variant (0 FP64 butterflies, 1 packed-FP32 first level [default])")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-native-multi", action="store_true",
+                    help="default workload: skip the native_multi_gpu object (jpezy_encode_batch_multi timed by rank 0 after everything else)")
     ap.add_argument("--no-others", action="store_true",
                     help="default workload at N = 1: skip the other_workloads object (configs[2] and [4] measured after the timed region)")
     ap.add_argument("--batch", action="store_true", help="measure the configs[3] batch pipeline also at N = 1")

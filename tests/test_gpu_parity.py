@@ -531,6 +531,11 @@ def test_bench_line_survives_a_failing_batch_leg_and_carries_the_other_workloads
         assert ow[k]["ms_per_step"] > 0 and 0 < ow[k]["roofline"]["frac"] < 1 and ow[k]["kernel"]
         assert abs(ow[k]["roofline"]["frac"] - ow[k]["roofline"]["achieved"] / 8000.0) < 1e-3
     assert ow["decode4096_tolerant"]["ms_per_step"] < ow["decode4096"]["ms_per_step"] * 1.05
+    # round 5: the native multi-GPU entry of the C-ABI timed by the same run (one device here: one shard, and two shards on it)
+    nm = d["native_multi_gpu"]
+    for k in ("devices_1", "two_shards_on_one_device"):
+        assert "error" not in nm[k], nm[k]
+        assert nm[k]["equal_to_single_frame_entry"] is True and nm[k]["Mpixels_per_s"] > 0
 
 
 def test_bench_decode4096_jpg_line():

@@ -12,7 +12,7 @@ cd /tmp
 for lib in $ROOT/ab/libjpezy_*.so; do
   name=$(basename $lib .so); name=${name#libjpezy_}
   rm -rf /tmp/rp_abk
-  JPEZY_LIB=$lib timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_abk -o w -- python3 $ROOT/bench.py --workload $WL --steps 20 --warmup 2 --repeats 2 --no-cpu > /dev/null 2>&1
+  JPEZY_LIB=$lib timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_abk -o w -- python3 $ROOT/bench.py --workload $WL --steps 20 --warmup 2 --repeats 2 --no-cpu --no-others --no-native-multi > /dev/null 2>&1
   f=$(find /tmp/rp_abk -name '*kernel_stats.csv' | head -1)
   echo "== $name" | tee -a $OUT
   python3 - "$f" "$FILTER" <<'PY' | tee -a $OUT

@@ -16,7 +16,7 @@ for name in ${LIBS:-$(cd $ROOT/ab; ls libjpezy_*.so | sed 's/libjpezy_//; s/\.so
   lib=$ROOT/ab/libjpezy_$name.so
   for grp in "$G1" "$G2" "$G3"; do
     rm -rf /tmp/rp_ab
-    JPEZY_ALLOW_EXPERIMENT=1 JPEZY_LIB=$lib timeout -k 10 200 rocprofv3 --pmc $grp --output-format csv -d /tmp/rp_ab -o pmc -- python3 $ROOT/bench.py --steps 20 --warmup 2 --repeats 1 --no-cpu "$@" > /tmp/rp_ab.log 2>&1
+    JPEZY_ALLOW_EXPERIMENT=1 JPEZY_LIB=$lib timeout -k 10 200 rocprofv3 --pmc $grp --output-format csv -d /tmp/rp_ab -o pmc -- python3 $ROOT/bench.py --steps 20 --warmup 2 --repeats 1 --no-cpu --no-others --no-native-multi "$@" > /tmp/rp_ab.log 2>&1
     f=$(find /tmp/rp_ab -name '*counter_collection.csv' | head -1)
     if [ -z "$f" ]; then echo "$name: no counters for [$grp]" | tee -a $OUT; tail -3 /tmp/rp_ab.log | tee -a $OUT; continue; fi
     python3 - "$f" "$name" <<'PY' | tee -a $OUT

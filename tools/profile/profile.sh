@@ -8,7 +8,7 @@ TAG=${1:-r01}; shift || true
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-ARGS="--steps 40 --warmup 5 --repeats 2 --no-cpu --no-others $*"   # (--no-others: the default workload would otherwise append configs[2] and [4], whose kernels share truncated names with the timed one)
+ARGS="--steps 40 --warmup 5 --repeats 2 --no-cpu --no-others --no-native-multi $*"   # (--no-others: the default workload would otherwise append configs[2] and [4], whose kernels share truncated names with the timed one)
 cd /tmp
 run() { # name, rocprof flags...
   local name=$1; shift

@@ -21,11 +21,11 @@ COMMON = ["-std=c++17", "-O3", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unus
 # and pays v_mov shuffles for it -- the f32 encode kernel is 10 % faster without (33.8 vs 37.5 us per 4096^2 frame)
 DEVICE = ["--offload-arch=gfx950", "-fno-slp-vectorize"]
 
-LIB_SOURCES = [CSRC / "jpezy_kernels.hip", CSRC / "jpezy_kernels_f32.hip", CSRC / "jpezy_kernels_generic.hip",
+LIB_SOURCES = [CSRC / "jpezy_kernels.hip", CSRC / "jpezy_kernels_f32.hip", CSRC / "jpezy_kernels_f32_ps.hip", CSRC / "jpezy_kernels_generic.hip",
                CSRC / "jpezy_entropy.hip", CSRC / "jpezy_huffdec.hip",
                CSRC / "jpezy_capi.hip", CSRC / "jpezy_capi_entropy.hip", CSRC / "jpezy_capi_huffdec.hip", CSRC / "jpezy_capi_decode_batch.hip", CSRC / "jpezy_capi_multi.hip",
                CSRC / "jpezy_host_codec.cpp"]
-LIB_DEPS = LIB_SOURCES + [CSRC / "jpezy_device.h", CSRC / "jpezy_capi_internal.h", CSRC / "jpezy_experiment.h", CSRC / "jpezy_hostpipe.h", CSRC / "jpezy_host_codec.h", CSRC / "jpezy_entropy.h", CSRC / "jpezy_huffdec.h", CSRC / "jpezy_huffdec_core.h",
+LIB_DEPS = LIB_SOURCES + [CSRC / "jpezy_device.h", CSRC / "jpezy_f32_quad.h", CSRC / "jpezy_capi_internal.h", CSRC / "jpezy_experiment.h", CSRC / "jpezy_hostpipe.h", CSRC / "jpezy_host_codec.h", CSRC / "jpezy_entropy.h", CSRC / "jpezy_huffdec.h", CSRC / "jpezy_huffdec_core.h",
                           ROOT / "include" / "jpezy_hip.h", ROOT / "include" / "jpezy_constants.h"]
 CLI = {"jpezy_encode": CSRC / "host" / "encode_main.cpp", "jpezy_decode": CSRC / "host" / "decode_main.cpp"}
 

@@ -115,7 +115,7 @@ hipError_t launch_fdct_quant(const EncParams& p, bool gray, bool force_exact, hi
 // coefficient through the reference-order chain, 2 every coefficient through the FP64 second level, 3 every quad
 // through the per-lane evaluator of the queue-overflow case.
 hipError_t launch_fdct_quant_f32(const EncParams& p, bool gray, int force, hipStream_t stream);
-// variant 2: the same arithmetic in persistent workgroups with LDS-DMA loader waves (jpezy_kernels_f32.hip); frames whose rows do
+// variant 2: the same arithmetic in persistent workgroups with LDS-DMA loader waves (jpezy_kernels_f32_ps.hip); frames whose rows do
 // not divide into groups of four quads, or unaligned planes, go to variant 1's launch.  n_cus: compute units of the device.
 hipError_t launch_fdct_quant_f32_ps(const EncParams& p, bool gray, int force, int n_cus, hipStream_t stream);
 bool fdct_quant_f32_ps_applies(const EncParams& p);

@@ -24,7 +24,7 @@ K1, K2, K3, K4, K5, K6, K7 = (cosk(k) for k in range(1, 8))
 
 
 def fdct8f(x):
-    """x: [..., 8] float32 -> [..., 8]; mirrors f32::fdct8p of jpezy_kernels_f32.hip operation by operation (the kernel
+    """x: [..., 8] float32 -> [..., 8]; mirrors f32::fdct8p of jpezy_f32_quad.h operation by operation (the kernel
     computes the pairs (s_k, d_k), (e0, e2), (e1, e3), (X0, X4), (X2, X6), (X1, X3), (X5, X7) with one packed instruction per
     line below and pair: same operands, same order of the fused multiply-adds)"""
     x = x.astype(f32)

@@ -1,5 +1,6 @@
 """Encode variant 2 on the GPU: variant 1's arithmetic in persistent workgroups with LDS-DMA loader waves
-(jpezy_kernels_f32.hip, fdct_quant_f32_ps_kernel).  Same bar as every encode test: the coefficients are the oracle's, bit
+(jpezy_kernels_f32_ps.hip: fdct_quant_f32_ps_kernel, and variant 3, fdct_quant_f32_ps2_kernel: 16 compute waves per CU that
+prefetch their next quad into registers).  Same bar as every encode test: the coefficients are the oracle's, bit
 for bit, at every force_exact level.  What is specific to the persistent form is its hand-off machinery, so the cases
 are chosen by the SHAPE OF THE WORK rather than by pixel content:
 

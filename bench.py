@@ -957,8 +957,8 @@ def run_rank(args):
         metric = {"encode": "Mpixels/s encode (FDCT+quant)", "decode": "Mpixels/s decode (dequant+IDCT)",
                   "encode+entropy": "Mpixels/s encode (FDCT+quant + GPU Huffman stage)",
                   "entropy+decode": "Mpixels/s decode (GPU Huffman decoder + dequant+IDCT)"}[direction]
-        kernel = {None: "f32::fdct_quant_f32_kernel", 1: "f32::fdct_quant_f32_kernel",
-                  0: "fdct_quant_kernel"}[args.variant] if direction.startswith("encode") else "dequant_idct_kernel"
+        kernel = {None: "f32::fdct_quant_f32_kernel", 1: "f32::fdct_quant_f32_kernel", 0: "fdct_quant_kernel",
+                  2: "f32::fdct_quant_f32_ps_kernel", 3: "f32::fdct_quant_f32_ps2_kernel"}[args.variant] if direction.startswith("encode") else "dequant_idct_kernel"
         out = {
             "metric": metric,
             "value": round(total_px / elapsed / 1e6, 2),
@@ -1049,7 +1049,7 @@ def parse_args(argv=None):
                     "(each repetition then is `W warm-up steps, K timed steps`, as the first one is); 0: once, before the first")
     ap.add_argument("--workload", default="encode4096", choices=sorted(WORKLOADS))
     ap.add_argument("--ring", type=int, default=0, help="distinct batches in the ring (0 = enough to exceed 512 MiB)")
-    ap.add_argument("--variant", type=int, default=None, help="encode kernel variant (0 FP64 butterflies, 1 packed-FP32 first level [default])")
+    ap.add_argument("--variant", type=int, default=None, help="encode kernel variant (0 FP64 butterflies, 1 packed-FP32 first level, one quad per wave [default], 2 / 3 the same arithmetic in persistent workgroups: loader waves + LDS ring / register prefetch)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-native-multi", action="store_true",
                     help="default workload: skip the native_multi_gpu object (jpezy_encode_batch_multi timed by rank 0 after everything else)")

@@ -213,6 +213,8 @@ try {
     J.plane = (size_t)W * H;
     J.cpf = jpezy_coeff_count(W, H, gray);
     J.dev_stride = (jpezy_jpeg_bound(W, H) + 15) & ~(size_t)15;
+    if (out->jpg)
+        for (int f = 0; f < n_frames; ++f) out->jpg_sizes[f] = 0;       // (a shard that fails leaves its frames at 0, never at garbage)
     std::vector<Worker> workers((size_t)n_dev);
     for (int i = 0; i < n_dev; ++i) {
         workers[(size_t)i].index = i;

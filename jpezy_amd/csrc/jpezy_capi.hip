@@ -83,6 +83,19 @@ jpezy_ctx* jpezy_ctx_create(int device)
             const int dct = (int)((double)sum * cu * cv / 4);          // int(sum * cu * cv / 4), no contraction (build flag)
             h.dcq[t][sum + 8192] = (signed char)(dct / kQt[t][0]);
         }
+    // the table-free form of the same value (f32::dc_formula, persistent encode kernels): usable only if it reproduces the table for
+    // every sum with these constants -- evaluated here with the kernel's own FP32 operations
+    for (int t = 0; t < 2; ++t) {
+        const float rq = 1.0f / (float)kQt[t][0], bias = 0.5f / (float)kQt[t][0];
+        bool ok = true;
+        for (int sum = -8192; sum <= 8192 && ok; ++sum) {
+            const float d = std::trunc(std::fmaf(std::fabs((float)sum), 0.125f, -0.125f));
+            const float q = std::trunc(std::fmaf(d, rq, bias));
+            ok = (int)std::copysign(q, (float)sum) == (int)h.dcq[t][sum + 8192];
+        }
+        c->dc_rq[t] = ok ? rq : 0.f;
+        c->dc_bias[t] = ok ? bias : 0.f;
+    }
     {
         // f32 kernel, level 1: |t_fp32 - t| <= gamma_13 * S_i * S_j * 128 * ks + 2^-23 * |t|max, S_u = sum_x |cos_u(x)|
         // (13 roundings at most on any input->output path of the two butterfly passes; ks rounded to FP32 and the
@@ -248,6 +261,7 @@ int jpezy_fdct_quant_dev(jpezy_ctx* c, const uint8_t* d_r, const uint8_t* d_g, c
     p.quads_per_row = (p.mcu_cols + 3) / 4;
     p.n_frames = n_frames;
     fast_div_setup((unsigned)p.quads_per_row, &p.qpr_magic, &p.qpr_shift);
+    for (int t = 0; t < 2; ++t) { p.dc_rq[t] = c->dc_rq[t]; p.dc_bias[t] = c->dc_bias[t]; }
     // the f32 kernel puts the frame index in grid.y (at most 65535): larger batches go out in chunks
     constexpr int kMaxFramesPerLaunch = 65535;
     for (int f0 = 0; f0 < n_frames; f0 += kMaxFramesPerLaunch) {

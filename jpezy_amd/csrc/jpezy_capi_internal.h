@@ -142,6 +142,7 @@ struct jpezy_ctx {
 #endif
     int variant = JPEZY_DEFAULT_VARIANT;   // encode kernel: 0 = FP64 butterflies, 1 = FP32 first level (default), 2 = variant 1's arithmetic in persistent workgroups
     int n_cus = 0;                 // compute units of the device (grid of the persistent kernel)
+    float dc_rq[2] = { 0, 0 }, dc_bias[2] = { 0, 0 };   // f32::dc_formula's constants; 0: the formula does not reproduce the DC table (jpezy_ctx_create)
 #ifdef JPEZY_TRACE
     unsigned long long* d_trace = nullptr;
 #endif

@@ -73,6 +73,9 @@ struct EncParams {
     unsigned ps_total_groups, ps_groups_per_frame, gpf_magic, gpf_shift;
     // variant 3: quads over all frames of the launch, fast_div by the quads of one frame
     unsigned ps_total_quads, ps_quads_per_frame, qpf_magic, qpf_shift;
+    // quantised DC without the table (f32::dc_formula): fl(1 / Q_t[0]) and 1 / (2 Q_t[0]); 0: the formula did not reproduce DeviceTables::dcq
+    // for these constants (checked for every sum at context creation) and must not be used
+    float dc_rq[2], dc_bias[2];
 #ifdef JPEZY_TRACE
     unsigned long long* trace;       // development builds only (tools/profile/wave_trace.py): 4 words per wave
 #endif

@@ -303,6 +303,7 @@ struct PsTables {
     double qinv[2][64];       // DeviceTables::qinv
     int qt[2][64];            // DeviceTables::qt
     unsigned char zzinv[64];  // c_zzinv
+    F32Column f32col[2][8];   // DeviceTables::f32col (JPEZY_PS_CONSTS_LDS: the lane's quantiser records are read from here per quad)
 };
 
 template <int FORCE, bool PS>
@@ -356,6 +357,19 @@ __device__ __forceinline__ int dc_lookup(float sum, const signed char* dcq)
     // unsigned index keeps the lookup a scalar-base + 32-bit-offset load
     const unsigned si = (unsigned)(__builtin_amdgcn_fmed3f(sum, -8192.f, 8192.f) + 8192.f);
     return dcq[si];
+}
+
+// The same value without a table (persistent kernel, JPEZY_PS_DC_FORMULA): with the shipped constants S * S = 0.4999999999999999 puts
+// int(((sum * S) * S) / 4) at (|sum| - 1) >> 3 for every sum != 0 (0 for sum = 0), and the C division by Q truncates toward zero:
+// q = sign(sum) * (((|sum| - 1) >> 3) / Q).  In FP32, all exact but the division: d = trunc(|sum| / 8 - 1 / 8) (|sum| = 0 gives -0.125,
+// truncated to 0), q = trunc(d * rq + bias) with rq = fl(1 / Q), bias = 1 / (2 Q): d <= 1023 puts d * rq within 6e-5 of d / Q, whose
+// fractional part is a multiple of 1 / Q.  jpezy_capi.hip evaluates exactly these operations for every sum in [-8192, 8192] against
+// DeviceTables::dcq at context creation and only then lets the kernel use them (EncParams::dc_rq[t] != 0).
+__device__ __forceinline__ int dc_formula(float sum, float rq, float bias)
+{
+    const float d = __builtin_truncf(FMAF(__builtin_fabsf(sum), 0.125f, -0.125f));
+    const float q = __builtin_truncf(FMAF(d, rq, bias));
+    return (int)__builtin_copysignf(q, sum);
 }
 
 // Quantise one block column and stage it in zig-zag order.  F: the column pass' four output pairs (order pair_row);
@@ -503,8 +517,17 @@ struct QuadTrace { unsigned long long t2; unsigned long long ph[8]; };
 // ([2][16385] bytes) and the cosine table in LDS; null in the one-quad kernel, which reads all three from global memory.
 // The scheduler fences between the phases of a quad keep the one-quad kernel at 79 VGPRs (6 waves per SIMD); the persistent kernel has
 // 128 registers per lane anyway (16 waves per CU) and may let the scheduler overlap the phases (JPEZY_PS_FENCES=0).
+#ifndef JPEZY_PS_CONSTS_LDS
+#define JPEZY_PS_CONSTS_LDS 0  // 1: the persistent kernels read the lane's quantiser records per quad from an LDS copy of the tables instead of keeping them in 22 registers
+#endif
+#ifndef JPEZY_PS_DC_FORMULA
+#define JPEZY_PS_DC_FORMULA 1  // 1: the persistent kernels compute the quantised DC (dc_formula, host-verified) instead of looking it up in a 32 KB table in LDS
+#endif
 #ifndef JPEZY_PS_DCQ_LDS
-#define JPEZY_PS_DCQ_LDS 1     // 0: the quantised-DC tables stay in global memory (32 KB of LDS more for ring slots; the loop then holds three byte loads)
+#define JPEZY_PS_DCQ_LDS (!JPEZY_PS_DC_FORMULA)   // without the formula: 1 = the quantised-DC tables copied to LDS, 0 = they stay in global memory (the loop then holds three byte loads)
+#endif
+#ifndef JPEZY_PS_HOOK_LATE
+#define JPEZY_PS_HOOK_LATE 0   // 1: after_pixels() runs behind the luma quantiser (step 3+4) instead of behind step 2b: the next quad's pixel registers are not live across the most register-hungry phase
 #endif
 #ifndef JPEZY_PS_FENCES
 #define JPEZY_PS_FENCES 1
@@ -624,7 +647,7 @@ __device__ __forceinline__ void encode_quad_compute(const EncParams& p, const ui
         }
     }
     PHASE_FENCE();
-    after_pixels();
+    if (!JPEZY_PS_HOOK_LATE) after_pixels();
     PROBE_ALL();
     PHASE_STAMP(3);
     wave_sync();
@@ -642,32 +665,35 @@ __device__ __forceinline__ void encode_quad_compute(const EncParams& p, const ui
     char* stage = reinterpret_cast<char*>(lds) + CT_BYTES;
     const int bx = cq >> 3;
     char* sbase = stage + (m * BPM + bx) * STG_BLK;   // this lane's first block (m, bx); the others are immediates away
-    const F32Column* lcol = &tab->f32col[0][ju];                       // (one-quad kernel: read where they are used, luma now, chroma later)
-    const uint32_t zz_lo = PS ? pre->zz_lo : lcol->zz_lo, zz_hi = PS ? pre->zz_hi : lcol->zz_hi;
+    constexpr bool PRE = PS && !JPEZY_PS_CONSTS_LDS;                   // the records are in registers (pre); else read where they are used, luma now, chroma later:
+    const F32Column* lcol = PS && JPEZY_PS_CONSTS_LDS ? &pst->f32col[0][ju] : &tab->f32col[0][ju];   // from LDS / from global memory (one-quad kernel)
+    const uint32_t zz_lo = PRE ? pre->zz_lo : lcol->zz_lo, zz_hi = PRE ? pre->zz_hi : lcol->zz_hi;
+    constexpr bool DCF = PS && JPEZY_PS_DC_FORMULA;
     const signed char* dcq_l = PS && JPEZY_PS_DCQ_LDS ? dcq_lds : p.dcq_luma;
     const signed char* dcq_c = PS && JPEZY_PS_DCQ_LDS ? dcq_lds + 16385 : p.dcq_chroma;
     {
         f2 ks[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) ks[k] = PS ? pre->ks_l[k] : f2{ lcol->ks[2 * k], lcol->ks[2 * k + 1] };
-        const f2 dd = PS ? pre->dd_l : f2{ lcol->delta1[0], lcol->delta1[1] };
-        const float th = PS ? pre->th_l : lcol->th;
+        for (int k = 0; k < 4; ++k) ks[k] = PRE ? pre->ks_l[k] : f2{ lcol->ks[2 * k], lcol->ks[2 * k + 1] };
+        const f2 dd = PRE ? pre->dd_l : f2{ lcol->delta1[0], lcol->delta1[1] };
+        const float th = PRE ? pre->th_l : lcol->th;
         {
             f2 F[4];
             fdct8p(TP, F, kc);
-            const int dc_top = dc_lookup(F[0].x, dcq_l);
+            const int dc_top = DCF ? dc_formula(F[0].x, p.dc_rq[0], p.dc_bias[0]) : dc_lookup(F[0].x, dcq_l);
             quant_block_column(F, ks, dd, th, j, dc_top, live, sbase, zz_lo, zz_hi, 0, m * BPM + bx, queue, FORCE != 0 DUMP_ARG);
         }
         PHASE_FENCE();
         {
             f2 F[4];
             fdct8p(BT, F, kc);
-            const int dc_bot = dc_lookup(F[0].x, dcq_l);
+            const int dc_bot = DCF ? dc_formula(F[0].x, p.dc_rq[0], p.dc_bias[0]) : dc_lookup(F[0].x, dcq_l);
             quant_block_column(F, ks, dd, th, j, dc_bot, live, sbase, zz_lo, zz_hi, 2 * STG_BLK, m * BPM + 2 + bx, queue, FORCE != 0 DUMP_ARG);
         }
     }
 
     PHASE_FENCE();
+    if (JPEZY_PS_HOOK_LATE) after_pixels();
     PROBE_ALL();
     PHASE_STAMP(5);
     // ---- 5. chroma row pass, transpose, column pass ----
@@ -685,13 +711,13 @@ __device__ __forceinline__ void encode_quad_compute(const EncParams& p, const ui
             f2 col[4];
             lds_column<C_PITCH>(ldsf + m * C_MCU + (cq >> 3) * C_COMP + (cq & 7), col);
             fdct8p(col, Fc, kc);
-            dc_c = dc_lookup(Fc[0].x, dcq_c);
+            dc_c = DCF ? dc_formula(Fc[0].x, p.dc_rq[1], p.dc_bias[1]) : dc_lookup(Fc[0].x, dcq_c);
         }
         f2 ks[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) ks[k] = PS ? pre->ks_c[k] : f2{ lcol[8].ks[2 * k], lcol[8].ks[2 * k + 1] };
-        const f2 dd = PS ? pre->dd_c : f2{ lcol[8].delta1[0], lcol[8].delta1[1] };
-        quant_block_column(Fc, ks, dd, PS ? pre->th_c : lcol[8].th, j, dc_c, live, sbase, zz_lo, zz_hi, 4 * STG_BLK, m * BPM + 4 + bx, queue, FORCE != 0 DUMP_ARG);
+        for (int k = 0; k < 4; ++k) ks[k] = PRE ? pre->ks_c[k] : f2{ lcol[8].ks[2 * k], lcol[8].ks[2 * k + 1] };
+        const f2 dd = PRE ? pre->dd_c : f2{ lcol[8].delta1[0], lcol[8].delta1[1] };
+        quant_block_column(Fc, ks, dd, PRE ? pre->th_c : lcol[8].th, j, dc_c, live, sbase, zz_lo, zz_hi, 4 * STG_BLK, m * BPM + 4 + bx, queue, FORCE != 0 DUMP_ARG);
     }
     wave_sync();
     PROBE_ALL();

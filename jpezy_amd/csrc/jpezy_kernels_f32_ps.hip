@@ -106,6 +106,8 @@ __global__ __launch_bounds__(64 * PS_WAVES, (JPEZY_PS_WG_PER_CU * PS_WAVES + 3) 
             (&pst.qinv[0][0])[threadIdx.x] = (&p.tab->qinv[0][0])[threadIdx.x];
             (&pst.qt[0][0])[threadIdx.x] = (&p.tab->qt[0][0])[threadIdx.x];
         }
+        if (JPEZY_PS_CONSTS_LDS && threadIdx.x < sizeof(pst.f32col) / 16)
+            reinterpret_cast<uint4*>(&pst.f32col[0][0])[threadIdx.x] = reinterpret_cast<const uint4*>(&p.tab->f32col[0][0])[threadIdx.x];
     }
     __syncthreads();
 
@@ -272,12 +274,15 @@ __global__ __launch_bounds__(64 * PS_WAVES, (JPEZY_PS_WG_PER_CU * PS_WAVES + 3) 
 #define JPEZY_PS2_WAVES 16
 #endif
 constexpr int PS2_WAVES = JPEZY_PS2_WAVES;      // waves per workgroup = quads per run (quad_of below)
-static_assert(PS2_WAVES * WAVE_LDS_DWORDS * 4 + (2 * 16385 + 15) / 16 * 16 + (int)sizeof(PsTables) <= 160 * 1024, "LDS per CU");
+// workgroups per CU: two when they are small enough (12 waves: six always-computing waves per SIMD -- which takes the DC formula instead of
+// the 32 KB table, the quantiser records read from LDS instead of kept in 22 registers, and a kernel within 80 VGPRs)
+constexpr int PS2_WG_PER_CU = PS2_WAVES <= 12 ? 2 : 1;
+static_assert(PS2_WG_PER_CU * (PS2_WAVES * WAVE_LDS_DWORDS * 4 + (JPEZY_PS_DC_FORMULA ? 16 : (2 * 16385 + 15) / 16 * 16) + (int)sizeof(PsTables) + 16) <= 160 * 1024, "LDS per CU");
 
 template <bool GRAY, int FORCE>
-__global__ __launch_bounds__(64 * PS2_WAVES) void fdct_quant_f32_ps2_kernel(EncParams p)
+__global__ __launch_bounds__(64 * PS2_WAVES, (PS2_WG_PER_CU * PS2_WAVES + 3) / 4) void fdct_quant_f32_ps2_kernel(EncParams p)
 {
-    constexpr int DCQ_BYTES = (2 * 16385 + 15) / 16 * 16;
+    constexpr int DCQ_BYTES = JPEZY_PS_DC_FORMULA ? 16 : (2 * 16385 + 15) / 16 * 16;
     __shared__ __attribute__((aligned(16))) uint32_t slices[PS2_WAVES][WAVE_LDS_DWORDS];
     __shared__ __attribute__((aligned(16))) signed char dcq_s[DCQ_BYTES];
     __shared__ PsTables pst;
@@ -320,7 +325,8 @@ __global__ __launch_bounds__(64 * PS2_WAVES) void fdct_quant_f32_ps2_kernel(EncP
     {
         const uint4* src = reinterpret_cast<const uint4*>(p.dcq_luma);           // &tab->dcq[0][0]: 16-byte aligned, [2][16385] contiguous
         uint4* dst = reinterpret_cast<uint4*>(dcq_s);
-        for (unsigned k = threadIdx.x; k < DCQ_BYTES / 16; k += 64 * PS2_WAVES) dst[k] = src[k];
+        if (!JPEZY_PS_DC_FORMULA)
+            for (unsigned k = threadIdx.x; k < DCQ_BYTES / 16; k += 64 * PS2_WAVES) dst[k] = src[k];
         if (threadIdx.x < 64) {
             pst.cos[threadIdx.x] = c_cos[threadIdx.x];
             pst.zzinv[threadIdx.x] = c_zzinv[threadIdx.x];
@@ -329,13 +335,18 @@ __global__ __launch_bounds__(64 * PS2_WAVES) void fdct_quant_f32_ps2_kernel(EncP
             (&pst.qinv[0][0])[threadIdx.x] = (&p.tab->qinv[0][0])[threadIdx.x];
             (&pst.qt[0][0])[threadIdx.x] = (&p.tab->qt[0][0])[threadIdx.x];
         }
+        if (JPEZY_PS_CONSTS_LDS && threadIdx.x < sizeof(pst.f32col) / 16)
+            reinterpret_cast<uint4*>(&pst.f32col[0][0])[threadIdx.x] = reinterpret_cast<const uint4*>(&p.tab->f32col[0][0])[threadIdx.x];
     }
     uint32_t* lds = slices[wave];
-    LaneConsts lc = load_lane_consts(p.tab, lane0);
+    LaneConsts lc = {};
+    if (!JPEZY_PS_CONSTS_LDS) lc = load_lane_consts(p.tab, lane0);
     __syncthreads();                                // (waits for every load above: vmcnt(0) in front of the barrier)
+    if (!JPEZY_PS_CONSTS_LDS) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) asm volatile("" : "+v"(lc.ks_l[k]), "+v"(lc.ks_c[k]));
-    asm volatile("" : "+v"(lc.dd_l), "+v"(lc.dd_c), "+v"(lc.th_l), "+v"(lc.th_c), "+v"(lc.zz_lo), "+v"(lc.zz_hi));
+        for (int k = 0; k < 4; ++k) asm volatile("" : "+v"(lc.ks_l[k]), "+v"(lc.ks_c[k]));
+        asm volatile("" : "+v"(lc.dd_l), "+v"(lc.dd_c), "+v"(lc.th_l), "+v"(lc.th_c), "+v"(lc.zz_lo), "+v"(lc.zz_hi));
+    }
 
 #ifndef JPEZY_PS2_STAGGER
 #define JPEZY_PS2_STAGGER 0       // s_sleep units (64 cycles)
@@ -428,6 +439,7 @@ bool fdct_quant_f32_ps_applies(const EncParams& p)
 hipError_t launch_fdct_quant_f32_ps(const EncParams& p0, bool gray, int force, int n_cus, hipStream_t stream)
 {
     if (!fdct_quant_f32_ps_applies(p0)) return launch_fdct_quant_f32(p0, gray, force, stream);
+    if (JPEZY_PS_DC_FORMULA && (p0.dc_rq[0] == 0.f || p0.dc_rq[1] == 0.f)) return launch_fdct_quant_f32(p0, gray, force, stream);   // formula not valid for these constants
     EncParams p = p0;
     p.groups_per_row = p.quads_per_row / 4;
     p.ps_groups_per_frame = (unsigned)p.mcu_rows * (unsigned)p.groups_per_row;
@@ -463,7 +475,8 @@ hipError_t launch_fdct_quant_f32_ps2(const EncParams& p0, bool gray, int force, 
     p.ps_quads_per_frame = (unsigned)p.mcu_rows * (unsigned)p.quads_per_row;
     p.ps_total_quads = (unsigned)total;
     fast_div_setup(p.ps_quads_per_frame, &p.qpf_magic, &p.qpf_shift);
-    const unsigned cus = (unsigned)(n_cus > 0 ? n_cus : 256);
+    if (JPEZY_PS_DC_FORMULA && (p.dc_rq[0] == 0.f || p.dc_rq[1] == 0.f)) return launch_fdct_quant_f32(p0, gray, force, stream);   // formula not valid for these constants
+    const unsigned cus = (unsigned)(n_cus > 0 ? n_cus : 256) * f32::PS2_WG_PER_CU;
     const unsigned need = (p.ps_total_quads + f32::PS2_WAVES - 1) / f32::PS2_WAVES;
     const unsigned nwg = need < cus ? need : cus;
     if (gray) enc_f32_ps2_launch2<true>(p, force, nwg, stream); else enc_f32_ps2_launch2<false>(p, force, nwg, stream);

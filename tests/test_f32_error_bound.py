@@ -150,3 +150,20 @@ def test_colour_level1_guard_band_exhaustive():
             assert worst[name] <= bound, (name, worst[name])
             assert int(flag.sum()) == int(integral.sum()), name        # the band catches nothing else
     assert flagged["y"] == 16777216 // 1000 + 1 or 16000 < flagged["y"] < 17500, flagged
+
+
+def test_dc_closed_form_reproduces_the_exact_table():
+    """f32::dc_formula (persistent encode kernels): sign(S) * (((|S| - 1) >> 3) / Q) in the kernel's own FP32 operations against
+    int(((S * s) * s) / 4) / Q evaluated in binary64 with C's truncating division, for every block sum and both DC quantisers.
+    (jpezy_ctx_create repeats this check against the device table and disables the formula if it ever fails.)"""
+    s = float.fromhex("0x1.6a09e667f3bccp-1")
+    S = np.arange(-8192, 8193)
+    for Q in (16, 17):
+        dct = np.trunc(((S * s) * s) / 4).astype(np.int64)
+        want = np.sign(dct) * (np.abs(dct) // Q)
+        a = np.abs(S).astype(np.float32)
+        d = np.trunc(np.float32(a * np.float32(0.125) - np.float32(0.125)))        # fma of exact quantities: exact
+        rq, bias = np.float32(1.0) / np.float32(Q), np.float32(0.5) / np.float32(Q)
+        u = (d.astype(np.float64) * np.float64(rq) + np.float64(bias)).astype(np.float32)   # one rounding, as v_fma_f32
+        got = np.copysign(np.trunc(u), S).astype(np.int64)
+        assert np.array_equal(got, want), Q

@@ -520,6 +520,10 @@ struct QuadTrace { unsigned long long t2; unsigned long long ph[8]; };
 #ifndef JPEZY_PS_CONSTS_LDS
 #define JPEZY_PS_CONSTS_LDS 0  // 1: the persistent kernels read the lane's quantiser records per quad from an LDS copy of the tables instead of keeping them in 22 registers
 #endif
+#ifndef JPEZY_DC_FORMULA_ONEQUAD
+#define JPEZY_DC_FORMULA_ONEQUAD 2   // the one-quad kernel's quantised DC: 0 = table lookup (three byte loads per quad), 1 = dc_formula unchecked (A/B only),
+                                     // 2 = dc_formula where the host check allowed it (EncParams::dc_rq != 0), else the table.  26.45 against 26.79 us (five rounds)
+#endif
 #ifndef JPEZY_PS_DC_FORMULA
 #define JPEZY_PS_DC_FORMULA 1  // 1: the persistent kernels compute the quantised DC (dc_formula, host-verified) instead of looking it up in a 32 KB table in LDS
 #endif
@@ -668,7 +672,9 @@ __device__ __forceinline__ void encode_quad_compute(const EncParams& p, const ui
     constexpr bool PRE = PS && !JPEZY_PS_CONSTS_LDS;                   // the records are in registers (pre); else read where they are used, luma now, chroma later:
     const F32Column* lcol = PS && JPEZY_PS_CONSTS_LDS ? &pst->f32col[0][ju] : &tab->f32col[0][ju];   // from LDS / from global memory (one-quad kernel)
     const uint32_t zz_lo = PRE ? pre->zz_lo : lcol->zz_lo, zz_hi = PRE ? pre->zz_hi : lcol->zz_hi;
-    constexpr bool DCF = PS && JPEZY_PS_DC_FORMULA;
+    // persistent kernels: the formula by build switch (their launchers check its validity); one-quad kernel: by the kernel argument
+    // (dc_rq == 0: the formula does not hold for this build's constants -- the table lookup stays)
+    const bool DCF = PS ? (bool)JPEZY_PS_DC_FORMULA : (JPEZY_DC_FORMULA_ONEQUAD == 1 || (JPEZY_DC_FORMULA_ONEQUAD == 2 && p.dc_rq[0] != 0.f && p.dc_rq[1] != 0.f));
     const signed char* dcq_l = PS && JPEZY_PS_DCQ_LDS ? dcq_lds : p.dcq_luma;
     const signed char* dcq_c = PS && JPEZY_PS_DCQ_LDS ? dcq_lds + 16385 : p.dcq_chroma;
     {

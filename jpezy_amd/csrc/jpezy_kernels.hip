@@ -29,6 +29,20 @@ namespace jpezy_dev {
 
 __constant__ double c_cos[64] = JPEZY_COS_INIT;            // [u*8+x] = cos((2x+1)u*pi/16)
 __constant__ unsigned char c_zzinv[64] = JPEZY_ZZ_INV_INIT;  // natural index -> zig-zag position
+// the same table by COLUMN: c_zzcol[u] = the eight zig-zag positions of natural column u (rows v = 0..7), one byte each -- the decode kernel's
+// lane (column u) fetches its eight staging offsets with ONE 8-byte load instead of eight byte loads (JPEZY_DEC_ZZCOL)
+struct ZzCol { uint32_t lo, hi; };
+constexpr unsigned char kZzInvH[64] = JPEZY_ZZ_INV_INIT;
+constexpr ZzCol zz_col(int u)
+{
+    uint32_t lo = 0, hi = 0;
+    for (int v = 0; v < 4; ++v) { lo |= (uint32_t)kZzInvH[v * 8 + u] << (8 * v); hi |= (uint32_t)kZzInvH[(v + 4) * 8 + u] << (8 * v); }
+    return ZzCol{ lo, hi };
+}
+__constant__ ZzCol c_zzcol[8] = { zz_col(0), zz_col(1), zz_col(2), zz_col(3), zz_col(4), zz_col(5), zz_col(6), zz_col(7) };
+#ifndef JPEZY_DEC_ZZCOL
+#define JPEZY_DEC_ZZCOL 1
+#endif
 
 __device__ __forceinline__ unsigned fast_div(unsigned n, unsigned magic, unsigned shift)   // see fast_div_setup
 {
@@ -629,10 +643,17 @@ __global__ __launch_bounds__(64 * WPB, GRAY ? JPEZY_DEC_WAVES_GRAY : JPEZY_DEC_W
     double dq[TOL ? 1 : 8];
     float dqf[TOL ? 8 : 1];
     unsigned char zp[8];
+#if JPEZY_DEC_ZZCOL
+    const ZzCol zc = c_zzcol[u];
+#endif
 #pragma unroll
     for (int v = 0; v < 8; ++v) {
         if (TOL) dqf[v] = p.dqscale_f[u * 8 + v]; else dq[v] = p.dqscale[(0 * 8 + u) * 8 + v];
+#if JPEZY_DEC_ZZCOL
+        zp[v] = (unsigned char)(((v < 4 ? zc.lo : zc.hi) >> (8 * (v & 3))) & 0xFFu);
+#else
         zp[v] = c_zzinv[v * 8 + u];
+#endif
     }
 
     // ---- 1. coalesced load of the quad's 3 KB of coefficients into the staging area ----

@@ -100,3 +100,20 @@ def test_traffic_json_is_what_the_cited_summaries_say():
     dec = have["decode4096"]
     assert abs(2 * dec["fetch_size_kib"] * 1024 / (b.algorithmic_bytes(4096, 4096, False, "decode") / 2) - 1) < 0.02
     assert 0.98 < dec["write_size_kib"] * 1024 / (3 * 4096 * 4096) < 1.40
+
+
+def test_other_workloads_and_native_multi_are_part_of_the_default_line():
+    """the default command measures BASELINE configs[2] and [4] and the native multi-GPU entry after the
+    timed region (objects of their own, never part of `value`); the run itself needs a GPU (tests/test_gpu_parity.py), here: the
+    pieces exist, name real workloads, and can be switched off for profiling passes."""
+    import inspect
+    b = _bench()
+    src = inspect.getsource(b.measure_other_workloads)
+    for name in ("decode4096", "gray8k", "gray8k_decode"):
+        assert name in b.WORKLOADS and f'"{name}"' in src
+    assert set(b.OTHER_KERNELS) == {"encode", "decode"}
+    assert "jpezy_encode_batch_multi" in inspect.getsource(b.measure_native_multi) or "encode_batch_multi" in inspect.getsource(b.measure_native_multi)
+    args = b.parse_args(["--no-others", "--no-native-multi"])
+    assert args.no_others and args.no_native_multi and not b.parse_args([]).no_others
+    run = inspect.getsource(b.run_rank)
+    assert 'out["other_workloads"] = others' in run and 'out["native_multi_gpu"] = native' in run

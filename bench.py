@@ -59,12 +59,15 @@ BATCH_W, BATCH_H, BATCH_FRAMES = 1920, 1080, 4096      # BASELINE configs[3]
 
 def algorithmic_bytes(W, H, gray, direction):
     """encode colour 3 B/px read + 1.5 samples x 2 B written; gray 3 + 2; decode colour
-    3 B/px of coefficients read + 3 B/px written.  Padded MCU grid for the coefficient side."""
+    3 B/px of coefficients read + 3 B/px written; decode gray 2 + 3: the kernel does not read the chroma blocks of a
+    GRAY_MODE decode (r = g = b = clamp(Y), ref decoder/jpezy_decoder.hpp:561), so they are not in the numerator either --
+    a fraction's numerator must not exceed what the launch moves (the counters say 166.2 MB for 8K).
+    Padded MCU grid for the coefficient side."""
     mc, mr = (W + 15) // 16, (H + 15) // 16
     px = W * H
     if direction.startswith("encode"):
         return 3 * px + mc * mr * (4 if gray else 6) * 128
-    return mc * mr * 6 * 128 + 3 * px
+    return mc * mr * (4 if gray else 6) * 128 + 3 * px
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -444,7 +447,7 @@ def run_batch(args, torch, dist, J, ctx, dev, rank, world, multi, comm_cpu):
 OTHER_KERNELS = {"encode": "f32::fdct_quant_f32_kernel", "decode": "dequant_idct_kernel"}
 
 
-def measure_other_workloads(torch, J, ctx, dev, steps=40, replays=3):
+def measure_other_workloads(torch, J, ctx, dev, steps=40, replays=3, copy_gbs=None):
     """Every entry: the same protocol as the headline in small -- a ring of distinct frames larger than the Infinity Cache,
     `steps` launches captured as one hipGraph, the median of `replays` replays timed with HIP events on the launch stream."""
     traffic = {}
@@ -507,7 +510,9 @@ def measure_other_workloads(torch, J, ctx, dev, steps=40, replays=3):
                         "steps": steps, "replays": replays, "kernel": OTHER_KERNELS[direction],
                         "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                      "frac": round(gbs / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": step_bytes,
-                                     "traffic": tj.get("bytes_per_launch"), "traffic_source": tj.get("source")}}
+                                     "traffic": tj.get("bytes_per_launch"), "traffic_source": tj.get("source"),
+                                     "device_copy_GBs_measured": round(copy_gbs, 1) if copy_gbs else None,
+                                     "frac_of_device_copy": round(gbs / copy_gbs, 4) if copy_gbs else None}}
             del g, pr, pg, pb, co
         except Exception as e:          # never at the cost of the headline line
             out[key] = {"error": f"{type(e).__name__}: {e}"[:300]}
@@ -520,36 +525,135 @@ def measure_other_workloads(torch, J, ctx, dev, steps=40, replays=3):
 
 
 # ------------------------------------------------------------------------------------------------------------------
-# The native multi-GPU entry of the C-ABI (jpezy_encode_batch_multi: ONE host process, a thread per device, gather by peer copies),
-# timed by rank 0 over the GPUs of the job after everything else.  Host planes in, .jpg files out in host memory: PCIe-inclusive,
-# reported beside `value`, never in it.  On a one-GPU run it also runs two shards on the one device (the multi-shard path).
+# The native multi-GPU entry of the C-ABI (jpezy_multi_create / jpezy_multi_encode: ONE host process, a lane per device -- pinned
+# staging rings, feeder / drainer threads, gather by peer copies), timed by rank 0 over the GPUs of the job after everything else.
+# Host planes in, .jpg files out in host memory: PCIe-inclusive, reported beside `value`, never in it.  The handle is created outside
+# the bracket (that is what it is for), the output buffers are touched before it, nothing but the C call is inside.  Reference for
+# the link: a pinned hipMemcpy host -> device measured in this same run.  On a one-GPU run it also runs two lanes on the one device
+# (the multi-lane path), and the round-5 one-shot shape (16 frames, handle built and torn down inside the call) beside it.
 # ------------------------------------------------------------------------------------------------------------------
-def measure_native_multi(J, ctx, n_dev, frames_per_dev=16):
+def _pinned_h2d_GBs(torch, dev, nbytes=256 << 20, reps=5):
+    h = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
+    h.fill_(7)
+    d = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    d.copy_(h, non_blocking=True)
+    torch.cuda.synchronize(dev)
+    best = 0.0
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        d.copy_(h, non_blocking=True)
+        e1.record()
+        e1.synchronize()
+        best = max(best, nbytes / (e0.elapsed_time(e1) * 1e-3) / 1e9)
+    del h, d
+    return best
+
+
+def measure_native_multi(J, ctx, n_dev, frames_per_dev=256, max_frames=1024):
+    import ctypes as C
+
     import numpy as np
+    import torch
+    from jpezy_amd import api
+    lib = api.load_library()
     W, H = BATCH_W, BATCH_H
+    plane = W * H
     rng = np.random.default_rng(0x6A70)
-    base = [rng.integers(0, 256, (4, W * H), dtype=np.uint8) for _ in range(3)]          # four distinct frames, repeated
-    res = {"workload": f"{W}x{H} frames, host planes -> .jpg files in host memory (PCIe inclusive), jpezy_encode_batch_multi",
-           "entry": "include/jpezy_hip.h: jpezy_encode_batch_multi (one host process, one thread + two contexts per device)"}
-    layouts = [("devices_%d" % n_dev, list(range(n_dev)))]
-    if n_dev == 1:
-        layouts.append(("two_shards_on_one_device", [0, 0]))
-    else:
-        layouts.insert(0, ("devices_1", [0]))
+    base = [rng.integers(0, 256, (4, plane), dtype=np.uint8) for _ in range(3)]          # four distinct frames, repeated
+    stride = 1 << 20                                                                      # a 1080p random-pixel frame codes to ~0.66 MB
+    comment = b"Encoded by jpezy"
+    pcie = _pinned_h2d_GBs(torch, torch.device("cuda", 0))
+    res = {"workload": f"{W}x{H} frames, host planes -> .jpg files in host memory (PCIe inclusive), jpezy_multi_encode on a handle created "
+                       "outside the bracket; planes are pageable numpy memory (staged through the lanes' pinned rings) unless a layout says pinned",
+           "entry": "include/jpezy_hip.h: jpezy_multi_create / jpezy_multi_encode (one host process; per device a context, a ring of 6 pinned + "
+                    "device slots, 4 feeder and 2 drainer threads)",
+           "pcie_h2d_GBs_pinned_hipMemcpy": round(pcie, 1),
+           "never_run_on_two_different_gpus_by_the_builder": True}
     ref = ctx.encode_jpeg(base[0][1], base[1][1], base[2][1], W, H)
-    for name, devs in layouts:
-        F = frames_per_dev * len(devs)
-        planes = [np.ascontiguousarray(np.tile(b, (F // 4 + 1, 1))[:F]).reshape(-1) for b in base]
+
+    def planes_for(F):
+        return [np.ascontiguousarray(np.tile(b, (F // 4 + 1, 1))[:F]).reshape(-1) for b in base]
+
+    def run(name, devs, F, planes, chunk_frames=0, reps=3):
+        jpg = np.zeros(F * stride, dtype=np.uint8)                                        # touched: no first-touch faults inside the bracket
+        sizes = (C.c_longlong * F)()
+        out = api.MultiOut()
+        out.jpg, out.jpg_stride, out.jpg_sizes, out.on_root_device = jpg.ctypes.data, stride, sizes, 0
+        ptrs = [C.c_void_p(p.data_ptr()) if hasattr(p, "data_ptr") else api._np_ptr(p) for p in planes]
+        darr = (C.c_int * len(devs))(*devs)
+        h = lib.jpezy_multi_create(darr, len(devs), W, H, 0, chunk_frames)
+        if not h:
+            raise RuntimeError(lib.jpezy_hip_last_error().decode(errors="replace"))
         try:
-            J.encode_batch_multi(devs, *planes, W, H, F, chunk_frames=8)              # contexts, buffers, first-touch
-            t0 = time.perf_counter()
-            _, jpg = J.encode_batch_multi(devs, *planes, W, H, F, chunk_frames=8)
-            dt = time.perf_counter() - t0
-            ok = all(isinstance(j, bytes) for j in jpg) and jpg[1] == ref and jpg[F - 3] == ref     # frames 1 and F-3 are copies of base frame 1
-            res[name] = {"devices": devs, "frames": F, "ms": round(dt * 1e3, 2), "Mpixels_per_s": round(F * W * H / dt / 1e6, 1),
-                         "jpg_bytes": int(sum(len(j) for j in jpg)), "equal_to_single_frame_entry": bool(ok)}
+            times = []
+            for i in range(reps + 1):                                                     # first call: output-dependent buffers, first touch
+                t0 = time.perf_counter()
+                rc = lib.jpezy_multi_encode(h, *ptrs, F, comment, C.byref(out))
+                dt = time.perf_counter() - t0
+                if rc != 0:
+                    raise RuntimeError(lib.jpezy_hip_last_error().decode(errors="replace"))
+                if i:
+                    times.append(dt)
+            dt = statistics.median(times)
+            st = (api.MultiLaneStats * len(devs))()
+            lib.jpezy_multi_last_stats(h, st, len(devs))
+            chunk = lib.jpezy_multi_chunk_frames(h)
+        finally:
+            lib.jpezy_multi_destroy(h)
+        ok = all(sizes[f] == len(ref) and jpg[f * stride: f * stride + sizes[f]].tobytes() == ref for f in (1, F - 3))   # copies of base frame 1
+        up = 3 * plane * F
+        per_dev_gbs = up / len(set(devs)) / dt / 1e9
+        res[name] = {"devices": devs, "frames": F, "chunk_frames": chunk, "calls_timed": reps, "ms": round(dt * 1e3, 2),
+                     "ms_min_max": [round(min(times) * 1e3, 2), round(max(times) * 1e3, 2)],
+                     "Mpixels_per_s": round(F * plane / dt / 1e6, 1), "GBs_h2d": round(up / dt / 1e9, 2),
+                     "GBs_h2d_per_device": round(per_dev_gbs, 2), "frac_of_pcie": round(per_dev_gbs / pcie, 3),
+                     "jpg_bytes": int(sum(sizes[f] for f in range(F))),
+                     "lanes": [{"device": s_.device, "frames": s_.frames, "wall_ms": round(s_.wall_ms, 2), "kernel_ms": round(s_.kernel_ms, 2),
+                                "staged": s_.staged} for s_ in st],
+                     "equal_to_single_frame_entry": bool(ok)}
+
+    F1 = min(frames_per_dev, max_frames)
+    Fn = min(frames_per_dev * n_dev, max_frames)
+    layouts = []
+    if n_dev > 1:
+        layouts.append(("devices_1", [0], F1))
+    layouts.append(("devices_%d" % n_dev, list(range(n_dev)), Fn))
+    if n_dev == 1:
+        layouts.append(("two_lanes_on_one_device", [0, 0], F1))
+    cache = {}
+    for name, devs, F in layouts:
+        try:
+            if F not in cache:
+                cache.clear()
+                cache[F] = planes_for(F)
+            run(name, devs, F, cache[F])
         except Exception as e:
             res[name] = {"devices": devs, "error": f"{type(e).__name__}: {e}"[:300]}
+    # the same with planes the caller has pinned itself: no staging copy, the DMA engines read the caller's memory
+    try:
+        F = Fn
+        if F not in cache:
+            cache.clear()
+            cache[F] = planes_for(F)
+        pinned = [torch.from_numpy(p_).pin_memory() for p_ in cache[F]]
+        run("devices_%d_caller_pinned_planes" % n_dev, list(range(n_dev)), F, pinned)
+        del pinned
+    except Exception as e:
+        res["devices_%d_caller_pinned_planes" % n_dev] = {"error": f"{type(e).__name__}: {e}"[:300]}
+    # round 5's measurement for comparison: 16 frames, one-shot entry (handle, contexts, rings created and destroyed inside the call)
+    try:
+        F = 16
+        planes = planes_for(F)
+        J.encode_batch_multi([0], *planes, W, H, F, chunk_frames=8)
+        t0 = time.perf_counter()
+        _, jpgs = J.encode_batch_multi([0], *planes, W, H, F, chunk_frames=8)
+        dt = time.perf_counter() - t0
+        res["one_shot_16_frames"] = {"devices": [0], "frames": F, "ms": round(dt * 1e3, 2), "Mpixels_per_s": round(F * plane / dt / 1e6, 1),
+                                     "GBs_h2d": round(3 * plane * F / dt / 1e9, 2), "equal_to_single_frame_entry": bool(jpgs[1] == ref),
+                                     "note": "jpezy_encode_batch_multi incl. handle creation + Python-side result slicing, as round 5 timed it"}
+    except Exception as e:
+        res["one_shot_16_frames"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     return res
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -926,7 +1030,7 @@ def run_rank(args):
     others = None
     if rank == 0 and world == 1 and args.workload == "encode4096" and not args.no_others and args.variant in (None, 1) and not args.tolerant:
         try:
-            others = measure_other_workloads(torch, J, ctx, dev)
+            others = measure_other_workloads(torch, J, ctx, dev, copy_gbs=copy_gbs)
         except Exception as e:
             others = {"error": f"{type(e).__name__}: {e}"[:300]}
 

@@ -235,11 +235,19 @@ long jpezy_encode_jpeg(jpezy_ctx* ctx, const uint8_t* r, const uint8_t* g, const
  * jpezy_shard_range: the partition rule of every batch entry point and of jpezy_amd/sharding.py -- shard k of n_shards owns the
  * contiguous units [*first, *first + *count) of n_units; counts differ by at most one, the earlier shards take the extra.
  *
- * jpezy_encode_batch_multi: encoder::encode (encoder/jpezy_encoder.hpp:38-77) for n_frames independent frames of one size, i.e. the
- * loop a caller of the reference runs over encoder objects, spread over the n_dev GPUs devices[0..n_dev) of this node; devices[0] is
- * the ROOT (the calling thread drives it, one more host thread per further device).  r, g, b: host memory, n_frames consecutive W*H
- * planes each.  Device k encodes shard k in chunks of chunk_frames (<= 0: 16) on two alternating streams with a context each, so that
- * a chunk's results travel while the next chunk's kernels run.  out says what is wanted and where:
+ * jpezy_multi_create / jpezy_multi_encode / jpezy_multi_destroy: encoder::encode (encoder/jpezy_encoder.hpp:38-77) for n_frames
+ * independent frames of one size, i.e. the loop a caller of the reference runs over encoder objects, spread over the n_dev GPUs
+ * devices[0..n_dev) of this node; devices[0] is the ROOT (the calling thread drives it, one more host thread per further device).
+ * The HANDLE owns, per entry of devices (a "lane"): a context, an upload stream, download streams and a ring of six slots, each a pinned
+ * host buffer + a device buffer per direction, sized for chunk_frames frames (<= 0: about 16 MB of planes per chunk: 2 frames of 1080p,
+ * one 4096^2 frame).  Nothing is allocated inside jpezy_multi_encode once the handle has served one call of the same shape, so a caller
+ * with a stream of batches creates it once.  A call shards its frames over the lanes (jpezy_shard_range, any n_frames > 0, it may change
+ * from call to call) and every lane streams its shard through its ring: feeder threads copy the caller's planes into pinned slots and
+ * start the uploads, the lane's thread enqueues FDCT + Huffman stage per chunk, drainer threads bring the results back at their real
+ * length -- upload of chunk c + 1, kernels of chunk c and download of chunk c - 1 overlap, PCIe runs in both directions.  The caller's
+ * PAGEABLE memory never reaches the DMA engines (uploads straight from it run at an eighth of the link's rate); planes the caller has
+ * pinned itself (hipHostMalloc / hipHostRegister; detected with hipPointerGetAttributes) are uploaded as they are, without the copy.
+ * r, g, b: host memory, n_frames consecutive W*H planes each.  out says what is wanted and where:
  *   coeffs      NULL, or room for n_frames * jpezy_coeff_count(W, H, gray) int16 (the layout of jpezy_fdct_quant)
  *   jpg         NULL, or n_frames * jpg_stride bytes: frame f's complete file at jpg + f * jpg_stride (MCU loop AND Huffman tail on
  *               the frame's GPU, only the finished file travels, at its real length); jpg_sizes[f] (HOST memory, n_frames entries)
@@ -248,9 +256,20 @@ long jpezy_encode_jpeg(jpezy_ctx* ctx, const uint8_t* r, const uint8_t* g, const
  *                   1: they are memory of devices[0] (coeffs 16-byte aligned) -- the consumer runs on that GPU: the other devices'
  *                      results are gathered into it chunk by chunk with hipMemcpyPeerAsync (xGMI between the GPUs of a node), the
  *                      root's own chunks are written in place.
- * An index may appear more than once in devices (several shards on one GPU, each with its own contexts and streams): that is how the
- * multi-shard path is exercised on a one-GPU box (tests/test_gpu_multi.py).  Returns JPEZY_OK, or the first failing shard's code
- * (message: which device and why); JPEZY_E_FORMAT when every shard ran but a frame was refused (see jpg_sizes).  Synchronous.
+ * THE GATHER IS hipMemcpyPeerAsync, NOT RCCL (north_star says "gather coefficient buffers with RCCL over xGMI"): one host process owns
+ * every device here, so a peer copy is the point-to-point transfer over the same xGMI link, with no communicator to build, no
+ * rendezvous and no second library in the link line of a C++ caller.  The one-process-per-GPU harness (jpezy_amd/sharding.py,
+ * bench.py --gpus N) is where RCCL moves the same buffers (send/recv to the consumer rank).
+ * An index may appear more than once in devices (several lanes on one GPU, each with its own context and streams): that is how the
+ * multi-lane path is exercised on a one-GPU box (tests/test_gpu_multi.py).  jpezy_multi_encode returns JPEZY_OK, or the first failing
+ * lane's code (message: which device and why); JPEZY_E_FORMAT when every lane ran but a frame was refused (see jpg_sizes).  Synchronous;
+ * one call at a time per handle; the calling thread's current HIP device is what it was on return.
+ * jpezy_multi_last_stats: per lane of the last call -- frames, wall time, the GPU time of its kernels (sum over its chunks, HIP
+ * events), bytes uploaded and brought back, whether the planes were staged (1) or were the caller's pinned memory (0); returns the
+ * number of lanes, fills at most cap entries.  jpezy_multi_chunk_frames: the chunk size the handle settled on.
+ *
+ * jpezy_encode_batch_multi: the one-shot form (create, one call, destroy; chunk_frames is clamped to the largest shard so that a
+ * single large frame does not reserve a ring for sixteen) -- what jpezy_encode --gpus N calls.
  * Replaces, for a batch: the caller's loop over encoder objects; inside each frame encoder/jpezy_encoder.hpp:55-67 and :174-225.
  */
 typedef struct jpezy_multi_out {
@@ -260,7 +279,21 @@ typedef struct jpezy_multi_out {
     long long* jpg_sizes;
     int on_root_device;
 } jpezy_multi_out;
+typedef struct jpezy_multi_lane_stats {
+    int device;
+    int staged;
+    long frames;
+    double wall_ms, kernel_ms;
+    unsigned long long bytes_up, bytes_down;
+} jpezy_multi_lane_stats;
+typedef struct jpezy_multi jpezy_multi;
 void jpezy_shard_range(long n_units, int n_shards, int k, long* first, long* count);
+jpezy_multi* jpezy_multi_create(const int* devices, int n_dev, int W, int H, int gray, int chunk_frames);
+void jpezy_multi_destroy(jpezy_multi* m);
+int jpezy_multi_encode(jpezy_multi* m, const uint8_t* r, const uint8_t* g, const uint8_t* b, int n_frames, const char* comment,
+                       const jpezy_multi_out* out);
+int jpezy_multi_last_stats(const jpezy_multi* m, jpezy_multi_lane_stats* stats, int cap);
+int jpezy_multi_chunk_frames(const jpezy_multi* m);
 int jpezy_encode_batch_multi(const int* devices, int n_dev, const uint8_t* r, const uint8_t* g, const uint8_t* b, int W, int H, int gray,
                              int n_frames, int chunk_frames, const char* comment, const jpezy_multi_out* out);
 

@@ -14,6 +14,7 @@ from .api import (  # noqa: F401
     Encoder,
     FrameInfo,
     JpezyError,
+    MultiEncoder,
     coeff_count,
     encode_batch_multi,
     library_path,
@@ -26,6 +27,6 @@ from .api import (  # noqa: F401
 )
 
 __all__ = [
-    "Context", "Decoder", "Encoder", "FrameInfo", "JpezyError", "coeff_count", "encode_batch_multi", "library_path",
+    "Context", "Decoder", "Encoder", "FrameInfo", "JpezyError", "MultiEncoder", "coeff_count", "encode_batch_multi", "library_path",
     "load_library", "mcu_grid", "read_jpeg", "shard_range", "write_jpeg", "write_jpeg_batch",
 ]

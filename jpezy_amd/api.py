@@ -39,6 +39,11 @@ class MultiOut(C.Structure):
                 ("on_root_device", C.c_int)]
 
 
+class MultiLaneStats(C.Structure):
+    _fields_ = [("device", C.c_int), ("staged", C.c_int), ("frames", C.c_long), ("wall_ms", C.c_double), ("kernel_ms", C.c_double),
+                ("bytes_up", C.c_ulonglong), ("bytes_down", C.c_ulonglong)]
+
+
 # every symbol include/jpezy_hip.h declares: (name, restype, argtypes)
 _u8p, _i16p, _vp = C.POINTER(C.c_uint8), C.POINTER(C.c_int16), C.c_void_p
 _QT = C.POINTER((C.c_uint16 * 64) * 4)
@@ -78,6 +83,11 @@ ABI = [
     ("jpezy_shard_range", None, [C.c_long, C.c_int, C.c_int, C.POINTER(C.c_long), C.POINTER(C.c_long)]),
     ("jpezy_encode_batch_multi", C.c_int, [C.POINTER(C.c_int), C.c_int, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p,
                                            C.POINTER(MultiOut)]),
+    ("jpezy_multi_create", _vp, [C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    ("jpezy_multi_destroy", None, [_vp]),
+    ("jpezy_multi_encode", C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_char_p, C.POINTER(MultiOut)]),
+    ("jpezy_multi_last_stats", C.c_int, [_vp, C.POINTER(MultiLaneStats), C.c_int]),
+    ("jpezy_multi_chunk_frames", C.c_int, [_vp]),
     ("jpezy_read_jpeg", C.c_int, [_vp, C.c_size_t, C.POINTER(FrameInfo), _vp, C.c_size_t]),
     ("jpezy_read_jpeg_gpu", C.c_int, [_vp, _vp, C.c_size_t, C.POINTER(FrameInfo), _vp, C.c_size_t]),
     ("jpezy_decode_jpeg", C.c_int, [_vp, _vp, C.c_size_t, C.c_int, C.POINTER(FrameInfo), _vp, _vp, _vp, C.c_size_t]),
@@ -418,16 +428,20 @@ def shard_range(n_units, n_shards, k):
     return lo.value, lo.value + n.value
 
 
-def encode_batch_multi(devices, r, g, b, W, H, n_frames, gray=False, chunk_frames=0, comment=None, want_coeffs=False, want_jpg=True,
-                       on_root_device=False, jpg_stride=None):
-    """jpezy_encode_batch_multi: n_frames frames (host planes, n_frames * W * H bytes each) over the GPUs `devices` (devices[0] = root).
-    Returns (coeffs or None, list of .jpg bytes or None).  on_root_device: the results are gathered into the root GPU's memory (torch
-    tensors on that device) and copied to the host here only to be returned."""
+def _multi_call(call, root_device, r, g, b, W, H, n_frames, gray, comment, want_coeffs, want_jpg, on_root_device, jpg_stride, raw=False):
+    """Shared body of encode_batch_multi and MultiEncoder.encode: buffers, the jpezy_multi_out record, the call, the results."""
     lib = load_library()
-    planes = [np.ascontiguousarray(p, dtype=np.uint8).reshape(-1) for p in (r, g, b)]
+    planes = [p if raw else np.ascontiguousarray(p, dtype=np.uint8).reshape(-1) for p in (r, g, b)]
+    ptrs = []
     for p in planes:
-        if p.size != W * H * n_frames:
-            raise JpezyError("plane size does not match W*H*n_frames")
+        if hasattr(p, "data_ptr"):              # a (pinned) torch tensor in host memory
+            if p.numel() != W * H * n_frames:
+                raise JpezyError("plane size does not match W*H*n_frames")
+            ptrs.append(C.c_void_p(p.data_ptr()))
+        else:
+            if p.size != W * H * n_frames:
+                raise JpezyError("plane size does not match W*H*n_frames")
+            ptrs.append(_np_ptr(p))
     if comment is None:
         comment = b"Encoded by JPEZY" if gray else b"Encoded by jpezy"
     cpf = lib.jpezy_coeff_count(W, H, int(gray))
@@ -440,7 +454,7 @@ def encode_batch_multi(devices, r, g, b, W, H, n_frames, gray=False, chunk_frame
     keep = []
     if on_root_device:
         import torch
-        dev = torch.device("cuda", int(devices[0]))
+        dev = torch.device("cuda", int(root_device))
         if want_coeffs:
             t = torch.empty(n_frames * cpf, dtype=torch.int16, device=dev); keep.append(t); out.coeffs = t.data_ptr()
         if want_jpg:
@@ -449,12 +463,12 @@ def encode_batch_multi(devices, r, g, b, W, H, n_frames, gray=False, chunk_frame
         if want_coeffs:
             t = np.empty(n_frames * cpf, dtype=np.int16); keep.append(t); out.coeffs = t.ctypes.data
         if want_jpg:
-            t = np.zeros(n_frames * stride, dtype=np.uint8); keep.append(t); out.jpg = t.ctypes.data
-    devs = (C.c_int * len(devices))(*[int(d) for d in devices])
-    rc = lib.jpezy_encode_batch_multi(devs, len(devices), _np_ptr(planes[0]), _np_ptr(planes[1]), _np_ptr(planes[2]), W, H, int(gray), n_frames,
-                                      int(chunk_frames), comment, C.byref(out))
+            t = np.empty(n_frames * stride, dtype=np.uint8); keep.append(t); out.jpg = t.ctypes.data
+    rc = call(ptrs, comment, out)
     if rc != 0 and not (rc == -5 and want_jpg):
         _check(rc)
+    if raw:                                     # (the benchmark: no per-file Python objects inside its bracket)
+        return keep, sizes
     host = [k.cpu().numpy() if on_root_device else k for k in keep]
     co = host.pop(0).reshape(n_frames, -1) if want_coeffs else None
     jpg = None
@@ -462,6 +476,69 @@ def encode_batch_multi(devices, r, g, b, W, H, n_frames, gray=False, chunk_frame
         buf = host.pop(0)
         jpg = [buf[f * stride: f * stride + sizes[f]].tobytes() if sizes[f] > 0 else int(sizes[f]) for f in range(n_frames)]
     return co, jpg
+
+
+def encode_batch_multi(devices, r, g, b, W, H, n_frames, gray=False, chunk_frames=0, comment=None, want_coeffs=False, want_jpg=True,
+                       on_root_device=False, jpg_stride=None):
+    """jpezy_encode_batch_multi (one-shot: handle created and destroyed inside): n_frames frames (host planes, n_frames * W * H bytes
+    each) over the GPUs `devices` (devices[0] = root).  Returns (coeffs or None, list of .jpg bytes or None).  on_root_device: the
+    results are gathered into the root GPU's memory (torch tensors on that device) and copied to the host here only to be returned."""
+    lib = load_library()
+    devs = (C.c_int * len(devices))(*[int(d) for d in devices])
+
+    def call(ptrs, comment, out):
+        return lib.jpezy_encode_batch_multi(devs, len(devices), ptrs[0], ptrs[1], ptrs[2], W, H, int(gray), n_frames, int(chunk_frames), comment,
+                                            C.byref(out))
+    return _multi_call(call, devices[0], r, g, b, W, H, n_frames, gray, comment, want_coeffs, want_jpg, on_root_device, jpg_stride)
+
+
+class MultiEncoder:
+    """jpezy_multi_create / jpezy_multi_encode / jpezy_multi_destroy: a reusable handle over the GPUs `devices` for frames of one
+    size -- contexts, streams and the pinned staging rings live as long as it does; encode() may be called with any number of frames."""
+
+    def __init__(self, devices, W, H, gray=False, chunk_frames=0):
+        lib = load_library()
+        self.devices = [int(d) for d in devices]
+        self.W, self.H, self.gray = int(W), int(H), bool(gray)
+        devs = (C.c_int * len(self.devices))(*self.devices)
+        self._h = lib.jpezy_multi_create(devs, len(self.devices), self.W, self.H, int(self.gray), int(chunk_frames))
+        if not self._h:
+            raise JpezyError(lib.jpezy_hip_last_error().decode(errors="replace"))
+        self.chunk_frames = lib.jpezy_multi_chunk_frames(self._h)
+
+    def encode(self, r, g, b, n_frames, comment=None, want_coeffs=False, want_jpg=True, on_root_device=False, jpg_stride=None, raw=False):
+        lib = load_library()
+        if not self._h:
+            raise JpezyError("MultiEncoder is closed")
+
+        def call(ptrs, comment, out):
+            return lib.jpezy_multi_encode(self._h, ptrs[0], ptrs[1], ptrs[2], n_frames, comment, C.byref(out))
+        return _multi_call(call, self.devices[0], r, g, b, self.W, self.H, n_frames, self.gray, comment, want_coeffs, want_jpg, on_root_device,
+                           jpg_stride, raw=raw)
+
+    def stats(self):
+        """per lane of the last encode(): dicts of jpezy_multi_lane_stats"""
+        lib = load_library()
+        arr = (MultiLaneStats * len(self.devices))()
+        n = lib.jpezy_multi_last_stats(self._h, arr, len(self.devices))
+        return [{k: getattr(arr[i], k) for k, _ in MultiLaneStats._fields_} for i in range(min(n, len(self.devices)))]
+
+    def close(self):
+        if self._h:
+            load_library().jpezy_multi_destroy(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def read_jpeg(data):

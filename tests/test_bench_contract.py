@@ -28,6 +28,8 @@ def test_algorithmic_bytes_match_the_survey():
     assert b.algorithmic_bytes(7680, 4320, True, "encode") == 3 * 7680 * 4320 + 480 * 270 * 4 * 128 == 165888000
     # config B: 1920x1080, height padded to 1088 by edge replication: 6.22 MB read + 6.27 MB written per frame
     assert b.algorithmic_bytes(1920, 1080, False, "encode") == 3 * 1920 * 1080 + 120 * 68 * 6 * 128 == 6220800 + 6266880
+    # gray decode: the kernel skips the chroma blocks (r = g = b = clamp(Y)): 2 B/px of luma coefficients + 3 B/px written = 5 B/px
+    assert b.algorithmic_bytes(7680, 4320, True, "decode") == 480 * 270 * 4 * 128 + 3 * 7680 * 4320 == 165888000
     assert b.HBM_PEAK_GBS == 8000.0
     assert b.WORKLOADS["encode4096"][:5] == (4096, 4096, False, 1, "encode")
     assert set(b.WORKLOADS) == {"encode4096", "decode4096", "gray8k", "batch1080p", "gray8k_decode", "encode4096_jpg", "decode4096_jpg"}
@@ -100,6 +102,15 @@ def test_traffic_json_is_what_the_cited_summaries_say():
     dec = have["decode4096"]
     assert abs(2 * dec["fetch_size_kib"] * 1024 / (b.algorithmic_bytes(4096, 4096, False, "decode") / 2) - 1) < 0.02
     assert 0.98 < dec["write_size_kib"] * 1024 / (3 * 4096 * 4096) < 1.40
+    # a roofline fraction's numerator may not exceed what the launch moves: for EVERY workload the counters' traffic is at least
+    # 0.98 x the algorithmic bytes bench.py charges it (gray8k_decode was charged 6 B/px, moved 5)
+    for wl, e in have.items():
+        if wl.startswith("_"):
+            continue
+        W, H, gray, fps, direction, _ = b.WORKLOADS[wl]
+        alg = b.algorithmic_bytes(W, H, gray, direction) * fps
+        assert e["bytes_per_launch"] >= 0.98 * alg, (wl, e["bytes_per_launch"], alg)
+        assert e["bytes_per_launch"] <= 1.10 * alg, (wl, e["bytes_per_launch"], alg)         # ... and no wasted re-reads either
 
 
 def test_other_workloads_and_native_multi_are_part_of_the_default_line():

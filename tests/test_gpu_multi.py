@@ -76,6 +76,81 @@ def test_bigger_frames_many_chunks(J, ctx, oracle):
         assert jpg[f] == ctx.encode_jpeg(*frames[f], W, H)
 
 
+def test_handle_reuse_with_changing_frame_counts(J, ctx, oracle):
+    """jpezy_multi_create once, jpezy_multi_encode many times: frame counts that grow, shrink, leave lanes empty, do not divide by the
+    chunk; outputs switch between host and root-device memory, coefficients and files; every call equal to the single-frame entries"""
+    import torch
+    W, H = 208, 120
+    frames, (r, g, b) = _frames(oracle, W, H, 23, 4000)
+    want_co = [ctx.fdct_quant(*fr, W, H).reshape(-1) for fr in frames]
+    want_jpg = [ctx.encode_jpeg(*fr, W, H) for fr in frames]
+    torch.cuda.set_device(0)
+    with J.MultiEncoder([0, 0, 0], W, H, chunk_frames=2) as M:
+        assert M.chunk_frames == 2
+        for n, on_root, co_too in [(7, False, True), (23, False, False), (1, False, True), (2, True, True), (23, True, True), (5, False, True),
+                                   (3, True, False)]:
+            px = [p[: n * W * H] for p in (r, g, b)]
+            co, jpg = M.encode(*px, n, want_coeffs=co_too, on_root_device=on_root)
+            assert [j for j in jpg] == want_jpg[:n], (n, on_root)
+            if co_too:
+                assert np.array_equal(co, np.stack(want_co[:n])), (n, on_root)
+            st = M.stats()
+            assert len(st) == 3 and sum(s["frames"] for s in st) == n
+            assert sum(s["bytes_up"] for s in st) == 3 * W * H * n
+            assert all(s["staged"] == 1 for s in st if s["frames"])                     # numpy memory is pageable: staged through the ring
+            assert all(s["kernel_ms"] > 0 and s["wall_ms"] >= s["kernel_ms"] * 0.5 for s in st if s["frames"])
+        assert torch.cuda.current_device() == 0
+    # a gray handle, default chunk size
+    with J.MultiEncoder([0, 0], W, H, gray=True) as M:
+        assert M.chunk_frames >= 1
+        for n in (3, 9):
+            co, jpg = M.encode(r[: n * W * H], g[: n * W * H], b[: n * W * H], n, want_coeffs=True)
+            for f in range(n):
+                assert np.array_equal(co[f], ctx.fdct_quant(*frames[f], W, H, gray=True).reshape(-1))
+                assert jpg[f] == ctx.encode_jpeg(*frames[f], W, H, gray=True)
+
+
+def test_planes_the_caller_has_pinned_are_uploaded_as_they_are(J, ctx, oracle):
+    """pinned host memory (torch pin_memory = hipHostMalloc) goes to the DMA engines without the staging copy; same results"""
+    import torch
+    W, H, F = 256, 80, 11
+    frames, planes = _frames(oracle, W, H, F, 5000)
+    pinned = [torch.from_numpy(p.copy()).pin_memory() for p in planes]
+    with J.MultiEncoder([0, 0], W, H, chunk_frames=3) as M:
+        co, jpg = M.encode(*pinned, F, want_coeffs=True, raw=False)
+        assert all(s["staged"] == 0 for s in M.stats() if s["frames"])
+        co2, jpg2 = M.encode(*planes, F, want_coeffs=True)                               # the same handle, pageable planes
+        assert all(s["staged"] == 1 for s in M.stats() if s["frames"])
+    assert np.array_equal(co, co2) and jpg == jpg2
+    for f in (0, 5, 10):
+        assert jpg[f] == ctx.encode_jpeg(*frames[f], W, H)
+
+
+def test_a_failing_call_leaves_the_handle_usable(J, ctx, oracle):
+    W, H, F = 128, 64, 6
+    frames, (r, g, b) = _frames(oracle, W, H, F, 6000)
+    with J.MultiEncoder([0, 0], W, H, chunk_frames=2) as M:
+        co, jpg = M.encode(r, g, b, F, jpg_stride=1024)                                  # every frame refused: JPEZY_E_NOSPACE each
+        assert all(j == -6 for j in jpg)
+        co, jpg = M.encode(r, g, b, F)
+        assert jpg == [ctx.encode_jpeg(*fr, W, H) for fr in frames]
+        with pytest.raises(J.JpezyError):
+            M.encode(r[:-1], g, b, F)
+
+
+def test_the_callers_current_device_is_put_back(J, oracle):
+    import ctypes as C
+    import torch
+    from jpezy_amd import api
+    hip = C.CDLL("libamdhip64.so")
+    torch.cuda.set_device(0)
+    W, H, F = 64, 48, 3
+    _, (r, g, b) = _frames(oracle, W, H, F, 1)
+    J.encode_batch_multi([0, 0], r, g, b, W, H, F)
+    d = C.c_int(-1)
+    assert hip.hipGetDevice(C.byref(d)) == 0 and d.value == 0
+
+
 def test_cli_gpus_mode(J, oracle, tmp_path):
     """jpezy_encode --gpus N in out [in out ...]: runs of one size form a batch; the files equal those of the one-file CLI form"""
     from pathlib import Path

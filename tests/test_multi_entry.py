@@ -54,3 +54,36 @@ def test_device_index_out_of_range_is_refused():
         pytest.skip("needs a device to have a range")
     with pytest.raises(J.JpezyError):
         J.encode_batch_multi([lib.jpezy_hip_device_count()], *(np.zeros(256, np.uint8),) * 3, 16, 16, 1)
+
+
+def test_handle_entry_points_check_their_arguments_before_any_device_call():
+    lib = api.load_library()
+    devs = (C.c_int * 2)(0, 0)
+    assert not lib.jpezy_multi_create(None, 1, 16, 16, 0, 0) and b"devices" in lib.jpezy_hip_last_error()
+    assert not lib.jpezy_multi_create(devs, 0, 16, 16, 0, 0)
+    assert not lib.jpezy_multi_create(devs, 65, 16, 16, 0, 0)
+    assert not lib.jpezy_multi_create(devs, 2, 0, 16, 0, 0) and b"width/height" in lib.jpezy_hip_last_error()
+    assert not lib.jpezy_multi_create(devs, 2, 16, 65536, 0, 0)
+    px = np.zeros(256, np.uint8)
+    out = api.MultiOut()
+    assert lib.jpezy_multi_encode(None, api._np_ptr(px), api._np_ptr(px), api._np_ptr(px), 1, b"x", C.byref(out)) == -1
+    assert b"null handle" in lib.jpezy_hip_last_error()
+    assert lib.jpezy_multi_last_stats(None, None, 0) == 0 and lib.jpezy_multi_chunk_frames(None) == 0
+    lib.jpezy_multi_destroy(None)                                                         # a no-op, as free(NULL)
+    if lib.jpezy_hip_device_count() <= 0:
+        assert not lib.jpezy_multi_create(devs, 2, 16, 16, 0, 0) and b"no CPU fallback" in lib.jpezy_hip_last_error()
+        with pytest.raises(J.JpezyError):
+            J.MultiEncoder([0], 16, 16)
+    else:
+        h = lib.jpezy_multi_create(devs, 2, 16, 16, 0, 0)
+        assert h
+        assert lib.jpezy_multi_encode(h, None, api._np_ptr(px), api._np_ptr(px), 1, b"x", C.byref(out)) == -1
+        assert lib.jpezy_multi_encode(h, api._np_ptr(px), api._np_ptr(px), api._np_ptr(px), 1, b"x", None) == -1
+        assert lib.jpezy_multi_encode(h, api._np_ptr(px), api._np_ptr(px), api._np_ptr(px), 1, b"x", C.byref(out)) == -1   # nothing asked for
+        assert b"neither" in lib.jpezy_hip_last_error()
+        sizes = (C.c_longlong * 1)()
+        buf = np.zeros(4096, np.uint8)
+        out.jpg, out.jpg_sizes, out.jpg_stride = buf.ctypes.data, sizes, 4096
+        assert lib.jpezy_multi_encode(h, api._np_ptr(px), api._np_ptr(px), api._np_ptr(px), 0, b"x", C.byref(out)) == -1
+        assert lib.jpezy_multi_encode(h, api._np_ptr(px), api._np_ptr(px), api._np_ptr(px), 1, b"x", C.byref(out)) == 0 and sizes[0] > 600
+        lib.jpezy_multi_destroy(h)

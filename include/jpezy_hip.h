@@ -158,10 +158,14 @@ int jpezy_dequant_idct_generic_batch_dev(jpezy_ctx* ctx, const int16_t* d_coeffs
  * parity tests. */
 void jpezy_ctx_set_force_exact(jpezy_ctx* ctx, int on);
 /* Encode kernel variant: 0 = FP64 butterflies (round-1 kernel), 1 = packed-FP32 first level + FP64 second level +
- * reference-order third level, one quad of four MCUs per wave.  Two independently written kernels with proven error
- * bounds that must agree bit for bit (tests/test_gpu_parity.py runs every case through both).  2 = variant 1's arithmetic
- * in persistent workgroups whose loader waves stream the pixels into an LDS ring by LDS-DMA (frames whose rows divide into
- * groups of 16 MCUs and 16-byte aligned planes; anything else is handed to variant 1's launch).  tests/test_gpu_persistent.py. */
+ * reference-order third level, one quad of four MCUs per wave (the default).  Two independently written kernels with proven error
+ * bounds that must agree bit for bit (tests/test_gpu_parity.py runs every case through both).
+ * 2 and 3 are LABORATORY variants, present only in libraries built with -DJPEZY_WITH_LAB (python -m jpezy_amd._build --lab;
+ * tools/ab/ab_build.py): variant 1's arithmetic in persistent workgroups -- 2: loader waves stream the pixels into an LDS ring by
+ * LDS-DMA, 3: sixteen computing waves per CU prefetch their next quad into registers (frames whose rows divide into groups of 16
+ * MCUs and 16-byte aligned planes; anything else is handed to variant 1's launch).  Both are parity-green and were measured NOT
+ * faster than variant 1 (docs/ROUND5.md), so the shipped library does not contain them: it answers JPEZY_E_UNSUPPORTED and keeps
+ * the context's kernel.  Returns JPEZY_OK, JPEZY_E_BADARG (no such variant) or JPEZY_E_UNSUPPORTED.  tests/test_gpu_persistent.py. */
 int jpezy_ctx_set_variant(jpezy_ctx* ctx, int variant);
 /*
  * Decode tolerance (opt-in; default 0).  BASELINE.json's north_star asks of the decoder "PPM output within +-1 LSB per

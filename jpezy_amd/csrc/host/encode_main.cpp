@@ -48,6 +48,7 @@ int batch_main(const int argc, const char* argv[])
     jpezy::disp_logo();
     const int n_files = (argc - a) / 2;
     int f = 0;
+    jpezy_ctx* single = nullptr;
     while (f < n_files) {
         std::vector<std::uint8_t> r, g, b;
         std::size_t W = 0, H = 0;
@@ -62,10 +63,20 @@ int batch_main(const int argc, const char* argv[])
         const std::size_t stride = jpezy_jpeg_bound(static_cast<int>(W), static_cast<int>(H));
         std::vector<std::uint8_t> jpg(stride * static_cast<std::size_t>(n));
         std::vector<long long> sizes(static_cast<std::size_t>(n));
-        jpezy_multi_out out{ nullptr, jpg.data(), stride, sizes.data(), 0 };
-        const int rc = jpezy_encode_batch_multi(devices.data(), static_cast<int>(devices.size()), r.data(), g.data(), b.data(), static_cast<int>(W),
-                                                static_cast<int>(H), gray ? 1 : 0, n, 0, gray ? "Encoded by JPEZY" : "Encoded by jpezy", &out);
-        if (rc != JPEZY_OK) { std::cerr << "jpezy_encode_batch_multi: " << jpezy_hip_last_error() << std::endl; return EXIT_FAILURE; }
+        const char* comment = gray ? "Encoded by JPEZY" : "Encoded by jpezy";
+        if (n == 1) {
+            // a run of one frame has nothing to shard: the ordinary single-file path (streams the frame band by band, no ring of
+            // whole-frame slots: a 16K x 16K file would otherwise reserve several GB of pinned memory for nothing)
+            if (!single) single = jpezy_ctx_create(devices[0]);
+            if (!single) { std::cerr << "jpezy_ctx_create: " << jpezy_hip_last_error() << std::endl; return EXIT_FAILURE; }
+            sizes[0] = jpezy_encode_jpeg(single, r.data(), g.data(), b.data(), static_cast<int>(W), static_cast<int>(H), gray ? 1 : 0, comment, jpg.data(), stride);
+            if (sizes[0] < 0) { std::cerr << "jpezy_encode_jpeg: " << jpezy_hip_last_error() << std::endl; jpezy_ctx_destroy(single); return EXIT_FAILURE; }
+        } else {
+            jpezy_multi_out out{ nullptr, jpg.data(), stride, sizes.data(), 0 };
+            const int rc = jpezy_encode_batch_multi(devices.data(), static_cast<int>(devices.size()), r.data(), g.data(), b.data(), static_cast<int>(W),
+                                                    static_cast<int>(H), gray ? 1 : 0, n, 0, comment, &out);
+            if (rc != JPEZY_OK) { std::cerr << "jpezy_encode_batch_multi: " << jpezy_hip_last_error() << std::endl; if (single) jpezy_ctx_destroy(single); return EXIT_FAILURE; }
+        }
         for (int i = 0; i < n; ++i) {
             const char* name = argv[a + 2 * (f + i) + 1];
             std::ofstream ofs(name, std::ios::binary);
@@ -75,6 +86,7 @@ int batch_main(const int argc, const char* argv[])
         }
         f += n;
     }
+    if (single) jpezy_ctx_destroy(single);
     std::cout << "Encoded " << n_files << " file(s) on " << devices.size() << " GPU(s)" << std::endl;
     return EXIT_SUCCESS;
 }

@@ -49,10 +49,14 @@ jpezy_ctx* jpezy_ctx_create(int device)
     }
     c->device = device;
     if (hipDeviceGetAttribute(&c->n_cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || c->n_cus <= 0) c->n_cus = 256;
-    if (const char* v = getenv("JPEZY_ENC_VARIANT")) {   // development: the default encode kernel of every context (A/B runs of tools/ab/ab_run.sh)
+#ifdef JPEZY_WITH_LAB
+    // laboratory builds only (tools/ab/ab_run.sh): the default encode kernel of every context from the environment.  The shipped
+    // library reads no environment variable -- a stray one must not switch every context to another kernel
+    if (const char* v = getenv("JPEZY_ENC_VARIANT")) {
         const int k = atoi(v);
         if (k >= 0 && k <= 3) c->variant = k;
     }
+#endif
     std::vector<DeviceTables> hbuf(1); // 33 KB: off the stack, and private to this call (contexts may be created concurrently)
     DeviceTables& h = hbuf[0];
     const double S = JPEZY_INV_SQRT2;
@@ -203,6 +207,11 @@ int jpezy_ctx_set_variant(jpezy_ctx* c, int variant)
 {
     if (!c) return set_err(JPEZY_E_BADARG, "null context");
     if (variant < 0 || variant > 3) return set_err(JPEZY_E_BADARG, "unknown kernel variant");
+#ifndef JPEZY_WITH_LAB
+    if (variant >= 2)
+        return set_err(JPEZY_E_UNSUPPORTED, "encode variants 2 and 3 (persistent kernels) exist only in laboratory builds (-DJPEZY_WITH_LAB, "
+                                            "python -m jpezy_amd._build --lab): measured not faster than variant 1, they are not shipped");
+#endif
     c->variant = variant;
     return JPEZY_OK;
 }
@@ -217,6 +226,14 @@ long jpezy_ctx_last_fallback_count(jpezy_ctx* c)
     if (hipMemset(c->d_counter, 0, sizeof shards) != hipSuccess) return -1;
     unsigned long long v = 0;
     for (unsigned long long s : shards) v += s;
+#ifdef JPEZY_WITH_LAB
+    // encode variant 2 (laboratory): a workgroup whose bounded spin ran out drains the launch and raises bit 40 of the last shard --
+    // the coefficients of that launch are incomplete.  Surfaced as an error, not as a count.
+    if (shards[COUNTER_SHARDS - 1] >> 40) {
+        set_err(JPEZY_E_HIP, "encode variant 2: a persistent workgroup gave up waiting for its ring (spin cap); the last launch's coefficients are incomplete");
+        return -1;
+    }
+#endif
     return (long)v;
 }
 
@@ -269,11 +286,14 @@ int jpezy_fdct_quant_dev(jpezy_ctx* c, const uint8_t* d_r, const uint8_t* d_g, c
         q.n_frames = n_frames - f0 < kMaxFramesPerLaunch ? n_frames - f0 : kMaxFramesPerLaunch;
         q.r += (size_t)f0 * plane_stride; q.g += (size_t)f0 * plane_stride; q.b += (size_t)f0 * plane_stride;
         q.coeffs += (size_t)f0 * p.coeffs_per_frame;
+#ifdef JPEZY_WITH_LAB
         if (c->variant == 3)
             HIP_TRY(launch_fdct_quant_f32_ps2(q, gray != 0, c->force_exact, c->n_cus, s));
         else if (c->variant == 2)
             HIP_TRY(launch_fdct_quant_f32_ps(q, gray != 0, c->force_exact, c->n_cus, s));
-        else if (c->variant == 1)
+        else
+#endif
+        if (c->variant == 1)
             HIP_TRY(launch_fdct_quant_f32(q, gray != 0, c->force_exact, s));
         else
             HIP_TRY(launch_fdct_quant(q, gray != 0, c->force_exact != 0, s));

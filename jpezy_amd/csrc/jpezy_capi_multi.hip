@@ -55,6 +55,7 @@ struct Lane {
     jpezy_ctx* ctx = nullptr;
     hipStream_t s_up = nullptr, s_down[N_DRAIN] = {};
     Slot slot[RING];
+    int ring = RING;                    // slots in use (the one-shot form of a small batch builds no more than its chunks need)
     bool peer_enabled = false;
     // per call
     long f0 = 0, nf = 0;
@@ -131,7 +132,8 @@ int create_lane(const jpezy_multi& M, Lane& L)
     L_TRY(hipStreamCreateWithFlags(&L.s_up, hipStreamNonBlocking));
     for (hipStream_t& s : L.s_down) L_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
     const size_t in_bytes = 3 * M.plane * (size_t)M.chunk;
-    for (Slot& sl : L.slot) {
+    for (int k = 0; k < L.ring; ++k) {
+        Slot& sl = L.slot[k];
         L_TRY(hipEventCreateWithFlags(&sl.ev_up, hipEventDisableTiming));
         L_TRY(hipEventCreate(&sl.ev_k0));               // (timed: the lane's kernel time is the sum of its chunks' spans)
         L_TRY(hipEventCreate(&sl.ev_k));
@@ -180,7 +182,7 @@ void run_lane(const jpezy_multi& M, Lane& L, const Job& J)
     const auto t_begin = std::chrono::steady_clock::now();
     const int chunk = M.chunk;
     const int n_chunks = (int)((L.nf + chunk - 1) / chunk);
-    const int root_dev = M.devices[0];
+    const int root_dev = M.devices[0], ring = L.ring;
     const bool to_root = J.out.on_root_device != 0;
     const bool in_place = to_root && L.index == 0;                      // the root lane writes its results where they belong
     const bool want_jpg = J.out.jpg != nullptr, want_coef = J.out.coeffs != nullptr;
@@ -203,7 +205,8 @@ void run_lane(const jpezy_multi& M, Lane& L, const Job& J)
             if (hipDeviceEnablePeerAccess(root_dev, 0) != hipSuccess) (void)hipGetLastError();   // already enabled / not supported: hipMemcpyPeerAsync works either way
             L.peer_enabled = true;
         }
-        for (Slot& sl : L.slot) {
+        for (int k = 0; k < L.ring; ++k) {
+            Slot& sl = L.slot[k];
             if (rc || e != hipSuccess) break;
             if (!J.src_pinned && !sl.pin_in) e = hipHostMalloc((void**)&sl.pin_in, 3 * M.plane * (size_t)chunk, hipHostMallocDefault);
             if (e == hipSuccess && want_jpg && !in_place) rc = sl.dev_jpg.reserve(dstride * (size_t)chunk);
@@ -223,9 +226,9 @@ void run_lane(const jpezy_multi& M, Lane& L, const Job& J)
     auto feeder = [&](int id) {
         R_TRY(hipSetDevice(L.dev));
         for (int c = id; c < n_chunks && !R.failed.load(); c += N_FEED) {
-            Slot& sl = L.slot[c % RING];
-            if (c >= RING) {                                            // the slot's input buffers are free once the kernels of the chunk that used them last have run
-                if (!R.wait(c - RING, 2)) return;
+            Slot& sl = L.slot[c % ring];
+            if (c >= ring) {                                            // the slot's input buffers are free once the kernels of the chunk that used them last have run
+                if (!R.wait(c - ring, 2)) return;
                 R_TRY(hipEventSynchronize(sl.ev_k));
             }
             const int n = chunk_frames(c);
@@ -251,7 +254,7 @@ void run_lane(const jpezy_multi& M, Lane& L, const Job& J)
         R_TRY(hipSetDevice(L.dev));
         hipStream_t sd = L.s_down[id];
         for (int c = id; c < n_chunks && !R.failed.load(); c += N_DRAIN) {
-            Slot& sl = L.slot[c % RING];
+            Slot& sl = L.slot[c % ring];
             if (!R.wait(c, 2)) return;
             R_TRY(hipEventSynchronize(sl.ev_k));                        // the chunk's kernels are done, its sizes are in pin_sizes
             {
@@ -324,9 +327,9 @@ void run_lane(const jpezy_multi& M, Lane& L, const Job& J)
         }
         hipStream_t sc = (hipStream_t)jpezy_ctx_stream(L.ctx);
         for (int c = 0; c < n_chunks && !R.failed.load(); ++c) {
-            Slot& sl = L.slot[c % RING];
+            Slot& sl = L.slot[c % ring];
             if (!R.wait(c, 1)) break;
-            if (c >= RING && !R.wait(c - RING, 3)) break;               // the slot's output buffers have been delivered
+            if (c >= ring && !R.wait(c - ring, 3)) break;               // the slot's output buffers have been delivered
             const int n = chunk_frames(c);
             const long f = L.f0 + (long)c * chunk;
             const size_t qs = M.plane * (size_t)chunk;
@@ -430,6 +433,11 @@ jpezy_multi* multi_create(const int* devices, int n_dev, int W, int H, int gray,
         M->lanes.emplace_back(new Lane);
         M->lanes.back()->index = i;
         M->lanes.back()->dev = devices[i];
+        if (frames_hint > 0) {                          // ... and no more slots than the shard has chunks
+            long f0 = 0, nf = 0;
+            jpezy_shard_range(frames_hint, n_dev, i, &f0, &nf);
+            M->lanes.back()->ring = (int)std::max<long>(1, std::min<long>(RING, (nf + M->chunk - 1) / M->chunk));
+        }
     }
     for (auto& L : M->lanes) {
         const int rc = create_lane(*M, *L);

@@ -23,6 +23,21 @@
 #include "jpezy_device.h"
 #include "../../include/jpezy_constants.h"
 
+#ifdef JPEZY_WITH_LAB
+#include "jpezy_lab.h"         // the laboratory: timing probes (PROBE_*, JPEZY_ABL_*), the persistent kernels' build knobs (JPEZY_PS_*)
+#else
+// the shipped build: no probes; the persistent kernels (PS = true) are not instantiated, their knobs are constants
+#define PROBE_ALL() do { } while (0)
+#define JPEZY_LAB_COLOUR_VOTE(x) (x)
+#define JPEZY_LAB_GUARD_CAND(x) (x)
+#define JPEZY_LAB_VALID_CHUNKS(x) (x)
+#define JPEZY_PS_CONSTS_LDS 0
+#define JPEZY_PS_DC_FORMULA 1
+#define JPEZY_PS_DCQ_LDS 0
+#define JPEZY_PS_HOOK_LATE 0
+#define JPEZY_PS_FENCES 1
+#endif
+
 namespace jpezy_dev {
 namespace f32 {
 
@@ -246,11 +261,7 @@ __device__ __forceinline__ void luma8(const uint32_t* wr, const uint32_t* wg, co
     __builtin_amdgcn_sched_barrier(0);   // 4 pixels at a time: more in flight only costs registers
     luma_px2<2, 1>(wr[0], wg[0], wb[0], wr[1], wg[1], wb[1], A[2], e[2]);
     luma_px2<3, 0>(wr[0], wg[0], wb[0], wr[1], wg[1], wb[1], A[3], e[3]);
-#ifdef JPEZY_ABL_NOCFLAG    // timing probe (wrong results, tools/ab/ab_build.py): what the colour guard tests and their rare path cost
-    if (false) {
-#else
-    if (wave_any(min8(e) < LUMA_TH)) {   // one pixel in 1000: the reference's FP64 rounding decides
-#endif
+    if (JPEZY_LAB_COLOUR_VOTE(wave_any(min8(e) < LUMA_TH))) {   // one pixel in 1000: the reference's FP64 rounding decides
         bool f;
         f = e[0].x < LUMA_TH; if (f) A[0].x = luma_px_ref<0>(wr[0], wg[0], wb[0]);
         f = e[1].x < LUMA_TH; if (f) A[1].x = luma_px_ref<1>(wr[0], wg[0], wb[0]);
@@ -365,6 +376,8 @@ __device__ __forceinline__ int dc_lookup(float sum, const signed char* dcq)
 // truncated to 0), q = trunc(d * rq + bias) with rq = fl(1 / Q), bias = 1 / (2 Q): d <= 1023 puts d * rq within 6e-5 of d / Q, whose
 // fractional part is a multiple of 1 / Q.  jpezy_capi.hip evaluates exactly these operations for every sum in [-8192, 8192] against
 // DeviceTables::dcq at context creation and only then lets the kernel use them (EncParams::dc_rq[t] != 0).
+// Only the j == 0 lane's result is used (quant_block_column: `if (j == 0) q[0] = dc`); the other lanes feed it their X0 of some other
+// column -- an arbitrary float -- and throw the result away: no clamp is needed for them (an out-of-range v_cvt_i32_f32 saturates).
 __device__ __forceinline__ int dc_formula(float sum, float rq, float bias)
 {
     const float d = __builtin_truncf(FMAF(__builtin_fabsf(sum), 0.125f, -0.125f));
@@ -411,11 +424,7 @@ __device__ __forceinline__ void quant_block_column(const f2* F, const f2* ks, f2
     // v_min3_f32: 3.5 instructions for 8 values
     const float fmin = __builtin_fminf(__builtin_fminf(__builtin_fminf(fr[0], fr[1]), __builtin_fminf(fr[2], fr[3])),
                                        __builtin_fminf(__builtin_fminf(fr[4], fr[5]), __builtin_fminf(fr[6], fr[7])));
-#ifdef JPEZY_ABL_NOGUARD    // timing probe (wrong results): what the coefficient guard tests and levels 2/3 cost
-    const bool cand = false;
-#else
-    const bool cand = force || fmin < th;
-#endif
+    const bool cand = JPEZY_LAB_GUARD_CAND(force || fmin < th);
     // rare on noisy content; flat content (exact zeros) enters and finds nothing to queue.  (Lanes that are not live
     // repeat the quad's last MCU, so leaving them in the vote changes nothing and keeps it a bare v_cmp + s_cmp.)
     if (wave_any(cand)) {
@@ -517,24 +526,9 @@ struct QuadTrace { unsigned long long t2; unsigned long long ph[8]; };
 // ([2][16385] bytes) and the cosine table in LDS; null in the one-quad kernel, which reads all three from global memory.
 // The scheduler fences between the phases of a quad keep the one-quad kernel at 79 VGPRs (6 waves per SIMD); the persistent kernel has
 // 128 registers per lane anyway (16 waves per CU) and may let the scheduler overlap the phases (JPEZY_PS_FENCES=0).
-#ifndef JPEZY_PS_CONSTS_LDS
-#define JPEZY_PS_CONSTS_LDS 0  // 1: the persistent kernels read the lane's quantiser records per quad from an LDS copy of the tables instead of keeping them in 22 registers
-#endif
 #ifndef JPEZY_DC_FORMULA_ONEQUAD
 #define JPEZY_DC_FORMULA_ONEQUAD 2   // the one-quad kernel's quantised DC: 0 = table lookup (three byte loads per quad), 1 = dc_formula unchecked (A/B only),
                                      // 2 = dc_formula where the host check allowed it (EncParams::dc_rq != 0), else the table.  26.45 against 26.79 us (five rounds)
-#endif
-#ifndef JPEZY_PS_DC_FORMULA
-#define JPEZY_PS_DC_FORMULA 1  // 1: the persistent kernels compute the quantised DC (dc_formula, host-verified) instead of looking it up in a 32 KB table in LDS
-#endif
-#ifndef JPEZY_PS_DCQ_LDS
-#define JPEZY_PS_DCQ_LDS (!JPEZY_PS_DC_FORMULA)   // without the formula: 1 = the quantised-DC tables copied to LDS, 0 = they stay in global memory (the loop then holds three byte loads)
-#endif
-#ifndef JPEZY_PS_HOOK_LATE
-#define JPEZY_PS_HOOK_LATE 0   // 1: after_pixels() runs behind the luma quantiser (step 3+4) instead of behind step 2b: the next quad's pixel registers are not live across the most register-hungry phase
-#endif
-#ifndef JPEZY_PS_FENCES
-#define JPEZY_PS_FENCES 1
 #endif
 #define PHASE_FENCE() do { if (!PS || JPEZY_PS_FENCES) __builtin_amdgcn_sched_barrier(0); } while (0)
 struct NoHook { __device__ __forceinline__ void operator()() const {} };
@@ -560,37 +554,6 @@ __device__ __forceinline__ void encode_quad_compute(const EncParams& p, const ui
 #define DUMP_ARG
 #endif
     if (lane == 0) queue[0] = 0;
-#ifdef JPEZY_PROBE_SALU   // timing probe (results unchanged): JPEZY_PROBE_SALU extra scalar-ALU instructions per quad, in four places
-#define PROBE_SALU() do { int d_ = lane; d_ = __builtin_amdgcn_readfirstlane(d_); _Pragma("unroll") for (int k_ = 0; k_ < JPEZY_PROBE_SALU / 4; ++k_) asm volatile("s_add_u32 %0, %0, 1" : "+s"(d_)); asm volatile("" :: "s"(d_)); } while (0)
-#else
-#define PROBE_SALU() do { } while (0)
-#endif
-#ifdef JPEZY_PROBE_VALU   // the same with full-rate vector instructions
-#define PROBE_VALU() do { int d_ = lane; _Pragma("unroll") for (int k_ = 0; k_ < JPEZY_PROBE_VALU / 4; ++k_) asm volatile("v_add_u32 %0, %0, 1" : "+v"(d_)); asm volatile("" :: "v"(d_)); } while (0)
-#else
-#define PROBE_VALU() do { } while (0)
-#endif
-#ifdef JPEZY_PROBE_NOP    // s_nop 0
-#define PROBE_NOP() do { _Pragma("unroll") for (int k_ = 0; k_ < JPEZY_PROBE_NOP / 4; ++k_) asm volatile("s_nop 0"); } while (0)
-#else
-#define PROBE_NOP() do { } while (0)
-#endif
-#ifdef JPEZY_PROBE_HALF   // a second-class vector instruction (v_cvt_f32_ubyte0)
-#define PROBE_HALF() do { float d_ = __builtin_bit_cast(float, lane); _Pragma("unroll") for (int k_ = 0; k_ < JPEZY_PROBE_HALF / 4; ++k_) asm volatile("v_cvt_f32_ubyte0 %0, %0" : "+v"(d_)); asm volatile("" :: "v"(d_)); } while (0)
-#else
-#define PROBE_HALF() do { } while (0)
-#endif
-#ifdef JPEZY_PROBE_PK     // a packed FP32 instruction
-#define PROBE_PK() do { f2 d_ = { 1.f, 2.f }; _Pragma("unroll") for (int k_ = 0; k_ < JPEZY_PROBE_PK / 4; ++k_) asm volatile("v_pk_add_f32 %0, %0, %0" : "+v"(d_)); asm volatile("" :: "v"(d_)); } while (0)
-#else
-#define PROBE_PK() do { } while (0)
-#endif
-#ifdef JPEZY_PROBE_LDS    // a 2-byte LDS store into the (still unused) queue area of the wave's slice
-#define PROBE_LDS() do { _Pragma("unroll") for (int k_ = 0; k_ < JPEZY_PROBE_LDS / 4; ++k_) asm volatile("ds_write_b16 %0, %1 offset:%2" :: "v"((unsigned)(uintptr_t)(queue + 8) + 2u * (unsigned)lane), "v"(lane), "n"(0) : "memory"); } while (0)
-#else
-#define PROBE_LDS() do { } while (0)
-#endif
-#define PROBE_ALL() do { PROBE_SALU(); PROBE_VALU(); PROBE_NOP(); PROBE_HALF(); PROBE_PK(); PROBE_LDS(); } while (0)
     PROBE_ALL();
     PkCos kc = pk_cos();
 #if JPEZY_PIN_CONSTANTS
@@ -634,11 +597,7 @@ __device__ __forceinline__ void encode_quad_compute(const EncParams& p, const ui
         PHASE_FENCE();
         chroma_px2<0, 2>(R2[1], G2[1], B2[1], R2[2], G2[2], B2[2], k1, k2, k3, CS[2], e[2]);    // samples 2, 5
         chroma_px2<2, 0>(R2[1], G2[1], B2[1], R2[2], G2[2], B2[2], k1, k2, k3, CS[3], e[3]);    // samples 3, 4
-#ifdef JPEZY_ABL_NOCFLAG
-        if (false) {
-#else
-        if (wave_any(min8(e) < CHROMA_TH)) {
-#endif
+        if (JPEZY_LAB_COLOUR_VOTE(wave_any(min8(e) < CHROMA_TH))) {
             bool f;
             f = e[0].x < CHROMA_TH; if (f) CS[0].x = chroma_px_ref<0>(R2[0], G2[0], B2[0], odd);
             f = e[1].x < CHROMA_TH; if (f) CS[1].x = chroma_px_ref<2>(R2[0], G2[0], B2[0], odd);
@@ -843,11 +802,7 @@ __device__ __forceinline__ void encode_quad_store(const EncParams& p, uint32_t* 
     constexpr int BPM = GRAY ? 4 : 6;
     const char* stage = reinterpret_cast<const char*>(lds) + CT_BYTES;
     {
-#ifdef JPEZY_ABL_NOSTORE     // TIMING PROBE (wrong results): the coefficients are staged and read back but never stored (only lanes whose
-        const int valid_chunks = (lds[0] == 0x12345678u) ? 1 : 0;                   // staged data match a value they never have would store)
-#else
-        const int valid_chunks = min(4, p.mcu_cols - quad_x * 4) * BPM * 8;         // 16-byte chunks
-#endif
+        const int valid_chunks = JPEZY_LAB_VALID_CHUNKS(min(4, p.mcu_cols - quad_x * 4) * BPM * 8);         // 16-byte chunks
         int16_t* gbase = p.coeffs + (size_t)frame * p.coeffs_per_frame +
                          ((size_t)mcu_y * p.mcu_cols + (size_t)quad_x * 4) * (BPM * 64);
         uint4* g4 = reinterpret_cast<uint4*>(gbase);

@@ -12,6 +12,10 @@ are chosen by the SHAPE OF THE WORK rather than by pixel content:
     must hand them to variant 1's kernel,
   * every rare path inside the loop (force_exact 1/2/3; structured inputs full of guard-band hits): a wave that resolves
     hits must not disturb the waves it shares a ring with.
+
+These kernels are the LABORATORY (round 5 measured them not faster than variant 1): the shipped library does not contain them and
+jpezy_ctx_set_variant(ctx, 2) answers JPEZY_E_UNSUPPORTED -- this module then checks exactly that and skips the rest.  Against a
+laboratory build (`python -m jpezy_amd._build --lab`, run with JPEZY_LIB=jpezy_amd/libjpezy_hip_lab.so) every case runs.
 """
 import numpy as np
 import pytest
@@ -29,9 +33,34 @@ def J():
 @pytest.fixture(scope="module", params=[2, 3], ids=["loader-waves", "register-prefetch"])
 def ctx(J, request):
     c = J.Context(0)
-    c.set_variant(request.param)
+    try:
+        c.set_variant(request.param)
+    except J.JpezyError as e:
+        c.close()
+        assert "laboratory" in str(e)
+        pytest.skip("the shipped library holds no persistent encode kernels (laboratory builds only)")
     yield c
     c.close()
+
+
+def test_the_shipped_library_refuses_the_laboratory_variants_loudly(J):
+    """set_variant(2 / 3) either works (laboratory build) or fails with JPEZY_E_UNSUPPORTED and leaves the context on its kernel;
+    never a silent switch, and no environment variable selects a kernel in the shipped build"""
+    import os
+    import subprocess
+    import sys
+    from jpezy_amd import api
+    lib = api.load_library()
+    c = J.Context(0)
+    try:
+        rcs = [lib.jpezy_ctx_set_variant(c._h, v) for v in (2, 3)]
+        assert rcs in ([0, 0], [-4, -4])
+        assert lib.jpezy_ctx_set_variant(c._h, 4) == -1 and lib.jpezy_ctx_set_variant(c._h, 1) == 0
+    finally:
+        c.close()
+    if rcs == [-4, -4]:
+        have = subprocess.run(["strings", str(J.library_path())], capture_output=True, text=True).stdout
+        assert "fdct_quant_f32_ps" not in have and "JPEZY_ENC_VARIANT" not in have
 
 
 @pytest.fixture(scope="module")

@@ -21,9 +21,9 @@ def build(spec):
     out = ROOT / "ab" / name
     out.mkdir(parents=True, exist_ok=True)
     objs = []
-    for src in B.LIB_SOURCES:
+    for src in B.LIB_SOURCES + B.LAB_SOURCES:          # A/B builds are laboratory builds: variants 2 / 3 and the probe switches are in
         obj = out / (src.stem + ".o")
-        fl = B.COMMON + (B.DEVICE if src.suffix == ".hip" else ["-x", "c++"]) + flags.split()
+        fl = B.COMMON + (B.DEVICE if src.suffix == ".hip" else ["-x", "c++"]) + B.LAB_FLAGS + flags.split()
         subprocess.run([B.HIPCC, *fl, "-c", str(src), "-o", str(obj)], check=True, capture_output=True)
         objs.append(str(obj))
     lib = ROOT / "ab" / f"libjpezy_{name}.so"

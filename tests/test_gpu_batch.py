@@ -161,6 +161,31 @@ def test_bench_gpus_2_on_rccl_when_two_gpus_are_visible():
     assert bt["end_to_end_jpg"]["bytes_into_rank0"] < bt["gather"]["bytes_into_rank0"] // 5
 
 
+def test_native_entry_between_two_different_gpus_when_two_are_visible(oracle):
+    """the native entry's peer-copy branch with src != dst (jpezy_capi_multi.hip: hipMemcpyPeerAsync from a non-root lane's slot into
+    devices[0]'s memory) and the host delivery of two lanes over two PCIe links: results equal to the oracle's, lane statistics name two
+    devices.  No one-GPU box can run this: skipped there -- the first multi-GPU box that runs the suite is its first execution."""
+    import torch
+    import jpezy_amd as J
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one GPU visible: traffic between two different GPUs needs two (tests/test_gpu_multi.py runs the lanes on one device)")
+    W, H, F = 256, 80, 13
+    frames = [oracle.synth_rgb(W, H, frame=7000 + f) for f in range(F)]
+    planes = [np.concatenate([fr[k] for fr in frames]) for k in range(3)]
+    want = np.stack([oracle.encode_coeffs(*fr, W, H) for fr in frames])
+    with J.MultiEncoder([0, 1], W, H, chunk_frames=2) as M:
+        for on_root in (True, False):
+            co, jpg = M.encode(*planes, F, want_coeffs=True, on_root_device=on_root)
+            assert np.array_equal(co.reshape(want.shape), want), on_root
+            for f in range(F):
+                assert jpg[f] == oracle.write_jpeg(want[f], W, H, False), (f, on_root)
+            st = M.stats()
+            assert [s_["device"] for s_ in st] == [0, 1] and [s_["frames"] for s_ in st] == [7, 6]
+    with J.MultiEncoder([1, 0], W, H) as M:                                # the root need not be device 0
+        co, jpg = M.encode(*planes, F, want_coeffs=True, on_root_device=True)
+        assert np.array_equal(co.reshape(want.shape), want)
+
+
 @pytest.mark.parametrize("W,H,gray,band_rows", [(4096, 4096, False, 32), (7680, 4320, True, 17), (1000, 530, False, 5)])
 def test_one_frame_split_by_mcu_row_bands_on_the_gpu(oracle, W, H, gray, band_rows):
     """configs[1] / [4] as ONE frame cut into MCU-row bands (jpezy_amd.sharding.encode_frame_banded, the N > 1 form of a single

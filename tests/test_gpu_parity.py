@@ -531,11 +531,18 @@ def test_bench_line_survives_a_failing_batch_leg_and_carries_the_other_workloads
         assert ow[k]["ms_per_step"] > 0 and 0 < ow[k]["roofline"]["frac"] < 1 and ow[k]["kernel"]
         assert abs(ow[k]["roofline"]["frac"] - ow[k]["roofline"]["achieved"] / 8000.0) < 1e-3
     assert ow["decode4096_tolerant"]["ms_per_step"] < ow["decode4096"]["ms_per_step"] * 1.05
-    # round 5: the native multi-GPU entry of the C-ABI timed by the same run (one device here: one shard, and two shards on it)
+    # rounds 5 / 6: the native multi-GPU entry of the C-ABI timed by the same run on a handle created outside the bracket (one device
+    # here: one lane, two lanes on it, the caller's planes pinned, and round 5's one-shot shape), against a pinned hipMemcpy of this run
     nm = d["native_multi_gpu"]
-    for k in ("devices_1", "two_shards_on_one_device"):
+    assert nm["pcie_h2d_GBs_pinned_hipMemcpy"] > 5
+    for k in ("devices_1", "two_lanes_on_one_device", "devices_1_caller_pinned_planes"):
         assert "error" not in nm[k], nm[k]
         assert nm[k]["equal_to_single_frame_entry"] is True and nm[k]["Mpixels_per_s"] > 0
+        assert nm[k]["frames"] >= 256 * len(set(nm[k]["devices"])) and 0 < nm[k]["frac_of_pcie"] < 1.5
+        assert abs(nm[k]["GBs_h2d"] - 3 * 1920 * 1080 * nm[k]["frames"] / (nm[k]["ms"] * 1e-3) / 1e9) < 0.05 * nm[k]["GBs_h2d"]
+        assert all(0 < ln["kernel_ms"] <= ln["wall_ms"] for ln in nm[k]["lanes"])
+    assert [ln["staged"] for ln in nm["devices_1"]["lanes"]] == [1] and [ln["staged"] for ln in nm["devices_1_caller_pinned_planes"]["lanes"]] == [0]
+    assert nm["one_shot_16_frames"]["equal_to_single_frame_entry"] is True
 
 
 def test_bench_decode4096_jpg_line():

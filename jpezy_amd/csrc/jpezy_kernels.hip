@@ -100,13 +100,6 @@ constexpr int WAVE_LDS_DWORDS = TILE_DWORDS + 64;   // 9728 B per wave, 38912 B 
 // directions conflict-free), the chroma tile unpadded rows (64 instead of 80).  Model: 456 -> 324 cycles per wave;
 // counters (profiles/r02e_ab_decode.txt): SQ_LDS_BANK_CONFLICT 219 -> 104, SQ_LDS_IDX_ACTIVE 487 -> 371 per wave -- and
 // 39.5 -> 39.3 us: the kernel is not bound by its LDS traffic.
-// JPEZY_DEC_LDSDMA (round 6 A/B): the coefficient quad goes to LDS by LDS-DMA (global_load_lds_dwordx4: no
-// registers, no ds_write_b128).  The DMA image is lane-linear, so the staged blocks are 128 bytes apart; what the 144-byte pitch
-// did for the zig-zag column reads is done by a swizzle on the SOURCE side: 16-byte part j of a block of MCU m lies at part
-// j ^ (5m & 7) (tools/profile/lds_bank_model.py: 84 LDS cycles per wave for the 24 column reads against 108 with the pitch, 192 plain).
-#ifndef JPEZY_DEC_LDSDMA
-#define JPEZY_DEC_LDSDMA 0
-#endif
 #ifdef JPEZY_DEC_LDS_R01     // round-1 geometry, kept for A/B counters (tools/ab/ab_build.py)
 constexpr int DH_PITCH = 20, DH_MCU = 16 * DH_PITCH + 16;                    // 336
 constexpr int DC_PITCH = 20, DC_COMP = 8 * DC_PITCH, DC_MCU = 2 * DC_COMP + 16;
@@ -115,7 +108,7 @@ constexpr int DSTG_PITCH = 128;               // bytes per staged block
 constexpr int DH_PITCH = 20;                  // 8 doubles + 2 pad
 constexpr int DH_MCU = 16 * DH_PITCH + 8;     // 328
 constexpr int DC_PITCH = 16, DC_COMP = 8 * DC_PITCH, DC_MCU = 2 * DC_COMP + 8;    // 16 / 128 / 264
-constexpr int DSTG_PITCH = JPEZY_DEC_LDSDMA ? 128 : 144;
+constexpr int DSTG_PITCH = 144;
 #endif
 constexpr int TF_PITCH = 16, TF_MCU = 16 * TF_PITCH + 8;   // tolerance mode: the luma tile as floats, 4 x 264 dwords
 constexpr int DEC_TILE_DWORDS = 4 * 336;      // 1344 dwords = 5376 B
@@ -661,9 +654,6 @@ __global__ __launch_bounds__(64 * WPB, GRAY ? JPEZY_DEC_WAVES_GRAY : JPEZY_DEC_W
 #else
         zp[v] = c_zzinv[v * 8 + u];
 #endif
-#if JPEZY_DEC_LDSDMA
-        zp[v] ^= (unsigned char)(((5 * m) & 7) << 3);        // the part swizzle of this lane's MCU, in int16 units (16 bytes = 8 coefficients)
-#endif
     }
 
     // ---- 1. coalesced load of the quad's 3 KB of coefficients into the staging area ----
@@ -673,21 +663,6 @@ __global__ __launch_bounds__(64 * WPB, GRAY ? JPEZY_DEC_WAVES_GRAY : JPEZY_DEC_W
         const int valid_mcus = min(4, p.mcu_cols - quad_x * 4);
         const int valid_bytes = valid_mcus * BPM * 128;
         const uint4* g4 = reinterpret_cast<const uint4*>(gbase);
-#if JPEZY_DEC_LDSDMA
-        {
-            typedef __attribute__((address_space(1))) const void* gptr;
-            typedef __attribute__((address_space(3))) void* lptr;
-            char* stg = reinterpret_cast<char*>(lds);
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const int c = k * 64 + lane, b = c >> 3, j = c & 7;          // LDS position: block b, part j  <-  source part j ^ s(b)
-                const int src = b * 8 + (j ^ ((5 * (b / 6)) & 7));
-                const bool want = (!GRAY || (unsigned)(b % 6) < 4u) && src * 16 < valid_bytes;
-                if (want) __builtin_amdgcn_global_load_lds((gptr)(g4 + src), (lptr)(stg + k * 1024), 16, 0, 0);
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-#else
         // all three loads are issued before the first one is waited for (one memory latency per wave, not three)
         uint4 v[3];
         // --gray never looks at the chroma blocks (blocks 4 and 5 of every MCU: a third of the coefficients): their 16-byte pieces are
@@ -713,7 +688,6 @@ __global__ __launch_bounds__(64 * WPB, GRAY ? JPEZY_DEC_WAVES_GRAY : JPEZY_DEC_W
             const int c = k * 64 + lane;              // 16-byte chunk: block c >> 3, part c & 7
             if (wanted[k]) *reinterpret_cast<uint4*>(reinterpret_cast<char*>(lds) + (c >> 3) * DSTG_PITCH + (c & 7) * 16) = v[k];
         }
-#endif
     }
     wave_sync();
 

@@ -270,11 +270,6 @@ __global__ __launch_bounds__(WG) void code_tiles_kernel(Job job, uint32_t* S, ui
 {
     __shared__ LdsTables L;
     __shared__ __attribute__((aligned(16))) char tile[WG * ROW];
-#ifdef JPEZY_ENT_LDS_PAD     // occupancy probe (results unchanged): JPEZY_ENT_LDS_PAD more bytes of LDS per workgroup -> fewer resident workgroups
-    __shared__ char occ_pad[JPEZY_ENT_LDS_PAD];
-    if (job.n_frames < 0) occ_pad[threadIdx.x] = 1;
-    asm volatile("" :: "v"((unsigned)(uintptr_t)occ_pad) : "memory");
-#endif
     load_tables(L, job.tables);
     const unsigned tid = threadIdx.x, frame = blockIdx.y;
     const unsigned nblk = job.blocks_per_frame, g0 = blockIdx.x * (unsigned)WG;

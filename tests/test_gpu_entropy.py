@@ -79,6 +79,30 @@ def test_stress_coefficients_match_host_writer_and_oracle(J, ctx, oracle, size):
     assert ctx.write_jpeg_gpu(_dev(co), W, H, comment=b"")[0] == J.write_jpeg(co, W, H, False, comment=b"")
 
 
+@pytest.mark.parametrize("gray", [False, True])
+def test_narrow_and_wide_tiles_in_one_launch(J, ctx, gray):
+    """tiles (256 coded blocks) of small values next to tiles with ONE large value somewhere (first block, last block, DC, position 63),
+    dense blocks of +-127 whose private stream outgrows its row (re-coded by the direct writer), values at the int8 limits.  Written for
+    round 6's int8-row coder (rejected: profiles/r06_entropy.txt), kept because it drives the shipped coder through every hand-over
+    between short and long block streams inside one launch"""
+    W, H = 1024, 512                                  # 2048 MCUs = 12288 coded blocks = 48 tiles of 256
+    bpm = 4 if gray else 6
+    rng = np.random.default_rng(606 + gray)
+    co = rng.integers(-3, 4, (32, 64, bpm, 64)).astype(np.int16)
+    co[..., 20:] *= (rng.random((32, 64, bpm, 44)) < 0.2)
+    flat = co.reshape(-1, 64)                          # stored blocks in scan order
+    nb = flat.shape[0]
+    per_tile = 256 * bpm // 6 if gray else 256         # stored blocks per tile (gray: 4 of every 6 coded blocks are stored)
+    for t, (where, pos, val) in enumerate([(0, 0, 128), (per_tile - 1, 63, -129), (5, 17, 1023), (100, 1, -1023), (7, 0, -128), (9, 5, 127)]):
+        flat[(3 * t + 1) * per_tile + where, pos] = val
+    dense = rng.integers(-127, 128, (40, 64)).astype(np.int16)
+    dense[dense == 0] = 99
+    flat[20 * per_tile + 30: 20 * per_tile + 70] = dense       # 40 blocks of ~180 bytes each inside one narrow tile
+    flat[nb - 1, 63] = -128                                     # the frame's last coefficient at the int8 limit
+    want = J.write_jpeg(co, W, H, gray)
+    assert ctx.write_jpeg_gpu(_dev(co), W, H, gray=gray)[0] == want
+
+
 def test_byte_stuffing_heavy_stream(J, ctx):
     co = np.zeros((4, 4, 6, 64), np.int16)
     co[..., 0] = -1023

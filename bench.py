@@ -566,8 +566,8 @@ def measure_native_multi(J, ctx, n_dev, frames_per_dev=256, max_frames=1024):
     pcie = _pinned_h2d_GBs(torch, torch.device("cuda", 0))
     res = {"workload": f"{W}x{H} frames, host planes -> .jpg files in host memory (PCIe inclusive), jpezy_multi_encode on a handle created "
                        "outside the bracket; planes are pageable numpy memory (staged through the lanes' pinned rings) unless a layout says pinned",
-           "entry": "include/jpezy_hip.h: jpezy_multi_create / jpezy_multi_encode (one host process; per device a context, a ring of 6 pinned + "
-                    "device slots, 4 feeder and 2 drainer threads)",
+           "entry": "include/jpezy_hip.h: jpezy_multi_create / jpezy_multi_encode (one host process; per device a context, a ring of 8 pinned + "
+                    "device slots, feeder threads as the host's cores allow (2..6 per device) and 2 drainer threads)",
            "pcie_h2d_GBs_pinned_hipMemcpy": round(pcie, 1),
            "never_run_on_two_different_gpus_by_the_builder": True}
     ref = ctx.encode_jpeg(base[0][1], base[1][1], base[2][1], W, H)
@@ -599,12 +599,13 @@ def measure_native_multi(J, ctx, n_dev, frames_per_dev=256, max_frames=1024):
             st = (api.MultiLaneStats * len(devs))()
             lib.jpezy_multi_last_stats(h, st, len(devs))
             chunk = lib.jpezy_multi_chunk_frames(h)
+            feeders = lib.jpezy_multi_feeder_threads(h)
         finally:
             lib.jpezy_multi_destroy(h)
         ok = all(sizes[f] == len(ref) and jpg[f * stride: f * stride + sizes[f]].tobytes() == ref for f in (1, F - 3))   # copies of base frame 1
         up = 3 * plane * F
         per_dev_gbs = up / len(set(devs)) / dt / 1e9
-        res[name] = {"devices": devs, "frames": F, "chunk_frames": chunk, "calls_timed": reps, "ms": round(dt * 1e3, 2),
+        res[name] = {"devices": devs, "frames": F, "chunk_frames": chunk, "feeder_threads_per_lane": feeders, "calls_timed": reps, "ms": round(dt * 1e3, 2),
                      "ms_min_max": [round(min(times) * 1e3, 2), round(max(times) * 1e3, 2)],
                      "Mpixels_per_s": round(F * plane / dt / 1e6, 1), "GBs_h2d": round(up / dt / 1e9, 2),
                      "GBs_h2d_per_device": round(per_dev_gbs, 2), "frac_of_pcie": round(per_dev_gbs / pcie, 3),

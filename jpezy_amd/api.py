@@ -88,6 +88,8 @@ ABI = [
     ("jpezy_multi_encode", C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_char_p, C.POINTER(MultiOut)]),
     ("jpezy_multi_last_stats", C.c_int, [_vp, C.POINTER(MultiLaneStats), C.c_int]),
     ("jpezy_multi_chunk_frames", C.c_int, [_vp]),
+    ("jpezy_multi_feeder_threads", C.c_int, [_vp]),
+    ("jpezy_multi_set_feeder_threads", C.c_int, [_vp, C.c_int]),
     ("jpezy_read_jpeg", C.c_int, [_vp, C.c_size_t, C.POINTER(FrameInfo), _vp, C.c_size_t]),
     ("jpezy_read_jpeg_gpu", C.c_int, [_vp, _vp, C.c_size_t, C.POINTER(FrameInfo), _vp, C.c_size_t]),
     ("jpezy_decode_jpeg", C.c_int, [_vp, _vp, C.c_size_t, C.c_int, C.POINTER(FrameInfo), _vp, _vp, _vp, C.c_size_t]),
@@ -505,6 +507,11 @@ class MultiEncoder:
         if not self._h:
             raise JpezyError(lib.jpezy_hip_last_error().decode(errors="replace"))
         self.chunk_frames = lib.jpezy_multi_chunk_frames(self._h)
+        self.feeder_threads = lib.jpezy_multi_feeder_threads(self._h)
+
+    def set_feeder_threads(self, n):
+        _check(load_library().jpezy_multi_set_feeder_threads(self._h, int(n)))
+        self.feeder_threads = int(n)
 
     def encode(self, r, g, b, n_frames, comment=None, want_coeffs=False, want_jpg=True, on_root_device=False, jpg_stride=None, raw=False):
         lib = load_library()

@@ -30,7 +30,7 @@
 
 namespace {
 
-constexpr int RING = 6, N_FEED = 4, N_DRAIN = 2;
+constexpr int RING = 8, MAX_FEED = 6, N_DRAIN = 2;
 
 struct Job {                            // one jpezy_multi_encode call
     const uint8_t* src[3] = {};
@@ -69,6 +69,7 @@ struct Lane {
 struct jpezy_multi {
     std::vector<int> devices;
     int W = 0, H = 0, gray = 0, chunk = 1;
+    int n_feed = 4;                             // feeder threads per lane: a core copies ~11 GB/s into pinned memory, the link takes ~50
     size_t plane = 0, cpf = 0, bound = 0;       // bytes of a plane, int16 elements of a frame's coefficients, jpezy_jpeg_bound rounded to 16
     std::vector<std::unique_ptr<Lane>> lanes;
 };
@@ -182,7 +183,7 @@ void run_lane(const jpezy_multi& M, Lane& L, const Job& J)
     const auto t_begin = std::chrono::steady_clock::now();
     const int chunk = M.chunk;
     const int n_chunks = (int)((L.nf + chunk - 1) / chunk);
-    const int root_dev = M.devices[0], ring = L.ring;
+    const int root_dev = M.devices[0], ring = L.ring, n_feed = M.n_feed;
     const bool to_root = J.out.on_root_device != 0;
     const bool in_place = to_root && L.index == 0;                      // the root lane writes its results where they belong
     const bool want_jpg = J.out.jpg != nullptr, want_coef = J.out.coeffs != nullptr;
@@ -225,7 +226,7 @@ void run_lane(const jpezy_multi& M, Lane& L, const Job& J)
 
     auto feeder = [&](int id) {
         R_TRY(hipSetDevice(L.dev));
-        for (int c = id; c < n_chunks && !R.failed.load(); c += N_FEED) {
+        for (int c = id; c < n_chunks && !R.failed.load(); c += n_feed) {
             Slot& sl = L.slot[c % ring];
             if (c >= ring) {                                            // the slot's input buffers are free once the kernels of the chunk that used them last have run
                 if (!R.wait(c - ring, 2)) return;
@@ -318,9 +319,9 @@ void run_lane(const jpezy_multi& M, Lane& L, const Job& J)
     std::vector<std::thread> threads;
     {
         Joiner joiner{ threads, [&] { R.fail(JPEZY_E_HIP, "unexpected exception in the lane thread"); } };
-        threads.reserve(N_FEED + N_DRAIN);
+        threads.reserve((size_t)(n_feed + N_DRAIN));
         try {
-            for (int k = 0; k < std::min(N_FEED, n_chunks); ++k) threads.emplace_back(feeder, k);
+            for (int k = 0; k < std::min(n_feed, n_chunks); ++k) threads.emplace_back(feeder, k);
             for (int k = 0; k < std::min(N_DRAIN, n_chunks); ++k) threads.emplace_back(drainer, k);
         } catch (const std::exception&) {
             R.fail(JPEZY_E_HIP, "starting a copy thread failed");
@@ -425,6 +426,10 @@ jpezy_multi* multi_create(const int* devices, int n_dev, int W, int H, int gray,
     M->cpf = jpezy_coeff_count(W, H, gray);
     M->bound = (jpezy_jpeg_bound(W, H) + 15) & ~(size_t)15;
     M->chunk = chunk_frames > 0 ? chunk_frames : default_chunk(M->plane);
+    {   // feeders: what the host's cores allow when every lane runs its own (a lane also has its thread and two drainers)
+        const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+        M->n_feed = (int)std::min<unsigned>(MAX_FEED, std::max<unsigned>(2, hw / (2u * (unsigned)n_dev)));
+    }
     if (frames_hint > 0) {                              // one-shot form: no ring slot larger than the largest shard
         const long largest = (frames_hint + n_dev - 1) / n_dev;
         M->chunk = (int)std::max<long>(1, std::min<long>(M->chunk, largest));
@@ -488,6 +493,14 @@ void jpezy_multi_destroy(jpezy_multi* m)
 }
 
 int jpezy_multi_chunk_frames(const jpezy_multi* m) { return m ? m->chunk : 0; }
+int jpezy_multi_feeder_threads(const jpezy_multi* m) { return m ? m->n_feed : 0; }
+int jpezy_multi_set_feeder_threads(jpezy_multi* m, int n)
+{
+    if (!m) return set_err(JPEZY_E_BADARG, "multi_set_feeder_threads: null handle");
+    if (n < 1 || n > MAX_FEED) return set_err(JPEZY_E_BADARG, "multi_set_feeder_threads: 1.." + std::to_string(MAX_FEED));
+    m->n_feed = n;
+    return JPEZY_OK;
+}
 
 int jpezy_multi_encode(jpezy_multi* m, const uint8_t* r, const uint8_t* g, const uint8_t* b, int n_frames, const char* comment,
                        const jpezy_multi_out* out)

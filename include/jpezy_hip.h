@@ -242,8 +242,8 @@ long jpezy_encode_jpeg(jpezy_ctx* ctx, const uint8_t* r, const uint8_t* g, const
  * jpezy_multi_create / jpezy_multi_encode / jpezy_multi_destroy: encoder::encode (encoder/jpezy_encoder.hpp:38-77) for n_frames
  * independent frames of one size, i.e. the loop a caller of the reference runs over encoder objects, spread over the n_dev GPUs
  * devices[0..n_dev) of this node; devices[0] is the ROOT (the calling thread drives it, one more host thread per further device).
- * The HANDLE owns, per entry of devices (a "lane"): a context, an upload stream, download streams and a ring of eight slots, each a pinned
- * host buffer + a device buffer per direction, sized for chunk_frames frames (<= 0: about 16 MB of planes per chunk: 2 frames of 1080p,
+ * The HANDLE owns, per entry of devices (a "lane"): a context, an upload stream, download streams and a ring of six slots, each a pinned
+ * host buffer + a device buffer per direction, sized for chunk_frames frames (<= 0: about 28 MB of planes per chunk: 4 frames of 1080p,
  * one 4096^2 frame).  Nothing is allocated inside jpezy_multi_encode once the handle has served one call of the same shape, so a caller
  * with a stream of batches creates it once.  A call shards its frames over the lanes (jpezy_shard_range, any n_frames > 0, it may change
  * from call to call) and every lane streams its shard through its ring: feeder threads copy the caller's planes into pinned slots and
@@ -272,7 +272,7 @@ long jpezy_encode_jpeg(jpezy_ctx* ctx, const uint8_t* r, const uint8_t* g, const
  * events), bytes uploaded and brought back, whether the planes were staged (1) or were the caller's pinned memory (0); returns the
  * number of lanes, fills at most cap entries.  jpezy_multi_chunk_frames: the chunk size the handle settled on.
  * jpezy_multi_feeder_threads / jpezy_multi_set_feeder_threads: the staging threads per lane (a core copies ~11 GB/s into pinned
- * memory, a PCIe link takes ~50: the default is what the host's cores allow when every lane runs its own, between 2 and 6; tuning knob).
+ * memory, a PCIe link takes ~50: the default is what the host's cores allow when every lane runs its own, between 2 and 4 -- three keep a link busy; 1..6; tuning knob).
  *
  * jpezy_encode_batch_multi: the one-shot form (create, one call, destroy; chunk_frames is clamped to the largest shard so that a
  * single large frame does not reserve a ring for sixteen) -- what jpezy_encode --gpus N calls.

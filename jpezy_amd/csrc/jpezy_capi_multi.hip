@@ -30,7 +30,7 @@
 
 namespace {
 
-constexpr int RING = 8, MAX_FEED = 6, N_DRAIN = 2;
+constexpr int RING = 6, MAX_FEED = 6, DEFAULT_FEED = 4, N_DRAIN = 2;
 
 struct Job {                            // one jpezy_multi_encode call
     const uint8_t* src[3] = {};
@@ -409,11 +409,13 @@ int check_out(const jpezy_multi_out* out, const char* who)
     return JPEZY_OK;
 }
 
-// frames per chunk when the caller does not say: about 16 MB of planes (1080p: 2 frames, 4096^2: 1) -- long enough for the DMA engines,
-// short enough that a ring of RING slots is ~100 MB of pinned memory per lane
+// frames per chunk when the caller does not say: about 28 MB of planes (1080p: 4 frames, 4096^2: 1).  tools/measure/native_multi_sweep.py
+// on one device, 256 frames 1080p, GB/s of upload by (frames per chunk, feeder threads): 1 frame 39-40 whatever the feeders; 2 frames 42 / 47 /
+// 47 with 2 / 3 / 4 feeders; 4 frames 42.7 / 49.3 / 49.2; 8 frames 49.4 / 48.6 / 47.5 -- against 50.3 for a pinned hipMemcpy
+// (profiles/r06_native_multi_sweep.txt).  Three feeders keep a link busy; a ring of RING slots of that size is ~150 MB of pinned memory per lane.
 int default_chunk(size_t plane)
 {
-    const size_t per = ((size_t)16 << 20) / std::max<size_t>(3 * plane, 1);
+    const size_t per = ((size_t)28 << 20) / std::max<size_t>(3 * plane, 1);
     return (int)std::min<size_t>(std::max<size_t>(per, 1), 64);
 }
 
@@ -428,7 +430,7 @@ jpezy_multi* multi_create(const int* devices, int n_dev, int W, int H, int gray,
     M->chunk = chunk_frames > 0 ? chunk_frames : default_chunk(M->plane);
     {   // feeders: what the host's cores allow when every lane runs its own (a lane also has its thread and two drainers)
         const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-        M->n_feed = (int)std::min<unsigned>(MAX_FEED, std::max<unsigned>(2, hw / (2u * (unsigned)n_dev)));
+        M->n_feed = (int)std::min<unsigned>(DEFAULT_FEED, std::max<unsigned>(2, hw / (2u * (unsigned)n_dev)));
     }
     if (frames_hint > 0) {                              // one-shot form: no ring slot larger than the largest shard
         const long largest = (frames_hint + n_dev - 1) / n_dev;

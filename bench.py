@@ -567,7 +567,7 @@ def measure_native_multi(J, ctx, n_dev, frames_per_dev=256, max_frames=1024):
     res = {"workload": f"{W}x{H} frames, host planes -> .jpg files in host memory (PCIe inclusive), jpezy_multi_encode on a handle created "
                        "outside the bracket; planes are pageable numpy memory (staged through the lanes' pinned rings) unless a layout says pinned",
            "entry": "include/jpezy_hip.h: jpezy_multi_create / jpezy_multi_encode (one host process; per device a context, a ring of 6 pinned + "
-                    "device slots, feeder threads as the host's cores allow (2..4 per device) and 2 drainer threads)",
+                    "device slots, feeder threads as the host's cores allow (2..4 per device) and 2 drainer threads (as many as feeders when coefficients go back to host memory))",
            "pcie_h2d_GBs_pinned_hipMemcpy": round(pcie, 1),
            "never_run_on_two_different_gpus_by_the_builder": True}
     ref = ctx.encode_jpeg(base[0][1], base[1][1], base[2][1], W, H)

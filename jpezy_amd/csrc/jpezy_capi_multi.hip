@@ -30,7 +30,7 @@
 
 namespace {
 
-constexpr int RING = 6, MAX_FEED = 6, DEFAULT_FEED = 4, N_DRAIN = 2;
+constexpr int RING = 6, MAX_FEED = 6, DEFAULT_FEED = 4, MAX_DRAIN = 4;
 
 struct Job {                            // one jpezy_multi_encode call
     const uint8_t* src[3] = {};
@@ -53,7 +53,7 @@ struct Slot {
 struct Lane {
     int index = 0, dev = 0;
     jpezy_ctx* ctx = nullptr;
-    hipStream_t s_up = nullptr, s_down[N_DRAIN] = {};
+    hipStream_t s_up = nullptr, s_down[MAX_DRAIN] = {};
     Slot slot[RING];
     int ring = RING;                    // slots in use (the one-shot form of a small batch builds no more than its chunks need)
     bool peer_enabled = false;
@@ -189,6 +189,13 @@ void run_lane(const jpezy_multi& M, Lane& L, const Job& J)
     const bool want_jpg = J.out.jpg != nullptr, want_coef = J.out.coeffs != nullptr;
     // bytes reserved per file in a slot's device buffer: never more than the caller gives a file (a longer one is refused anyway)
     const size_t dstride = std::min(M.bound, (J.out.jpg_stride + 15) & ~(size_t)15);
+    // drainers: two bring a tenth of the upload's bytes back (.jpg files); coefficients to host memory are as many bytes as the planes
+    // and want as many copying threads as the way up
+#ifdef JPEZY_MULTI_FIXED_DRAIN       // A/B builds (tools/ab/ab_build.py)
+    const int n_drain = JPEZY_MULTI_FIXED_DRAIN;
+#else
+    const int n_drain = want_coef && !to_root ? std::min(MAX_DRAIN, std::max(2, n_feed)) : 2;
+#endif
     L.stats = {};
     L.stats.device = L.dev;
     L.stats.frames = L.nf;
@@ -254,7 +261,7 @@ void run_lane(const jpezy_multi& M, Lane& L, const Job& J)
     auto drainer = [&](int id) {
         R_TRY(hipSetDevice(L.dev));
         hipStream_t sd = L.s_down[id];
-        for (int c = id; c < n_chunks && !R.failed.load(); c += N_DRAIN) {
+        for (int c = id; c < n_chunks && !R.failed.load(); c += n_drain) {
             Slot& sl = L.slot[c % ring];
             if (!R.wait(c, 2)) return;
             R_TRY(hipEventSynchronize(sl.ev_k));                        // the chunk's kernels are done, its sizes are in pin_sizes
@@ -319,10 +326,10 @@ void run_lane(const jpezy_multi& M, Lane& L, const Job& J)
     std::vector<std::thread> threads;
     {
         Joiner joiner{ threads, [&] { R.fail(JPEZY_E_HIP, "unexpected exception in the lane thread"); } };
-        threads.reserve((size_t)(n_feed + N_DRAIN));
+        threads.reserve((size_t)(n_feed + n_drain));
         try {
             for (int k = 0; k < std::min(n_feed, n_chunks); ++k) threads.emplace_back(feeder, k);
-            for (int k = 0; k < std::min(N_DRAIN, n_chunks); ++k) threads.emplace_back(drainer, k);
+            for (int k = 0; k < std::min(n_drain, n_chunks); ++k) threads.emplace_back(drainer, k);
         } catch (const std::exception&) {
             R.fail(JPEZY_E_HIP, "starting a copy thread failed");
         }

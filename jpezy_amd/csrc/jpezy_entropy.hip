@@ -129,11 +129,13 @@ __device__ __forceinline__ void code_ac(uint32_t m, int base, const int16_t* z, 
     }
 }
 
-// the block's non-zero masks (bit 31 - n of mhi: position n in 0..31 is non-zero -- position 0, the DC, excluded; mlo likewise for
-// 32..63) and its DC value; z == nullptr: an all-zero block
-__device__ __forceinline__ void block_masks(const int16_t* z, uint32_t& mhi, uint32_t& mlo, int& dcv)
+template <class W>
+__device__ __forceinline__ bool code_block(const int16_t* z, int pred, const uint32_t* dc, const uint32_t* ac, const uint32_t* fast, W& w)
 {
-    mhi = 0; mlo = 0; dcv = 0;
+    unsigned amax = 0;
+    bool ok = true;
+    uint32_t mhi = 0, mlo = 0;          // bit (31 - n) of mhi: position n in 0..31 is non-zero; mlo likewise for 32..63
+    int dcv = 0;
     if (z) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
@@ -150,14 +152,6 @@ __device__ __forceinline__ void block_masks(const int16_t* z, uint32_t& mhi, uin
         }
         mhi &= 0x7FFFFFFFu;             // position 0 is the DC
     }
-}
-
-template <class W>
-__device__ __forceinline__ bool code_block_masked(const int16_t* z, uint32_t mhi, uint32_t mlo, int dcv, int pred, const uint32_t* dc,
-                                                  const uint32_t* ac, const uint32_t* fast, W& w)
-{
-    unsigned amax = 0;
-    bool ok = true;
     {
         const int diff = dcv - pred;
         const unsigned a = (unsigned)(diff < 0 ? -diff : diff);
@@ -180,15 +174,6 @@ __device__ __forceinline__ bool code_block_masked(const int16_t* z, uint32_t mhi
         w.put(e >> 8, (int)(e & 0xFF));
     }
     return ok && amax <= 1023u;
-}
-
-template <class W>
-__device__ __forceinline__ bool code_block(const int16_t* z, int pred, const uint32_t* dc, const uint32_t* ac, const uint32_t* fast, W& w)
-{
-    uint32_t mhi, mlo;
-    int dcv;
-    block_masks(z, mhi, mlo, dcv);
-    return code_block_masked(z, mhi, mlo, dcv, pred, dc, ac, fast, w);
 }
 
 constexpr int CHUNK = 64;   // bytes of the unstuffed stream U per thread of the 0xFF counting / stuffing kernels
@@ -214,9 +199,6 @@ __device__ __forceinline__ unsigned count_ff(uint32_t x)
 // Tile streams are MSB-first uint32 words, zero padded to a word.  assemble_kernel then forms the frame's unstuffed stream
 // U output-driven (one thread per 64-byte chunk: funnel shifts across tile borders, byte order swapped on the way out) and
 // counts the 0xFF bytes of its chunk while it has them.
-#ifndef JPEZY_ENT_SORT
-#define JPEZY_ENT_SORT 0          // 1: the tile's blocks are dealt to the lanes sorted by their number of non-zero coefficients (round 6 A/B)
-#endif
 constexpr int WG = 256;                                          // coded blocks per workgroup ("tile")
 constexpr int ROW = 144, ROW_DATA = 16, ROW_LAST_WORD = 34;      // private stream: words 0..34; word 35 (bytes 140..143): its length
 constexpr unsigned TILE_STREAM_WORDS = 256 * 208 / 4;            // worst case of 208 bytes per block
@@ -328,64 +310,6 @@ __global__ __launch_bounds__(WG) void code_tiles_kernel(Job job, uint32_t* S, ui
     uint32_t* const row = reinterpret_cast<uint32_t*>(tile + tid * ROW);
     unsigned n = 0;
     bool ovf = false;
-#if JPEZY_ENT_SORT
-    // The coding loop runs as long as the wave's FULLEST block has non-zero coefficients (code_ac): in scan order a wave mixes luma
-    // blocks (21 non-zero AC coefficients on noise) with chroma blocks (7) and busy with flat ones.  So the blocks are dealt to the lanes
-    // SORTED by their number of non-zero coefficients: lane `tid` builds the masks of block `tid` (its row), a counting sort over the 64
-    // possible counts ranks the tile's blocks, and lane s then codes the block of rank s -- in that block's own row, in place, as
-    // before; everything after the coding (lengths, scan, shift-copy, tails) is by block position again.  On noise a wave's loop
-    // falls from 27.2 to 19.7 iterations (mean 16.6).  The masks travel in the row's head (bytes 0..15 are the stream's head start:
-    // the coding lane reads them before it writes its first word).
-    __shared__ unsigned sort_hist[64], sort_base[64];
-    __shared__ unsigned char sort_perm[WG], row_ovf[WG];
-    if (tid < 64) sort_hist[tid] = 0;
-    __syncthreads();
-    unsigned key = 63, in_bucket = 0;
-    if (valid) {
-        uint32_t mhi, mlo;
-        int dcv;
-        block_masks(zg ? reinterpret_cast<const int16_t*>(tile + tid * ROW + ROW_DATA) : nullptr, mhi, mlo, dcv);
-        key = 63u - (unsigned)(__builtin_popcount(mhi) + __builtin_popcount(mlo));          // fullest first
-        in_bucket = atomicAdd(&sort_hist[key], 1u);
-        row[0] = mhi; row[1] = mlo;
-        row[2] = ((uint32_t)dcv & 0xFFFFu) | ((uint32_t)pred << 16);
-        row[3] = (uint32_t)table | (zg ? 2u : 0u);
-    }
-    __syncthreads();
-    if (tid < 64) {                          // exclusive scan of the 64 bucket sizes by the first wave
-        const unsigned v = sort_hist[tid];
-        unsigned inc = v;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const unsigned o = __shfl_up(inc, d, 64);
-            if ((int)tid >= d) inc += o;
-        }
-        sort_base[tid] = inc - v;
-    }
-    __syncthreads();
-    if (valid) sort_perm[sort_base[key] + in_bucket] = (unsigned char)tid;
-    __syncthreads();
-    if (valid) {
-        const unsigned p = sort_perm[tid];                   // the block this lane codes
-        uint32_t* const prow = reinterpret_cast<uint32_t*>(tile + p * ROW);
-        const uint32_t mhi = prow[0], mlo = prow[1], w2 = prow[2], w3 = prow[3];
-        const int ptab = (int)(w3 & 1u);
-        RowWriter w;
-        w.init(prow);
-        const bool ok = code_block_masked((w3 & 2u) ? reinterpret_cast<const int16_t*>(tile + p * ROW + ROW_DATA) : nullptr, mhi, mlo,
-                                          (int)(short)(w2 & 0xFFFFu), (int)w2 >> 16, L.dc[ptab], L.ac[ptab], L.fast[ptab], w);
-        const unsigned np = w.bits();
-        w.finish();
-        row_ovf[p] = w.overflowed() ? 1 : 0;
-        prow[ROW_LAST_WORD + 1] = np;
-        if (!ok) atomicOr(status + frame, 1u);
-    } else {
-        row[ROW_LAST_WORD + 1] = 0;
-    }
-    __syncthreads();
-    n = row[ROW_LAST_WORD + 1];
-    ovf = valid && row_ovf[tid] != 0;
-#else
     if (valid) {
         RowWriter w;
         w.init(row);
@@ -397,7 +321,6 @@ __global__ __launch_bounds__(WG) void code_tiles_kernel(Job job, uint32_t* S, ui
         if (!ok) atomicOr(status + frame, 1u);
     }
     row[ROW_LAST_WORD + 1] = n;            // where the owner of a partial word finds the length of the lanes after it
-#endif
     uint32_t total;
     const uint32_t o = wg256_exclusive_scan(n, &total);      // (barrier inside: rows and lengths are visible)
     const size_t t_index = (size_t)frame * gridDim.x + blockIdx.x;

@@ -138,6 +138,25 @@ def test_a_failing_call_leaves_the_handle_usable(J, ctx, oracle):
             M.encode(r[:-1], g, b, F)
 
 
+def test_512_frames_1080p_through_the_handle(J, ctx, oracle):
+    """a shard of BASELINE configs[3] as ONE call of the native handle (what one GPU of an 8-GPU run is handed): 512 frames 1920x1080 from
+    pageable host planes, two lanes on the one device, default chunking -- the rings wrap some sixty times; every file's size is checked,
+    a sample of frames byte for byte against the single-frame entry and the oracle, and the lanes' statistics must add up"""
+    W, H, F, distinct = 1920, 1080, 512, 8
+    base = [oracle.synth_rgb(W, H, frame=9000 + k) for k in range(distinct)]
+    planes = [np.ascontiguousarray(np.tile(np.stack([b[q] for b in base]), (F // distinct, 1))).reshape(-1) for q in range(3)]
+    want = [ctx.encode_jpeg(*base[k], W, H) for k in range(distinct)]
+    assert want[3] == oracle.write_jpeg(oracle.encode_coeffs(*base[3], W, H), W, H, False)
+    with J.MultiEncoder([0, 0], W, H) as M:
+        _, jpg = M.encode(*planes, F, jpg_stride=1 << 20)
+        st = M.stats()
+    assert len(jpg) == F and [len(j) for j in jpg] == [len(want[f % distinct]) for f in range(F)]
+    for f in (0, 1, 7, 8, 255, 256, 257, 300, 510, 511):
+        assert jpg[f] == want[f % distinct], f
+    assert [s_["frames"] for s_ in st] == [256, 256] and sum(s_["bytes_up"] for s_ in st) == 3 * W * H * F
+    assert sum(s_["bytes_down"] for s_ in st) == sum(len(j) for j in jpg)
+
+
 def test_the_callers_current_device_is_put_back(J, oracle):
     import ctypes as C
     import torch
